@@ -1,0 +1,79 @@
+/* pga_align.h -- the drop-in boundary, part 2: the native batch entry of libpgalign.so.
+ *
+ * One call aligns G independent all-vs-all GROUPS (one group = the block set of one `find_matches` call,
+ * reference: packages/pangraph/src/pangraph/graph_merging.rs:176-185 ->
+ * packages/pangraph/src/align/minimap2_lib/align_with_minimap2_lib.rs:15-85) and returns, per group, exactly the
+ * records `align_with_minimap2_lib` would build from minimap2's output (alignment.rs:13-57), in query order
+ * (ascending sequence index inside the group, then minimap2's own order inside a query).
+ * Plain pointers and sizes only; results are owned by the library until pga_result_free().
+ *
+ * Errors: negative return + pga_last_error() (thread-local string).  The library needs a gfx950 device; it has
+ * no CPU fallback.
+ */
+#ifndef PGA_ALIGN_H
+#define PGA_ALIGN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	int32_t sensitivity;         /* 5 | 10 | 20  -> minimap2 preset asm5/asm10/asm20 (align_with_minimap2_lib.rs:35-40) */
+	int32_t kmer_length;         /* <=0: preset default (-K, alignment_args.rs:33-35)                                  */
+	int32_t indel_len_threshold; /* -l; minimap2 -s = max(len-10, 5) (align_with_minimap2_lib.rs:47)                  */
+	int32_t n_threads;           /* host threads for CIGAR post-processing; <=0: all cores                           */
+} pga_params_t;
+
+/* One record == one `Alignment` (alignment.rs:40-57). */
+typedef struct {
+	int32_t group;               /* index of the group the record belongs to */
+	int32_t qry, ref;            /* sequence indices inside the group (-> Hit.name) */
+	int32_t qry_len, qry_start, qry_end;
+	int32_t ref_len, ref_start, ref_end;
+	int32_t matches, length, quality;  /* mlen, blen, mapq */
+	int32_t reverse;             /* 0 forward, 1 reverse (orientation) */
+	int32_t align;               /* AS = dp_score */
+	int32_t n_ambi, inv;
+	double divergence;           /* de = 1 - mm_event_identity (packages/minimap2/src/map.rs:320-325) */
+	uint64_t cigar_off;          /* first op in the CIGAR pool */
+	uint32_t n_cigar;            /* ops are len<<4|op, op in "MIDNSHP=XB" */
+	uint32_t pad;
+} pga_match_t;
+
+typedef struct pga_result_s pga_result_t;
+
+typedef struct {                 /* stage timings and work counters of the last call, seconds / counts */
+	double upload, sketch, index, seed, chain, align, total;
+	double n_bases, n_minimizers, n_anchors, n_dp_jobs, n_dp_cells, n_matches;
+} pga_stats_t;
+
+/* seqs: n_seqs sequences, ASCII, NOT necessarily NUL-terminated (lengths in seq_lens); names: NUL-terminated
+ * decimal BlockId strings (unique inside a group); group_off: n_groups+1 offsets into the sequence arrays. */
+int pga_align_groups(const pga_params_t *params, int32_t n_groups, const int64_t *group_off,
+                     const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_result_t **out);
+int64_t pga_result_n_matches(const pga_result_t *r);
+const pga_match_t *pga_result_matches(const pga_result_t *r);
+const uint32_t *pga_result_cigars(const pga_result_t *r, uint64_t *n_ops);
+const pga_stats_t *pga_result_stats(const pga_result_t *r);
+void pga_result_free(pga_result_t *r);
+const char *pga_last_error(void);
+/* number of visible HIP devices (<=0: none, the library cannot run) and selection of the one to use */
+int pga_device_count(void);
+int pga_set_device(int dev);
+
+/* Stage taps for parity tests (same semantics as the reference functions named in each comment). */
+/* mm_sketch (sketch.c:77): minimizers of n sequences; out arrays are malloc()ed, caller frees with pga_free */
+int pga_stage_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int w, int k, uint64_t **mz_xy, uint64_t **seq_off);
+/* collect_seed_hits + mg_lchain_rmq (map.c:168-204, lchain.c:250-368) of an all-vs-all group:
+ * anchors (x,y pairs) per query, chains u[] and compacted anchors per query, as flat malloc()ed arrays */
+int pga_stage_chain(const pga_params_t *params, int32_t n, const char *const *seqs, const uint32_t *lens, const char *const *names,
+                    uint64_t **anchors_xy, uint64_t **anchor_off, int32_t **n_u, int32_t **n_v, uint64_t **u, uint64_t **chain_xy, int32_t **rep_len, int32_t *mid_occ);
+/* ksw_extd2_sse (ksw2_extd2_sse.c:34) on explicit nt4 sequences; ez[12] = max,max_q,max_t,mqe,mqe_t,mte,mte_q,score,zdropped,reach_end,n_cigar,0 */
+int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const int32_t *qlen, const uint8_t *const *t, const int32_t *tlen,
+                    int a, int b, int sc_ambi, int gapo, int gape, int gapo2, int gape2, const int32_t *w, const int32_t *zdrop, const int32_t *end_bonus, const int32_t *flag,
+                    int32_t *ez, uint32_t **cigars, uint64_t *cigar_off);
+void pga_free(void *p);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,6 +23,8 @@
 #include <assert.h>
 #include "pgo.h"
 
+int pgo_dbg_tie_check = 0; long pgo_dbg_n_rmq = 0, pgo_dbg_n_tie = 0, pgo_dbg_n_inner = 0;
+
 typedef struct {
 	int32_t y;
 	int64_t i;
@@ -418,12 +420,24 @@ pg128 *pgo_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip
 		}
 		{
 			int32_t q = tree_rmq(&T, (int32_t)a[i].y - max_dist, INT32_MAX, (int32_t)a[i].y, 0);
+			if (pgo_dbg_tie_check && q >= 0) { /* debug: brute-force count of candidates tied with the returned minimum */
+				int64_t jj, n_tie = 0;
+				for (jj = st; jj < i0; ++jj) {
+					if (slot[jj] < 0) continue;
+					int32_t yj = (int32_t)a[jj].y;
+					if (yj <= (int32_t)a[i].y - max_dist || yj > (int32_t)a[i].y || (yj == (int32_t)a[i].y && jj > 0)) continue;
+					if (T.nd[slot[jj]].pri == T.nd[q].pri) ++n_tie;
+				}
+				++pgo_dbg_n_rmq;
+				if (n_tie > 1) ++pgo_dbg_n_tie;
+			}
 			if (q >= 0) {
 				int32_t sc, exact, width, n_skip = 0;
 				int64_t j = T.nd[q].i;
 				sc = f[j] + score_pair(&a[i], &a[j], chn_pen_gap, chn_pen_skip, &exact, &width);
 				if (width <= bw && sc > max_f) max_f = sc, max_j = j;
 				if (!exact && Ti.root >= 0 && (int32_t)a[i].y > 0) {
+					++pgo_dbg_n_inner;
 					iter_t it;
 					if (iter_seek_le(&Ti, (int32_t)a[i].y - 1, n, &it)) {
 						for (;;) {

@@ -1,0 +1,398 @@
+// pga_api.cpp -- the C-ABI of libpgalign.so and the host orchestration of one batch.
+//
+// Part 1 (include/pga_mm2_abi.h): the minimap2-sys symbols the reference's Rust crate binds.  pangraph always
+// queries exactly the sequences it indexed (align_with_minimap2_lib.rs:62-74), so mm_idx_str() uploads,
+// sketches and indexes the whole group on the GPU, the FIRST mm_map() against an index runs the complete
+// all-vs-all batch on the GPU (options only arrive with mm_map), and every mm_map() hands back its query's
+// records as malloc()ed mm_reg1_t[] exactly as minimap2 would (caller frees, packages/minimap2/src/map.rs:407-420).
+// Part 2 (include/pga_align.h): the native batch entry for a level-synchronous host.
+#include "pga_common.h"
+#include "pga_pipeline.h"
+#include "pga_dp.h"
+#include "../../include/pga_align.h"
+#include <chrono>
+#include <map>
+#include <thread>
+#include <climits>
+#include <cstdio>
+
+using namespace pga;
+
+static thread_local std::string g_err;
+static void set_err(const std::string &s) { g_err = s; }
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------- options (options.c)
+extern "C" void mm_idxopt_init(mm_idxopt_t *opt) // options.c:5-12
+{
+	memset(opt, 0, sizeof(*opt));
+	opt->k = 15, opt->w = 10, opt->flag = 0, opt->bucket_bits = 14;
+	opt->mini_batch_size = 50000000; opt->batch_size = 8000000000ULL;
+}
+extern "C" void mm_mapopt_init(mm_mapopt_t *o) // options.c:14-64
+{
+	memset(o, 0, sizeof(*o));
+	o->seed = 11; o->mid_occ_frac = 2e-4f; o->min_mid_occ = 10; o->max_mid_occ = 1000000; o->sdust_thres = 0; o->q_occ_frac = 0.01f;
+	o->min_cnt = 3; o->min_chain_score = 40; o->bw = 500; o->bw_long = 20000; o->max_gap = 5000; o->max_gap_ref = -1;
+	o->max_chain_skip = 25; o->max_chain_iter = 5000; o->rmq_inner_dist = 1000; o->rmq_size_cap = 100000; o->rmq_rescue_size = 1000;
+	o->rmq_rescue_ratio = 0.1f; o->chain_gap_scale = 0.8f; o->chain_skip_scale = 0.0f; o->max_max_occ = 4095; o->occ_dist = 500;
+	o->mask_level = 0.5f; o->mask_len = INT_MAX; o->pri_ratio = 0.8f; o->best_n = 5; o->alt_drop = 0.15f;
+	o->a = 2; o->b = 4; o->q = 4; o->e = 2; o->q2 = 24; o->e2 = 1; o->sc_ambi = 1; o->zdrop = 400; o->zdrop_inv = 200; o->end_bonus = -1;
+	o->min_dp_max = o->min_chain_score * o->a; o->min_ksw_len = 200; o->anchor_ext_len = 20; o->anchor_ext_shift = 6; o->max_clip_ratio = 1.0f;
+	o->mini_batch_size = 500000000; o->max_sw_mat = 100000000; o->cap_kalloc = 1000000000; o->rank_min_len = 500; o->rank_frac = 0.9f;
+	o->pe_ori = 0; o->pe_bonus = 33;
+}
+extern "C" int mm_set_opt(const char *preset, mm_idxopt_t *io, mm_mapopt_t *mo) // options.c:88-162 (asm* only: SURVEY.md section 8a row O)
+{
+	if (preset == 0) { mm_idxopt_init(io); mm_mapopt_init(mo); return 0; }
+	if (strncmp(preset, "asm", 3) == 0) {
+		io->flag = 0, io->k = 19, io->w = 19;
+		mo->bw = 1000, mo->bw_long = 100000; mo->max_gap = 10000; mo->flag |= MM_F_RMQ;
+		mo->min_mid_occ = 50, mo->max_mid_occ = 500; mo->min_dp_max = 200; mo->best_n = 50;
+		if (strcmp(preset, "asm5") == 0) mo->a = 1, mo->b = 19, mo->q = 39, mo->q2 = 81, mo->e = 3, mo->e2 = 1, mo->zdrop = mo->zdrop_inv = 200;
+		else if (strcmp(preset, "asm10") == 0) mo->a = 1, mo->b = 9, mo->q = 16, mo->q2 = 41, mo->e = 2, mo->e2 = 1, mo->zdrop = mo->zdrop_inv = 200;
+		else if (strcmp(preset, "asm20") == 0) mo->a = 1, mo->b = 4, mo->q = 6, mo->q2 = 26, mo->e = 2, mo->e2 = 1, mo->zdrop = mo->zdrop_inv = 200, io->w = 10;
+		else return -1;
+		return 0;
+	}
+	return -1;
+}
+extern "C" int mm_check_opt(const mm_idxopt_t *io, const mm_mapopt_t *mo) // options.c:164-234
+{
+	if (mo->bw > mo->bw_long) return -8;
+	if ((mo->flag & MM_F_RMQ) && (mo->flag & (MM_F_SR | MM_F_SPLICE))) return -7;
+	if (io->k <= 0 || io->w <= 0) return -5;
+	if (mo->best_n < 0) return -4;
+	if (mo->pri_ratio < 0.0f || mo->pri_ratio > 1.0f) return -4;
+	if ((mo->flag & MM_F_FOR_ONLY) && (mo->flag & MM_F_REV_ONLY)) return -3;
+	if (mo->e <= 0 || mo->q <= 0) return -1;
+	if ((mo->q != mo->q2 || mo->e != mo->e2) && !(mo->e > mo->e2 && mo->q + mo->e < mo->q2 + mo->e2)) return -2;
+	if ((mo->q + mo->e) + (mo->q2 + mo->e2) > 127) return -1;
+	if (mo->zdrop < mo->zdrop_inv) return -5;
+	return 0;
+}
+
+// ---------------------------------------------------------------- the index handle
+struct PgaIdx {
+	mm_idx_t hdr;                    // must stay first: the Rust side reads n_seq, seq[i].name, seq[i].len
+	SeqSet S; Minimizers M; Index I; DBuf<uint32_t> grp; DBuf<int32_t> d_name_rank;
+	std::vector<mm_idx_seq_t> seq_hdr; std::vector<std::string> names;
+	std::map<std::string, int> by_name;
+	std::mutex mtx;
+	bool have_results = false; mm_mapopt_t res_opt;
+	std::vector<std::vector<Reg>> results;
+	Timers tm;
+	hipStream_t st = 0;
+};
+
+static void require_device()
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		throw std::runtime_error("pga: no HIP device visible -- libpgalign.so is a gfx950 backend and has no CPU fallback");
+}
+
+static void check_supported(const mm_mapopt_t &o, int k, int w)
+{
+	if (o.flag & (MM_F_SPLICE | MM_F_SR | MM_F_QSTRAND | MM_F_HEAP_SORT | MM_F_EQX))
+		throw std::runtime_error("pga: splice / short-read / qstrand / heap-sort / eqx modes are outside pangraph's path (SURVEY.md section 2)");
+	if (!(o.flag & MM_F_RMQ)) throw std::runtime_error("pga: only RMQ chaining (asm presets) is implemented");
+	if (!(o.flag & MM_F_NO_LJOIN)) throw std::runtime_error("pga: long-join re-chaining is not implemented (pangraph always passes -X)");
+	if (!(o.flag & MM_F_ALL_CHAINS)) throw std::runtime_error("pga: primary/secondary selection is not implemented (pangraph always passes -X)");
+	if (o.q == o.q2 && o.e == o.e2) throw std::runtime_error("pga: single-affine scoring (ksw_extz2) is out of scope");
+	if (-(-o.b) > 2 * (o.q + o.e) && o.b > 2 * (o.q + o.e)) throw std::runtime_error("pga: mismatch penalty larger than 2*(q+e) disables the reference DP");
+	if (k > 28 || k < 1 || w < 1 || w > 255) throw std::runtime_error("pga: k must be in [1,28] and w in [1,255]");
+	if (o.sdust_thres > 0) throw std::runtime_error("pga: SDUST masking is not implemented");
+}
+
+static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name)
+{
+	require_device();
+	std::unique_ptr<PgaIdx> ix(new PgaIdx());
+	memset(&ix->hdr, 0, sizeof(ix->hdr));
+	if (w < 1) w = 1;
+	double t0 = now_s();
+	upload_seqs(ix->S, n, seq, len, name, ix->st);
+	ix->names = ix->S.name;
+	ix->seq_hdr.resize((size_t)n);
+	for (int i = 0; i < n; ++i) {
+		ix->seq_hdr[i].name = name && name[i] ? const_cast<char*>(ix->names[i].c_str()) : nullptr;
+		ix->seq_hdr[i].offset = ix->S.off[i]; ix->seq_hdr[i].len = len[i]; ix->seq_hdr[i].is_alt = 0;
+		if (name && name[i]) {
+			if (ix->by_name.count(ix->names[i])) throw std::runtime_error("pga: duplicate sequence name '" + ix->names[i] + "' (index.c:436 asserts uniqueness)");
+			ix->by_name[ix->names[i]] = i;
+		}
+	}
+	// rank of every name under strcmp order (skip_seed compares names as C strings, map.c:84,89)
+	std::vector<int> ord((size_t)n); for (int i = 0; i < n; ++i) ord[i] = i;
+	std::sort(ord.begin(), ord.end(), [&](int a, int b) { return strcmp(ix->names[a].c_str(), ix->names[b].c_str()) < 0; });
+	std::vector<int32_t> rank((size_t)n); for (int i = 0; i < n; ++i) rank[ord[i]] = i;
+	ix->d_name_rank.upload(rank, ix->st);
+	ix->hdr.b = 14 < 2 * k ? 14 : 2 * k, ix->hdr.w = w, ix->hdr.k = k, ix->hdr.flag = name ? 0 : MM_I_NO_NAME;
+	ix->hdr.n_seq = (uint32_t)n; ix->hdr.seq = ix->seq_hdr.data();
+	PGA_HIP(hipStreamSynchronize(ix->st));
+	double t1 = now_s();
+	sketch_all(ix->S, w, k, ix->M, ix->st);
+	double t2 = now_s();
+	build_index_ex(ix->M, w, k, ix->I, ix->grp, ix->st);
+	double t3 = now_s();
+	ix->tm.upload = t1 - t0, ix->tm.sketch = t2 - t1, ix->tm.index = t3 - t2; ix->tm.n_mz = (double)ix->M.n;
+	return ix.release();
+}
+
+static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
+{
+	check_supported(opt, ix.I.k, ix.I.w);
+	double t0 = now_s();
+	SeedResult SR;
+	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, SR, ix.st);
+	double t1 = now_s();
+	ChainResult CR;
+	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st);
+	double t2 = now_s();
+	if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 1; }
+	align_batch(ix.S, opt, ix.I.k, SR.h_q_aoff, CR, SR.h_rep_len, ix.results, n_threads, &ix.tm, ix.st);
+	double t3 = now_s();
+	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;
+	ix.have_results = true; ix.res_opt = opt;
+}
+
+// ---------------------------------------------------------------- minimap2-sys ABI
+extern "C" mm_idx_t *mm_idx_str(int w, int k, int is_hpc, int bucket_bits, int n, const char **seq, const char **name) // index.c:408-456
+{
+	(void)bucket_bits;
+	if (n <= 0) return 0;
+	try {
+		if (is_hpc) throw std::runtime_error("pga: homopolymer-compressed minimizers are outside pangraph's path");
+		std::vector<uint32_t> len((size_t)n);
+		for (int i = 0; i < n; ++i) len[i] = (uint32_t)strlen(seq[i]);
+		return reinterpret_cast<mm_idx_t*>(idx_build(w, k, n, seq, len.data(), name));
+	} catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_idx_str: %s\n", e.what()); return 0; }
+}
+extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete reinterpret_cast<PgaIdx*>(mi); }
+
+extern "C" void mm_mapopt_update(mm_mapopt_t *opt, const mm_idx_t *mi) // options.c:66-80
+{
+	PgaIdx *ix = reinterpret_cast<PgaIdx*>(const_cast<mm_idx_t*>(mi));
+	if (opt->mid_occ <= 0) {
+		try { opt->mid_occ = index_cal_max_occ(ix->I, opt->mid_occ_frac, ix->st); }
+		catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_mapopt_update: %s\n", e.what()); return; }
+		if (opt->mid_occ < opt->min_mid_occ) opt->mid_occ = opt->min_mid_occ;
+		if (opt->max_mid_occ > opt->min_mid_occ && opt->mid_occ > opt->max_mid_occ) opt->mid_occ = opt->max_mid_occ;
+	}
+	if (opt->bw_long < opt->bw) opt->bw_long = opt->bw;
+}
+
+struct mm_tbuf_s { int unused; };
+extern "C" mm_tbuf_t *mm_tbuf_init(void) { return (mm_tbuf_t*)calloc(1, sizeof(mm_tbuf_s)); }
+extern "C" void mm_tbuf_destroy(mm_tbuf_t *b) { free(b); }
+
+static mm_reg1_t *regs_to_c(const std::vector<Reg> &regs, int *n_regs)
+{
+	*n_regs = (int)regs.size();
+	if (regs.empty()) return 0;
+	mm_reg1_t *out = (mm_reg1_t*)calloc(regs.size(), sizeof(mm_reg1_t));
+	for (size_t i = 0; i < regs.size(); ++i) {
+		const Reg &r = regs[i]; mm_reg1_t &o = out[i];
+		o.id = r.id, o.cnt = r.cnt, o.rid = r.rid, o.score = r.score, o.qs = r.qs, o.qe = r.qe, o.rs = r.rs, o.re = r.re;
+		o.parent = r.parent, o.subsc = r.subsc, o.as = r.as, o.mlen = r.mlen, o.blen = r.blen, o.n_sub = r.n_sub, o.score0 = r.score0;
+		o.mapq = r.mapq, o.split = r.split, o.rev = r.rev, o.inv = r.inv, o.split_inv = r.split_inv;
+		o.hash = r.hash, o.div = -1.0f;
+		if (r.has_p) {
+			uint32_t cap = (uint32_t)r.cigar.size() + (uint32_t)sizeof(mm_extra_t) / 4;
+			--cap, cap |= cap >> 1, cap |= cap >> 2, cap |= cap >> 4, cap |= cap >> 8, cap |= cap >> 16, ++cap; // kroundup32 (align.c:296)
+			o.p = (mm_extra_t*)calloc(cap, 4);
+			o.p->capacity = cap, o.p->dp_score = r.dp_score, o.p->dp_max = r.dp_max, o.p->dp_max2 = r.dp_max2;
+			o.p->n_ambi = r.n_ambi, o.p->trans_strand = 0, o.p->n_cigar = (uint32_t)r.cigar.size();
+			if (!r.cigar.empty()) memcpy(o.p->cigar, r.cigar.data(), r.cigar.size() * 4);
+		}
+	}
+	return out;
+}
+
+static bool same_opt(const mm_mapopt_t &a, const mm_mapopt_t &b) { return memcmp(&a, &b, offsetof(mm_mapopt_t, split_prefix)) == 0; }
+
+extern "C" mm_reg1_t *mm_map(const mm_idx_t *mi, int l_seq, const char *seq, int *n_regs, mm_tbuf_t *b, const mm_mapopt_t *opt, const char *name) // map.c:376-381
+{
+	(void)b;
+	*n_regs = 0;
+	PgaIdx *ix = reinterpret_cast<PgaIdx*>(const_cast<mm_idx_t*>(mi));
+	try {
+		if (l_seq == 0) return 0;
+		auto it = name ? ix->by_name.find(name) : ix->by_name.end();
+		if (it == ix->by_name.end() || (int)ix->S.len[it->second] != l_seq)
+			throw std::runtime_error(std::string("pga: mm_map() query '") + (name ? name : "(null)") + "' is not one of the indexed sequences; this backend aligns a group all-vs-all "
+			                         "(what pangraph's find_matches does); mapping foreign queries is not implemented");
+		const int qid = it->second;
+		{   // cheap identity check of the bases
+			const uint8_t *h = ix->S.h_nt4.data() + ix->S.off[qid];
+			static const char tbl[] = "ACGT";
+			for (int i = 0; i < l_seq; i += (l_seq > 64 ? l_seq / 64 : 1)) {
+				char c = seq[i] & 0xdf; uint8_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
+				if ((uint8_t)seq[i] < 0x40) code = 4;
+				if (code != h[i]) throw std::runtime_error("pga: mm_map() query bases differ from the indexed sequence of the same name");
+			}
+			(void)tbl;
+		}
+		std::lock_guard<std::mutex> lk(ix->mtx);
+		if (!ix->have_results || !same_opt(ix->res_opt, *opt)) run_batch(*ix, *opt, 0);
+		return regs_to_c(ix->results[qid], n_regs);
+	} catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_map: %s\n", e.what()); *n_regs = 0; return 0; }
+}
+
+extern "C" double mm_event_identity(const mm_reg1_t *r) // align.c:897-917
+{
+	int32_t n_gapo = 0, n_gap = 0;
+	if (r->p == 0) return -1.0f;
+	for (uint32_t i = 0; i < r->p->n_cigar; ++i) {
+		int32_t op = r->p->cigar[i] & 0xf, len = (int32_t)(r->p->cigar[i] >> 4);
+		if (op == MM_CIGAR_INS || op == MM_CIGAR_DEL) ++n_gapo, n_gap += len;
+	}
+	return (double)r->mlen / (r->blen + (int32_t)r->p->n_ambi - n_gap + n_gapo);
+}
+
+// ---------------------------------------------------------------- native batch entry
+struct pga_result_s { std::vector<pga_match_t> m; std::vector<uint32_t> cig; pga_stats_t st; };
+
+static void params_to_opts(const pga_params_t &p, mm_idxopt_t &io, mm_mapopt_t &mo) // align_with_minimap2_lib.rs:35-57 + options_args.rs:273-325
+{
+	const char *preset = p.sensitivity == 5 ? "asm5" : p.sensitivity == 10 ? "asm10" : p.sensitivity == 20 ? "asm20" : nullptr;
+	if (!preset) throw std::runtime_error("Unknown sensitivity preset: " + std::to_string(p.sensitivity));
+	mm_set_opt(0, &io, &mo); mm_set_opt(preset, &io, &mo);
+	if (p.kmer_length > 0) io.k = (short)p.kmer_length;
+	mo.flag |= MM_F_OUT_CG | MM_F_CIGAR;
+	int s = p.indel_len_threshold - 10; if (s < 5) s = 5;
+	mo.min_dp_max = s;
+	mo.flag |= MM_F_ALL_CHAINS | MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_NO_LJOIN;
+	io.bucket_bits = 14;
+	if (mm_check_opt(&io, &mo) != 0) throw std::runtime_error("minimap2: mm_check_opt(): options are invalid");
+}
+
+extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, const int64_t *group_off,
+                                const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_result_t **out)
+{
+	*out = nullptr;
+	try {
+		mm_idxopt_t io; mm_mapopt_t mo0;
+		params_to_opts(*params, io, mo0);
+		std::unique_ptr<pga_result_s> R(new pga_result_s());
+		memset(&R->st, 0, sizeof(R->st));
+		double t_all = now_s();
+		for (int g = 0; g < n_groups; ++g) {
+			const int64_t b = group_off[g], n = group_off[g + 1] - b;
+			if (n <= 0) continue;
+			std::unique_ptr<PgaIdx> ix(idx_build(io.w, io.k, (int)n, seqs + b, seq_lens + b, names + b));
+			mm_mapopt_t mo = mo0;
+			mm_mapopt_update(&mo, &ix->hdr);
+			run_batch(*ix, mo, params->n_threads);
+			for (int q = 0; q < (int)n; ++q) for (const Reg &r : ix->results[q]) {
+				if (!r.has_p) throw std::runtime_error("Unable to find CIGAR string in the result"); // align_with_minimap2_lib.rs:118
+				pga_match_t m; memset(&m, 0, sizeof(m));
+				m.group = g, m.qry = q, m.ref = r.rid, m.qry_len = (int32_t)ix->S.len[q], m.qry_start = r.qs, m.qry_end = r.qe;
+				m.ref_len = (int32_t)ix->S.len[r.rid], m.ref_start = r.rs, m.ref_end = r.re;
+				m.matches = r.mlen, m.length = r.blen, m.quality = (int32_t)r.mapq, m.reverse = (int32_t)r.rev, m.align = r.dp_score;
+				m.n_ambi = (int32_t)r.n_ambi, m.inv = (int32_t)r.inv;
+				int32_t n_gapo = 0, n_gap = 0;
+				for (uint32_t c : r.cigar) { int32_t op = c & 0xf, len = (int32_t)(c >> 4); if (op == 1 || op == 2) ++n_gapo, n_gap += len; }
+				m.divergence = 1.0 - (double)r.mlen / (r.blen + (int32_t)r.n_ambi - n_gap + n_gapo);
+				m.cigar_off = R->cig.size(), m.n_cigar = (uint32_t)r.cigar.size();
+				R->cig.insert(R->cig.end(), r.cigar.begin(), r.cigar.end());
+				R->m.push_back(m);
+			}
+			const Timers &t = ix->tm;
+			R->st.upload += t.upload, R->st.sketch += t.sketch, R->st.index += t.index, R->st.seed += t.seed, R->st.chain += t.chain, R->st.align += t.align;
+			R->st.n_bases += (double)ix->S.total, R->st.n_minimizers += t.n_mz, R->st.n_anchors += t.n_anchor, R->st.n_dp_jobs += t.dp_jobs, R->st.n_dp_cells += t.dp_cells;
+		}
+		R->st.total = now_s() - t_all; R->st.n_matches = (double)R->m.size();
+		*out = R.release();
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+extern "C" int64_t pga_result_n_matches(const pga_result_t *r) { return (int64_t)r->m.size(); }
+extern "C" const pga_match_t *pga_result_matches(const pga_result_t *r) { return r->m.data(); }
+extern "C" const uint32_t *pga_result_cigars(const pga_result_t *r, uint64_t *n_ops) { if (n_ops) *n_ops = r->cig.size(); return r->cig.data(); }
+extern "C" const pga_stats_t *pga_result_stats(const pga_result_t *r) { return &r->st; }
+extern "C" void pga_result_free(pga_result_t *r) { delete r; }
+extern "C" const char *pga_last_error(void) { return g_err.c_str(); }
+extern "C" int pga_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int pga_set_device(int dev) { if (hipSetDevice(dev) != hipSuccess) { set_err("hipSetDevice failed"); return -1; } return 0; }
+extern "C" void pga_free(void *p) { free(p); }
+
+// ---------------------------------------------------------------- stage taps (parity tests)
+template <class T> static T *dup_out(const std::vector<T> &v) { T *p = (T*)malloc((v.size() ? v.size() : 1) * sizeof(T)); if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T)); return p; }
+
+extern "C" int pga_stage_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int w, int k, uint64_t **mz_xy, uint64_t **seq_off)
+{
+	try {
+		require_device();
+		SeqSet S; Minimizers M;
+		upload_seqs(S, n, seqs, lens, nullptr, 0);
+		sketch_all(S, w, k, M, 0);
+		std::vector<u128> h = M.mz.download(0); h.resize(M.n);
+		std::vector<uint64_t> flat(h.size() * 2);
+		for (size_t i = 0; i < h.size(); ++i) flat[2 * i] = h[i].x, flat[2 * i + 1] = h[i].y;
+		*mz_xy = dup_out(flat); *seq_off = dup_out(M.h_seq_off);
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_stage_chain(const pga_params_t *params, int32_t n, const char *const *seqs, const uint32_t *lens, const char *const *names,
+                               uint64_t **anchors_xy, uint64_t **anchor_off, int32_t **n_u, int32_t **n_v, uint64_t **u, uint64_t **chain_xy, int32_t **rep_len, int32_t *mid_occ)
+{
+	try {
+		mm_idxopt_t io; mm_mapopt_t mo;
+		params_to_opts(*params, io, mo);
+		std::unique_ptr<PgaIdx> ix(idx_build(io.w, io.k, n, seqs, lens, names));
+		mm_mapopt_update(&mo, &ix->hdr);
+		*mid_occ = mo.mid_occ;
+		check_supported(mo, io.k, io.w);
+		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, SR, 0);
+		std::vector<u128> a = SR.a.download(0); a.resize(SR.n_a);
+		std::vector<uint64_t> flat(a.size() * 2);
+		for (size_t i = 0; i < a.size(); ++i) flat[2 * i] = a[i].x, flat[2 * i + 1] = a[i].y;
+		*anchors_xy = dup_out(flat); *anchor_off = dup_out(SR.h_q_aoff); *rep_len = dup_out(SR.h_rep_len);
+		ChainResult CR; chain_all(ix->S, SR.a, SR.q_aoff, SR.n_a, mo, io.k, CR, 0);
+		*n_u = dup_out(CR.n_u); *n_v = dup_out(CR.n_v);
+		std::vector<uint64_t> uu(CR.u); uu.resize(SR.n_a);
+		*u = dup_out(uu);
+		std::vector<uint64_t> cf(SR.n_a * 2);
+		for (size_t i = 0; i < SR.n_a && i < CR.a.size(); ++i) cf[2 * i] = CR.a[i].x, cf[2 * i + 1] = CR.a[i].y;
+		*chain_xy = dup_out(cf);
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const int32_t *qlen, const uint8_t *const *t, const int32_t *tlen,
+                               int a, int b, int sc_ambi, int gapo, int gape, int gapo2, int gape2, const int32_t *w, const int32_t *zdrop, const int32_t *end_bonus, const int32_t *flag,
+                               int32_t *ez, uint32_t **cigars, uint64_t *cigar_off)
+{
+	try {
+		require_device();
+		// lay the explicit sequences out as one nt4 array: query i then target i
+		std::vector<uint8_t> buf; std::vector<DpJob> jobs((size_t)n_jobs);
+		for (int i = 0; i < n_jobs; ++i) {
+			DpJob &j = jobs[i]; memset(&j, 0, sizeof(j));
+			j.q_off = buf.size(); buf.insert(buf.end(), q[i], q[i] + qlen[i]);
+			j.t_off = buf.size(); buf.insert(buf.end(), t[i], t[i] + tlen[i]);
+			j.qlen_full = qlen[i], j.qs = 0, j.qlen = qlen[i], j.tlen = tlen[i], j.w = w[i], j.zdrop = zdrop[i], j.end_bonus = end_bonus[i], j.flag = flag[i];
+		}
+		buf.resize(buf.size() + 64, 4);
+		DBuf<uint8_t> d; d.upload(buf, 0);
+		a = a < 0 ? -a : a; b = b > 0 ? -b : b; sc_ambi = sc_ambi > 0 ? -sc_ambi : sc_ambi;
+		DpParams P{gapo, gape, gapo2, gape2, a, b, sc_ambi};
+		std::vector<DpJob> run; std::vector<int> idx;
+		for (int i = 0; i < n_jobs; ++i) if (qlen[i] > 0 && tlen[i] > 0) run.push_back(jobs[i]), idx.push_back(i);
+		std::vector<DpRes> res; std::vector<uint32_t> cg;
+		dp_run(d.p, run, P, res, cg, 0);
+		std::vector<uint32_t> all;
+		for (int i = 0; i < n_jobs; ++i) { int32_t *e = ez + 12 * i; e[0] = 0; e[1] = e[2] = -1; e[3] = -0x40000000; e[4] = -1; e[5] = -0x40000000; e[6] = -1; e[7] = -0x40000000; e[8] = e[9] = e[10] = e[11] = 0; cigar_off[i] = 0; }
+		for (size_t r = 0; r < res.size(); ++r) {
+			int i = idx[r]; int32_t *e = ez + 12 * i; const DpRes &R = res[r];
+			e[0] = R.max, e[1] = R.max_q, e[2] = R.max_t, e[3] = R.mqe, e[4] = R.mqe_t, e[5] = R.mte, e[6] = R.mte_q, e[7] = R.score, e[8] = R.zdropped, e[9] = R.reach_end, e[10] = R.n_cigar;
+			cigar_off[i] = all.size();
+			all.insert(all.end(), cg.begin() + R.cigar_off, cg.begin() + R.cigar_off + R.n_cigar);
+		}
+		*cigars = dup_out(all);
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}

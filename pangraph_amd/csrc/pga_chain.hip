@@ -1,0 +1,483 @@
+// pga_chain.hip -- kernel group #4: co-linear chaining of every query's anchors.
+//
+// Replaces mg_lchain_rmq / comput_sc_simple / mg_chain_backtrack / mg_chain_bk_end / compact_a
+// (reference: packages/minimap2-sys/minimap2/lchain.c:9-111,232-368) and the range-min AVL tree behind it
+// (krmq.h).  minimap2's asm presets chain with MM_F_RMQ (options.c:119).
+//
+// Why a re-enactment and not a textbook parallel range-min: which of several equal-priority predecessors the
+// reference picks depends on the shape of its AVL tree and on the order in which subtree minima were refreshed
+// (krmq.h:110-150), i.e. on the whole insert/erase history.  Bit-exact chains therefore need that history.
+// What the GPU adds is parallelism ACROSS histories: the tree is empty whenever the sweep crosses to another
+// (strand, target) or jumps more than max_dist in target position (lchain.c:295), so the anchor array of a
+// batch is cut into independent SEGMENTS at those points and every segment is swept by its own lane with
+// index-addressed nodes (node id == anchor id, no allocator).  Thousands of segments are in flight per batch;
+// within a segment the sweep is sequential, as in the reference.  Backtracking and compaction run one lane
+// per query (they depend on the reference's unstable sort of the per-anchor scores, pga_sort_exact.h).
+#include "pga_common.h"
+#include "pga_sort_exact.h"
+#include "pga_pipeline.h"
+#include <rocprim/rocprim.hpp>
+
+namespace pga {
+
+struct ChainParams {
+	int32_t max_dist, max_dist_inner, bw, max_skip, cap, min_cnt, min_sc;
+	float pen_gap, pen_skip;
+};
+
+struct __attribute__((aligned(16))) CNode {
+	double pri;
+	int32_t y;
+	int32_t c[2];
+	int32_t s;
+	uint32_t size;
+	int32_t bal;
+};
+
+#define CMAXD 64
+
+__device__ __forceinline__ float mg_log2(float x) // mmpriv.h:118-126
+{
+	union { float f; uint32_t i; } z = { x };
+	float log_2 = (float)(((z.i >> 23) & 255) - 128);
+	z.i &= ~(255u << 23);
+	z.i += 127u << 23;
+	log_2 = __fadd_rn(log_2, __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(-0.34484843f, z.f), 2.02466578f), z.f), 0.67487759f));
+	return log_2;
+}
+
+// lchain.c:232-248 (all float operations individually rounded: no FMA contraction)
+__device__ __forceinline__ int32_t score_pair(const u128 ai, const u128 aj, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)
+{
+	int32_t dq = (int32_t)ai.y - (int32_t)aj.y, dr, dd, dg, q_span, sc;
+	dr = (int32_t)(ai.x - aj.x);
+	*width = dd = dr > dq ? dr - dq : dq - dr;
+	dg = dr < dq ? dr : dq;
+	q_span = (int32_t)(aj.y >> 32 & 0xff);
+	sc = q_span < dg ? q_span : dg;
+	if (exact) *exact = (dd == 0 && dg <= q_span);
+	if (dd || dq > q_span) {
+		float lin_pen = __fadd_rn(__fmul_rn(pen_gap, (float)dd), __fmul_rn(pen_skip, (float)dg));
+		float log_pen = dd >= 1 ? mg_log2((float)(dd + 1)) : 0.0f;
+		sc -= (int)__fadd_rn(lin_pen, __fmul_rn(.5f, log_pen));
+	}
+	return sc;
+}
+
+// ---- AVL tree on nodes nd[0..), keys (y, index); RMQ=true maintains subtree minima of pri ----
+template <bool RMQ> struct Tree {
+	CNode *nd; int32_t root;
+	__device__ __forceinline__ int cmp(int32_t ya, int32_t ia, int32_t b) const {
+		int32_t yb = nd[b].y; return ya < yb ? -1 : ya > yb ? 1 : (ia > b) - (ia < b);
+	}
+	__device__ __forceinline__ uint32_t sz(int32_t x) const { return x < 0 ? 0u : nd[x].size; }
+	__device__ __forceinline__ void refresh(int32_t p, int32_t q, int32_t r) { // krmq.h:110-113 with explicit children
+		if (!RMQ) return;
+		int32_t s = (q < 0 || nd[p].pri < nd[nd[q].s].pri) ? p : nd[q].s;
+		s = (r < 0 || nd[s].pri < nd[nd[r].s].pri) ? s : nd[r].s;
+		nd[p].s = s;
+	}
+	__device__ int32_t rotate1(int32_t p, int dir) { // krmq.h:115-126
+		int opp = 1 - dir;
+		int32_t q = nd[p].c[opp], s = nd[p].s;
+		uint32_t size_p = nd[p].size;
+		nd[p].size -= nd[q].size - sz(nd[q].c[dir]);
+		nd[q].size = size_p;
+		refresh(p, nd[p].c[dir], nd[q].c[dir]);
+		nd[q].s = s;
+		nd[p].c[opp] = nd[q].c[dir];
+		nd[q].c[dir] = p;
+		return q;
+	}
+	__device__ int32_t rotate2(int32_t p, int dir) { // krmq.h:128-149
+		int opp = 1 - dir, b1;
+		int32_t q = nd[p].c[opp], r = nd[q].c[dir], s = nd[p].s;
+		uint32_t size_x_dir = sz(nd[r].c[dir]);
+		nd[r].size = nd[p].size;
+		nd[p].size -= nd[q].size - size_x_dir;
+		nd[q].size -= size_x_dir + 1;
+		refresh(p, nd[p].c[dir], nd[r].c[dir]);
+		refresh(q, nd[q].c[opp], nd[r].c[opp]);
+		nd[r].s = s;
+		nd[p].c[opp] = nd[r].c[dir];
+		nd[r].c[dir] = p;
+		nd[q].c[dir] = nd[r].c[opp];
+		nd[r].c[opp] = q;
+		b1 = dir == 0 ? +1 : -1;
+		if (nd[r].bal == b1) nd[q].bal = 0, nd[p].bal = -b1;
+		else if (nd[r].bal == 0) nd[q].bal = nd[p].bal = 0;
+		else nd[q].bal = b1, nd[p].bal = 0;
+		nd[r].bal = 0;
+		return r;
+	}
+	__device__ void insert(int32_t x) { // krmq.h:152-200; nd[x].y/pri are set by the caller
+		uint8_t stack[CMAXD]; int32_t path[CMAXD];
+		int32_t bp = root, bq = -1, p, q, r;
+		int top = 0, path_len = 0, which = 0;
+		const int32_t yx = nd[x].y;
+		for (p = bp, q = bq; p >= 0; q = p, p = nd[p].c[which]) {
+			int c = cmp(yx, x, p);
+			if (nd[p].bal != 0) bq = q, bp = p, top = 0;
+			stack[top++] = (uint8_t)(which = (c > 0));
+			path[path_len++] = p;
+		}
+		nd[x].bal = 0, nd[x].size = 1, nd[x].c[0] = nd[x].c[1] = -1, nd[x].s = x;
+		if (q < 0) root = x; else nd[q].c[which] = x;
+		if (bp < 0) return;
+		for (int i = 0; i < path_len; ++i) ++nd[path[i]].size;
+		if (RMQ) for (int i = path_len - 1; i >= 0; --i) {
+			refresh(path[i], nd[path[i]].c[0], nd[path[i]].c[1]);
+			if (nd[path[i]].s != x) break;
+		}
+		for (p = bp, top = 0; p != x; p = nd[p].c[stack[top]], ++top) {
+			if (stack[top] == 0) --nd[p].bal; else ++nd[p].bal;
+		}
+		if (nd[bp].bal > -2 && nd[bp].bal < 2) return;
+		which = (nd[bp].bal < 0);
+		int b1 = which == 0 ? +1 : -1;
+		q = nd[bp].c[1 - which];
+		if (nd[q].bal == b1) { r = rotate1(bp, which); nd[q].bal = nd[bp].bal = 0; }
+		else r = rotate2(bp, which);
+		if (bq < 0) root = r; else nd[bq].c[bp != nd[bq].c[0]] = r;
+	}
+	// krmq.h:203-285; path slot 0 is the reference's stack copy of the root ("fake"), encoded as -2
+	__device__ __forceinline__ int32_t getc(int32_t p, int d) const { return p == -2 ? (d == 0 ? root : -1) : nd[p].c[d]; }
+	__device__ __forceinline__ void setc(int32_t p, int d, int32_t v) { if (p == -2) { if (d == 0) root = v; } else nd[p].c[d] = v; }
+	__device__ void erase(int32_t x) {
+		int32_t path[CMAXD], p; uint8_t dir[CMAXD];
+		int d = 0, i;
+		{
+			int c = -1; p = -2;
+			const int32_t yx = nd[x].y;
+			while (c) { int which = (c > 0); dir[d] = (uint8_t)which, path[d++] = p; p = getc(p, which); c = cmp(yx, x, p); }
+		}
+		for (i = 1; i < d; ++i) --nd[path[i]].size;
+		if (nd[p].c[1] < 0) setc(path[d-1], dir[d-1], nd[p].c[0]);
+		else {
+			int32_t q = nd[p].c[1];
+			if (nd[q].c[0] < 0) {
+				nd[q].c[0] = nd[p].c[0];
+				nd[q].bal = nd[p].bal;
+				setc(path[d-1], dir[d-1], q);
+				path[d] = q, dir[d++] = 1;
+				nd[q].size = nd[p].size - 1;
+			} else {
+				int32_t r; int e = d++;
+				for (;;) { dir[d] = 0, path[d++] = q; r = nd[q].c[0]; if (nd[r].c[0] < 0) break; q = r; }
+				nd[r].c[0] = nd[p].c[0];
+				nd[q].c[0] = nd[r].c[1];
+				nd[r].c[1] = nd[p].c[1];
+				nd[r].bal = nd[p].bal;
+				setc(path[e-1], dir[e-1], r);
+				path[e] = r, dir[e] = 1;
+				for (i = e + 1; i < d; ++i) --nd[path[i]].size;
+				nd[r].size = nd[p].size - 1;
+			}
+		}
+		if (RMQ) for (i = d - 1; i >= 1; --i) refresh(path[i], nd[path[i]].c[0], nd[path[i]].c[1]);
+		while (--d > 0) {
+			int32_t q = path[d];
+			int which = dir[d], other = 1 - which, b1 = 1, b2 = 2;
+			if (which) b1 = -b1, b2 = -b2;
+			nd[q].bal += b1;
+			if (nd[q].bal == b1) break;
+			else if (nd[q].bal == b2) {
+				int32_t r = nd[q].c[other];
+				if (nd[r].bal == -b1) setc(path[d-1], dir[d-1], rotate2(q, which));
+				else {
+					setc(path[d-1], dir[d-1], rotate1(q, which));
+					if (nd[r].bal == 0) { nd[r].bal = -b1; nd[q].bal = b1; break; }
+					else nd[r].bal = nd[q].bal = 0;
+				}
+			}
+		}
+	}
+	// krmq.h:98-140, closed interval [(lo_y,lo_i),(hi_y,hi_i)]
+	__device__ int32_t rmq(int32_t lo_y, int32_t lo_i, int32_t hi_y, int32_t hi_i) const {
+		int32_t path[2][CMAXD], p, mn; int8_t pc[2][CMAXD];
+		int plen[2] = {0, 0}, i, c, lca;
+		if (root < 0) return -1;
+		for (p = root; p >= 0;) { c = cmp(lo_y, lo_i, p); path[0][plen[0]] = p, pc[0][plen[0]++] = (int8_t)c; if (c < 0) p = nd[p].c[0]; else if (c > 0) p = nd[p].c[1]; else break; }
+		for (p = root; p >= 0;) { c = cmp(hi_y, hi_i, p); path[1][plen[1]] = p, pc[1][plen[1]++] = (int8_t)c; if (c < 0) p = nd[p].c[0]; else if (c > 0) p = nd[p].c[1]; else break; }
+		for (i = 0; i < plen[0] && i < plen[1]; ++i)
+			if (path[0][i] == path[1][i] && pc[0][i] <= 0 && pc[1][i] >= 0) break;
+		if (i == plen[0] || i == plen[1]) return -1;
+		lca = i, mn = path[0][lca];
+		for (i = lca + 1; i < plen[0]; ++i) if (pc[0][i] <= 0) {
+			int32_t u = path[0][i], r = nd[u].c[1];
+			if (nd[u].pri < nd[mn].pri) mn = u;
+			if (r >= 0 && nd[nd[r].s].pri < nd[mn].pri) mn = nd[r].s;
+		}
+		for (i = lca + 1; i < plen[1]; ++i) if (pc[1][i] >= 0) {
+			int32_t u = path[1][i], l = nd[u].c[0];
+			if (nd[u].pri < nd[mn].pri) mn = u;
+			if (l >= 0 && nd[nd[l].s].pri < nd[mn].pri) mn = nd[l].s;
+		}
+		return mn;
+	}
+};
+
+struct Iter { int32_t stack[CMAXD]; int top; };
+
+// one lane per segment: the sweep of lchain.c:276-357 restricted to anchors [b,e) (tree empty at b)
+__global__ void k_chain_segments(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
+                                 uint64_t n_total, ChainParams P, CNode *__restrict__ nd_main, CNode *__restrict__ nd_inner,
+                                 int32_t *__restrict__ f, int32_t *__restrict__ pp, int32_t *__restrict__ t)
+{
+	uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sidx >= n_seg) return;
+	const uint32_t sg = seg_order[sidx];
+	const uint64_t b = seg_start[sg], e = sg + 1 < n_seg ? seg_start[sg + 1] : n_total;
+	const int32_t n = (int32_t)(e - b);
+	const u128 *A = a + b;
+	int32_t *F = f + b, *PP = pp + b, *T = t + b;            // PP holds segment-local predecessor indices (-1 none)
+	Tree<true> Tm; Tm.nd = nd_main + b; Tm.root = -1;
+	Tree<false> Ti; Ti.nd = nd_inner + b; Ti.root = -1;
+	int32_t max_dist = P.max_dist, max_dist_inner = P.max_dist_inner;
+	if (max_dist < P.bw) max_dist = P.bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	int32_t st = 0, st_inner = 0, i0 = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		const u128 ai = A[i];
+		int32_t max_j = -1, q_span = (int32_t)(ai.y >> 32 & 0xff), max_f = q_span;
+		if (i0 < i && A[i0].x != ai.x) {
+			for (int32_t j = i0; j < i; ++j) {
+				const u128 aj = A[j];
+				const double pri = -((double)F[j] + 0.5 * (double)P.pen_gap * (double)((int32_t)aj.x + (int32_t)aj.y));
+				Tm.nd[j].y = (int32_t)aj.y, Tm.nd[j].pri = pri;
+				Tm.insert(j);
+				if (max_dist_inner > 0) { Ti.nd[j].y = (int32_t)aj.y; Ti.insert(j); }
+			}
+			i0 = i;
+		}
+		// anchors [st,i0) are in the tree; [i0,i) share x with anchor i and are not inserted yet
+		while (st < i && (ai.x >> 32 != A[st].x >> 32 || ai.x > A[st].x + (uint64_t)max_dist || (int32_t)Tm.sz(Tm.root) > P.cap)) {
+			if (st < i0) Tm.erase(st);
+			++st;
+		}
+		if (max_dist_inner > 0) {
+			while (st_inner < i && (ai.x >> 32 != A[st_inner].x >> 32 || ai.x > A[st_inner].x + (uint64_t)max_dist_inner || (int32_t)Ti.sz(Ti.root) > P.cap)) {
+				if (st_inner < i0) Ti.erase(st_inner);
+				++st_inner;
+			}
+		}
+		const int32_t yi = (int32_t)ai.y;
+		int32_t q = Tm.rmq(yi - max_dist, INT32_MAX, yi, 0);
+		if (q >= 0) {
+			int32_t sc, exact, width, n_skip = 0, j = q;
+			sc = F[j] + score_pair(ai, A[j], P.pen_gap, P.pen_skip, &exact, &width);
+			if (width <= P.bw && sc > max_f) max_f = sc, max_j = j;
+			if (!exact && Ti.root >= 0 && yi > 0) {
+				// largest key <= (yi-1, +inf), then walk in descending key order (krmq.h:97-109,306-340)
+				Iter it; int32_t p = Ti.root, lower = -1;
+				while (p >= 0) { if (yi - 1 < Ti.nd[p].y) p = Ti.nd[p].c[0]; else lower = p, p = Ti.nd[p].c[1]; }
+				if (lower >= 0) {
+					it.top = -1;
+					for (p = Ti.root; p >= 0;) { int c = Ti.cmp(Ti.nd[lower].y, lower, p); it.stack[++it.top] = p; if (c < 0) p = Ti.nd[p].c[0]; else if (c > 0) p = Ti.nd[p].c[1]; else break; }
+					for (;;) {
+						const int32_t ej = it.stack[it.top];
+						if (Ti.nd[ej].y < yi - max_dist_inner) break;
+						j = ej;
+						sc = F[j] + score_pair(ai, A[j], P.pen_gap, P.pen_skip, nullptr, &width);
+						if (width <= P.bw) {
+							if (sc > max_f) { max_f = sc, max_j = j; if (n_skip > 0) --n_skip; }
+							else if (T[j] == i) { if (++n_skip > P.max_skip) break; }
+							if (PP[j] >= 0) T[PP[j]] = i;
+						}
+						// predecessor in key order
+						p = Ti.nd[it.stack[it.top]].c[0];
+						if (p >= 0) { for (; p >= 0; p = Ti.nd[p].c[1]) it.stack[++it.top] = p; }
+						else {
+							do { p = it.stack[it.top--]; } while (it.top >= 0 && p == Ti.nd[it.stack[it.top]].c[0]);
+							if (it.top < 0) break;
+						}
+					}
+				}
+			}
+		}
+		F[i] = max_f, PP[i] = max_j;
+	}
+}
+
+// T[] marks inside a segment use segment-local anchor numbers as the reference uses global ones: `t[j] == i`
+// only ever compares marks written during the same query, and marks never cross a segment (the inner tree is
+// empty at a segment start), so the numbering is immaterial as long as it is injective within a segment...
+// EXCEPT for the initial zeros (calloc, lchain.c:268): t[j]==0 matches i==0 only for the first anchor of the
+// whole query, which has no predecessors.  Segment-local numbering would make anchor 0 of EVERY segment match
+// zero-initialised marks, but that anchor has an empty tree, so no mark is ever read for it.
+
+__global__ void k_seg_flags(const u128 *__restrict__ a, uint64_t n, int32_t max_dist, uint32_t *__restrict__ flag)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (i == 0) { flag[i] = 1; return; }
+	if (flag[i]) return;                                      // query start, set by k_mark_query_starts
+	const uint64_t x = a[i].x, px = a[i - 1].x;
+	flag[i] = (x >> 32 != px >> 32 || x > px + (uint64_t)max_dist) ? 1u : 0u;
+}
+__global__ void k_mark_query_starts(const uint64_t *__restrict__ q_aoff, int n_seq, uint64_t n, uint32_t *__restrict__ flag)
+{
+	int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n_seq) { uint64_t o = q_aoff[q]; if (o < n && q_aoff[q + 1] > o) flag[o] = 1; }
+}
+__global__ void k_seg_starts(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ pos, uint64_t n, uint64_t *__restrict__ seg_start)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && flag[i]) seg_start[pos[i]] = i;
+}
+__global__ void k_seg_len(const uint64_t *__restrict__ seg_start, uint32_t n_seg, uint64_t n, uint32_t *__restrict__ neg_len, uint32_t *__restrict__ id)
+{
+	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_seg) return;
+	uint64_t e = s + 1 < n_seg ? seg_start[s + 1] : n;
+	neg_len[s] = 0xffffffffu - (uint32_t)(e - seg_start[s]); id[s] = s;
+}
+// make predecessor indices query-local (the segment kernel wrote segment-local ones)
+__global__ void k_fix_pred(const uint64_t *__restrict__ seg_start, uint32_t n_seg, uint64_t n, const uint64_t *__restrict__ q_aoff, int n_seq,
+                           const uint32_t *__restrict__ seg_id_incl, int32_t *__restrict__ pp)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int32_t p = pp[i];
+	if (p < 0) return;
+	const uint64_t sb = seg_start[seg_id_incl[i] - 1];
+	int lo = 0, hi = n_seq;
+	while (lo < hi) { int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= i) lo = m + 1; else hi = m; }
+	pp[i] = (int32_t)(sb + (uint64_t)p - q_aoff[lo]);
+}
+
+__device__ inline int32_t bk_end(int32_t max_drop, const u128 *z, const int32_t *f, const int32_t *p, int32_t *t, int64_t k) // lchain.c:9-25
+{
+	int32_t i = (int32_t)z[k].y, end_i = -1, max_i = i, max_s = 0;
+	if (i < 0 || t[i] != 0) return i;
+	do {
+		int32_t s;
+		t[i] = 2;
+		end_i = i = p[i];
+		s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
+		if (s > max_s) max_s = s, max_i = i;
+		else if (max_s - s > max_drop) break;
+	} while (i >= 0 && t[i] == 0);
+	for (i = (int32_t)z[k].y; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
+	return max_i;
+}
+
+// one lane per query: lchain.c:27-111.  Outputs u[] (score<<32|cnt) and the compacted anchors.
+__global__ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
+                            const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, u128 *__restrict__ z_all,
+                            uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
+                            ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out)
+{
+	int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_seq) return;
+	const uint64_t b = q_aoff[q];
+	const int64_t n = (int64_t)(q_aoff[q + 1] - b);
+	n_u_out[q] = 0, n_v_out[q] = 0;
+	if (n == 0) return;
+	uint32_t head[256], tail[256];
+	const u128 *A = a + b; const int32_t *f = f_all + b, *p = p_all + b;
+	int32_t *t = t_all + b, *v = v_all + b;
+	u128 *z = z_all + b, *w = w_all + b, *out = out_all + b;
+	uint64_t *u = u_all + b, *u2 = u2_all + b;
+	int64_t n_z = 0, k, i, n_v = 0; int32_t n_u = 0;
+	for (i = 0; i < n; ++i) if (f[i] >= P.min_sc) { z[n_z].x = (uint64_t)f[i], z[n_z].y = (uint64_t)i; ++n_z; }
+	if (n_z == 0) return;
+	radix_sort_128x_exact(z, z + n_z, head, tail);
+	for (i = 0; i < n; ++i) t[i] = 0;
+	const int32_t max_drop = P.bw;
+	for (k = n_z - 1; k >= 0; --k) {
+		if (t[z[k].y] != 0) continue;
+		int64_t n_v0 = n_v; int32_t end_i, sc, ii;
+		end_i = bk_end(max_drop, z, f, p, t, k);
+		for (ii = (int32_t)z[k].y; ii != end_i; ii = p[ii]) v[n_v++] = ii, t[ii] = 1;
+		sc = ii < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[ii];
+		if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
+		else n_v = n_v0;
+	}
+	n_u_out[q] = n_u, n_v_out[q] = (int32_t)n_v;
+	if (n_u == 0) return;
+	// compact_a: chains to ascending anchor order (into z, reused as scratch b[]), then order chains by first target position
+	u128 *bb = z;
+	for (i = 0, k = 0; i < n_u; ++i) {
+		int32_t k0 = (int32_t)k, ni = (int32_t)u[i];
+		for (int32_t j = 0; j < ni; ++j) bb[k++] = A[v[k0 + (ni - j - 1)]];
+	}
+	for (i = k = 0; i < n_u; ++i) { w[i].x = bb[k].x, w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
+	radix_sort_128x_exact(w, w + n_u, head, tail);
+	for (i = k = 0; i < n_u; ++i) {
+		int32_t j = (int32_t)w[i].y, nn = (int32_t)u[j];
+		u2[i] = u[j];
+		const u128 *src = bb + (w[i].y >> 32);
+		for (int32_t m = 0; m < nn; ++m) out[k + m] = src[m];
+		k += nn;
+	}
+	for (i = 0; i < n_u; ++i) u[i] = u2[i];
+}
+
+
+void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st)
+{
+	const int n_seq = S.n_seq;
+	O.n_u.assign((size_t)n_seq, 0); O.n_v.assign((size_t)n_seq, 0); O.u.clear(); O.a.clear();
+	if (n_a == 0) return;
+	if (n_a >= (1ULL << 31)) throw std::runtime_error("pga: more than 2^31 anchors in one batch");
+	ChainParams P;
+	P.max_dist = opt.max_gap, P.max_dist_inner = opt.rmq_inner_dist, P.bw = opt.bw, P.max_skip = opt.max_chain_skip, P.cap = opt.rmq_size_cap;
+	P.min_cnt = opt.min_cnt, P.min_sc = opt.min_chain_score;
+	P.pen_gap = (float)(opt.chain_gap_scale * 0.01 * k);     // map.c:273: float*double*int evaluated in double, stored to float
+	P.pen_skip = (float)(opt.chain_skip_scale * 0.01 * k);
+	int32_t seg_dist = P.max_dist < P.bw ? P.bw : P.max_dist;
+	const unsigned nba = (unsigned)((n_a + 255) / 256);
+	// segments
+	DBuf<uint32_t> flag(n_a + 1); flag.zero(st);
+	hipLaunchKernelGGL(k_mark_query_starts, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, st, q_aoff.p, n_seq, n_a, flag.p);
+	hipLaunchKernelGGL(k_seg_flags, dim3(nba), dim3(256), 0, st, a.p, n_a, seg_dist, flag.p);
+	DBuf<uint64_t> pos(n_a + 1);
+	{
+		size_t tb = 0;
+		auto it = rocprim::make_transform_iterator(flag.p, [] __device__ (uint32_t v) { return (uint64_t)v; });
+		PGA_HIP(rocprim::exclusive_scan(nullptr, tb, it, pos.p, (uint64_t)0, n_a + 1, rocprim::plus<uint64_t>(), st));
+		DBuf<uint8_t> tmp(tb ? tb : 1);
+		PGA_HIP(rocprim::exclusive_scan(tmp.p, tb, it, pos.p, (uint64_t)0, n_a + 1, rocprim::plus<uint64_t>(), st));
+	}
+	uint64_t n_seg64 = 0;
+	PGA_HIP(hipMemcpyAsync(&n_seg64, pos.p + n_a, 8, hipMemcpyDeviceToHost, st));
+	PGA_HIP(hipStreamSynchronize(st));
+	const uint32_t n_seg = (uint32_t)n_seg64;
+	DBuf<uint64_t> seg_start(n_seg);
+	hipLaunchKernelGGL(k_seg_starts, dim3(nba), dim3(256), 0, st, flag.p, pos.p, n_a, seg_start.p);
+	// inclusive segment id per anchor (for the predecessor fix-up): incl = excl + flag
+	DBuf<uint32_t> seg_incl(n_a);
+	{
+		struct Op { const uint32_t *flag; const uint64_t *pos; uint32_t *out; };
+		Op op{flag.p, pos.p, seg_incl.p};
+		PGA_HIP(rocprim::transform(rocprim::make_counting_iterator<uint64_t>(0), rocprim::make_discard_iterator(), n_a,
+		        [op] __device__ (uint64_t i) { op.out[i] = (uint32_t)(op.pos[i] + op.flag[i]); return 0; }, st));
+	}
+	// longest segments first, so that the lanes of a wave carry similar work
+	DBuf<uint32_t> neg_len(n_seg), ord0(n_seg), neg_len2(n_seg), ord(n_seg);
+	hipLaunchKernelGGL(k_seg_len, dim3((n_seg + 255) / 256), dim3(256), 0, st, seg_start.p, n_seg, n_a, neg_len.p, ord0.p);
+	{
+		size_t tb = 0;
+		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 0, 32, st));
+		DBuf<uint8_t> tmp(tb ? tb : 1);
+		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 0, 32, st));
+	}
+	DBuf<CNode> nd_main(n_a), nd_inner(n_a);
+	DBuf<int32_t> f(n_a), pp(n_a), t(n_a), v(n_a);
+	t.zero(st);
+	hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+	hipLaunchKernelGGL(k_fix_pred, dim3(nba), dim3(256), 0, st, seg_start.p, n_seg, n_a, q_aoff.p, n_seq, seg_incl.p, pp.p);
+	// backtrack + compact, one lane per query
+	DBuf<u128> z(n_a), w(n_a), out(n_a);
+	DBuf<uint64_t> u(n_a), u2(n_a);
+	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
+	hipLaunchKernelGGL(k_backtrack, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p);
+	PGA_HIP(hipGetLastError());
+	O.n_u = n_u.download(st); O.n_v = n_v.download(st);
+	O.u = u.download(st);
+	std::vector<u128> oa = out.download(st);
+	O.a.swap(oa);
+}
+
+} // namespace pga

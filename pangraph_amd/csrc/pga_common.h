@@ -1,0 +1,87 @@
+// pga_common.h -- shared declarations of libpgalign.so (HIP backend, gfx950 only).
+//
+// Stage-separated pairwise block-alignment backend for pangraph's `build`:
+//   sketch -> index -> seed/anchor -> chain -> regions -> banded dual-affine DP -> records.
+// Device data is structure-of-arrays, sized for one whole batch ("level") at a time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/pga_mm2_abi.h"
+
+#define PGA_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+	throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " __FILE__ ":" + std::to_string(__LINE__)); } while (0)
+
+namespace pga {
+
+// ---- device buffer ----
+template <class T> struct DBuf {
+	T *p = nullptr; size_t n = 0, cap = 0;
+	DBuf() {}
+	explicit DBuf(size_t n_) { alloc(n_); }
+	DBuf(const DBuf&) = delete; DBuf &operator=(const DBuf&) = delete;
+	DBuf(DBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+	DBuf &operator=(DBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+	~DBuf() { release(); }
+	void release() { if (p) (void)hipFree(p); p = nullptr; n = cap = 0; }
+	void alloc(size_t n_) { // contents undefined
+		if (n_ > cap) { release(); size_t c = n_ + n_ / 8 + 64; PGA_HIP(hipMalloc((void**)&p, c * sizeof(T))); cap = c; }
+		n = n_;
+	}
+	void zero(hipStream_t s = 0) { if (n) PGA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+	void upload(const T *h, size_t n_, hipStream_t s = 0) { alloc(n_); if (n_) PGA_HIP(hipMemcpyAsync(p, h, n_ * sizeof(T), hipMemcpyHostToDevice, s)); }
+	void upload(const std::vector<T> &h, hipStream_t s = 0) { upload(h.data(), h.size(), s); }
+	std::vector<T> download(hipStream_t s = 0) const {
+		std::vector<T> h(n);
+		if (n) { PGA_HIP(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(hipStreamSynchronize(s)); }
+		return h;
+	}
+};
+
+struct u128 { uint64_t x, y; };
+
+// ---- the sequence set of one batch, resident in HBM ----
+struct SeqSet {
+	int n_seq = 0;
+	uint64_t total = 0;                 // sum of lengths
+	std::vector<uint64_t> off;          // n_seq+1 offsets into nt4
+	std::vector<uint32_t> len;
+	std::vector<std::string> name;
+	std::vector<uint8_t> h_nt4;         // host copy (the align driver's CIGAR post-processing reads it)
+	DBuf<uint8_t> d_nt4;                // 1 byte per base: 0..3 ACGT, 4 other (sketch.c:9-26 table)
+	DBuf<uint64_t> d_off;
+	DBuf<uint32_t> d_len;
+};
+
+// ---- minimizers of a SeqSet (sorted by sequence, then by position == mm_sketch output order) ----
+struct Minimizers {
+	DBuf<u128> mz;                      // x = hash<<8|k, y = rid<<32|pos<<1|strand
+	DBuf<uint64_t> seq_off;             // n_seq+1
+	std::vector<uint64_t> h_seq_off;
+	uint64_t n = 0;
+};
+
+// ---- index: distinct hashes ascending + CSR occurrence lists (y ascending inside a key) ----
+struct Index {
+	int w = 0, k = 0;
+	uint64_t n_keys = 0, n_occ = 0;
+	DBuf<uint64_t> key;
+	DBuf<uint32_t> occ_off;             // n_keys+1
+	DBuf<uint64_t> occ;
+	int32_t mid_occ_raw = 0;            // mm_idx_cal_max_occ(2e-4) before clamping
+};
+
+struct Timers { double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0; };
+
+// stage entry points (each in its own .hip/.cpp)
+void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, hipStream_t st);
+void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st);
+int32_t index_cal_max_occ(const Index &I, float f, hipStream_t st);
+
+} // namespace pga

@@ -1,0 +1,378 @@
+// pga_ksw.hip -- kernel #5: batched dual-affine-gap extension / global alignment with backtrack.
+//
+// Replaces ksw_extd2_sse() (reference: packages/minimap2-sys/minimap2/ksw2_extd2_sse.c:34-401) together with
+// ksw_backtrack / ksw_apply_zdrop (ksw2.h:127-184): the 57 % hotspot of the path.
+//
+// One wavefront per DP problem, anti-diagonal sweep, lane <-> target coordinate t:
+//   * the six difference rows u,v,x,y,x2,y2 and the score profile s live in LDS (or in a per-wave HBM slab for
+//     problems wider than LDS_T); the t-1 neighbour that SSE gets with _mm_slli_si128 comes from a wave shuffle,
+//     with a scalar carry across 64-lane chunks;
+//   * arithmetic is the reference's int8 difference recurrence, evaluated in 32-bit lanes and re-wrapped to
+//     8 bits (v_bfe_i32) wherever the SSE code produces a byte, INCLUDING the lanes the SSE code computes
+//     outside the band (16-lane rounding of [st0,en0], stale score profile, ksw2_extd2_sse.c:140-190): banded
+//     extensions depend on them;
+//   * the 1-byte/cell direction matrix streams to a per-wave HBM slab with coalesced 64-byte stores and is
+//     walked back by lane 0; CIGARs are appended to a shared pool with one atomic per problem;
+//   * exact-max diagonals reduce (H,t) with the reference's 4-lane-strided tie order encoded in the key.
+// Persistent launch: a fixed grid of waves pulls problems from an atomic queue (problem sizes are ragged).
+#include "pga_common.h"
+#include "pga_dp.h"
+
+namespace pga {
+
+#define KSW_NEG_INF (-0x40000000)
+#define EZ_RIGHT      0x02
+#define EZ_APPROX_MAX 0x08
+#define EZ_APPROX_DROP 0x10
+#define EZ_EXTZ_ONLY  0x40
+#define EZ_REV_CIGAR  0x80
+
+__device__ __forceinline__ int sx8(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
+
+struct SeqView {
+	const uint8_t *t_base, *q_base;   // target window start / query sequence start in the resident nt4 array
+	int32_t qlen_full, qs, qlen, tlen;
+	bool q_rev, seq_rev;
+	__device__ __forceinline__ int target(int i) const { // 0 beyond the window (the reference's zero padding)
+		if (i >= tlen) return 0;
+		return t_base[seq_rev ? tlen - 1 - i : i];
+	}
+	__device__ __forceinline__ int query(int j) const {
+		if (j < 0 || j >= qlen) return 0;
+		int pj = qs + (seq_rev ? qlen - 1 - j : j);
+		if (!q_rev) return q_base[pj];
+		int c = q_base[qlen_full - 1 - pj];
+		return c < 4 ? 3 - c : 4;
+	}
+};
+
+__device__ __forceinline__ void diag_range(int r, int qlen, int tlen, int w, int &st0, int &en0)
+{
+	int st = 0, en = tlen - 1;
+	if (st < r - qlen + 1) st = r - qlen + 1;
+	if (en > r) en = r;
+	if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+	if (en > (r + w) >> 1) en = (r + w) >> 1;
+	st0 = st, en0 = en;
+}
+
+__device__ __forceinline__ long long wave_max64(long long v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		int lo = __shfl_xor((int)(v & 0xffffffffLL), d), hi = __shfl_xor((int)(v >> 32), d);
+		long long o = ((long long)hi << 32) | (unsigned int)lo;
+		v = o > v ? o : v;
+	}
+	return v;
+}
+
+#define LDS_T 2048   // problems with tlen16 <= LDS_T keep their rows in LDS
+
+__global__ __launch_bounds__(64)
+void k_extd2(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+             uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes,
+             DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
+{
+	__shared__ int8_t s_rows[7 * LDS_T];
+	__shared__ int32_t s_H[LDS_T];
+	__shared__ uint32_t s_job;
+	const int lane = threadIdx.x;
+	uint8_t *slab = slab_all + (size_t)blockIdx.x * slab_bytes;
+
+	for (;;) {
+		if (lane == 0) s_job = atomicAdd(job_counter, 1u);
+		__syncthreads();
+		const uint32_t jid = s_job;
+		__syncthreads();
+		if (jid >= n_jobs) break;
+		const DpJob J = jobs[jid];
+		SeqView V;
+		V.t_base = nt4 + J.t_off, V.q_base = nt4 + J.q_off, V.qlen_full = J.qlen_full, V.qs = J.qs, V.qlen = J.qlen, V.tlen = J.tlen;
+		V.q_rev = J.q_rev, V.seq_rev = J.seq_rev;
+		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
+		int w = J.w;
+		int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+		const int qe_h = q + e;                                   // ksw2_extd2_sse.c:73 (taken before the swap)
+		if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t, t = e, e = e2, e2 = t; }
+		const int qe = q + e, qe2 = q2 + e2;
+		const int sc_mch = P.sc_mch, sc_mis = P.sc_mis, sc_N = P.sc_ambi == 0 ? -e2 : P.sc_ambi;
+		const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
+		if (w < 0) w = tlen > qlen ? tlen : qlen;
+		const int tlen16 = (tlen + 15) / 16 * 16;
+		int n_col = qlen < tlen ? qlen : tlen;
+		n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
+		int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+		if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+		const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+		// row storage: LDS when it fits, else the head of this wave's HBM slab; the direction matrix follows
+		int8_t *rows; int32_t *H; uint8_t *pmat;
+		if (tlen16 <= LDS_T) { rows = s_rows; H = s_H; pmat = slab; }
+		else { rows = (int8_t*)slab; H = (int32_t*)(slab + (((size_t)7 * tlen16 + 15) & ~(size_t)15)); pmat = (uint8_t*)(H + tlen16); }
+		int8_t *u = rows, *v = u + tlen16, *x = v + tlen16, *y = x + tlen16, *x2 = y + tlen16, *y2 = x2 + tlen16, *s = y2 + tlen16;
+		uint32_t *cig_tmp = (uint32_t*)(pmat + (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15));
+		for (int t = lane; t < tlen16; t += 64) {
+			u[t] = v[t] = x[t] = y[t] = (int8_t)(-q - e);
+			x2[t] = y2[t] = (int8_t)(-q2 - e2);
+			s[t] = 0;
+			if (!approx_max) H[t] = KSW_NEG_INF;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__syncthreads();
+
+		// ez
+		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
+		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
+		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
+
+		for (int r = 0; r < qlen + tlen - 1; ++r) {
+			int st0, en0;
+			diag_range(r, qlen, tlen, w, st0, en0);
+			if (st0 > en0) { ez_zdropped = 1; break; }
+			const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+			int x1, x21, v1;
+			if (st > 0) {
+				if (st - 1 >= last_st && st - 1 <= last_en) x1 = x[st - 1], x21 = x2[st - 1], v1 = v[st - 1];
+				else x1 = sx8(-q - e), x21 = sx8(-q2 - e2), v1 = sx8(-q - e);
+			} else {
+				x1 = sx8(-q - e), x21 = sx8(-q2 - e2);
+				v1 = r == 0 ? sx8(-q - e) : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : sx8(-e2);
+			}
+			if (en >= r && lane == 0) {
+				y[r] = (int8_t)(-q - e), y2[r] = (int8_t)(-q2 - e2);
+				u[r] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+			}
+			// score profile, refreshed in 16-lane groups starting at st0 (ksw2_extd2_sse.c:165-181)
+			{
+				const int span = ((en0 - st0) / 16 + 1) * 16;
+				for (int o = lane; o < span; o += 64) {
+					const int t = st0 + o;
+					if (t < tlen16) {
+						const int a = V.target(t), b = V.query(r - t);
+						int sc = a == b ? sc_mch : sc_mis;
+						if (a == 4 || b == 4) sc = sc_N;
+						s[t] = (int8_t)sc;
+					}
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			__syncthreads();
+			uint8_t *prow = pmat + (size_t)r * n_col;
+			for (int c0 = st; c0 <= en; c0 += 64) {
+				const int t = c0 + lane;
+				const bool act = t <= en;
+				int xo = 0, vo = 0, x2o = 0, ut = 0, yo = 0, y2o = 0, z = 0;
+				if (act) { xo = x[t], vo = v[t], x2o = x2[t], ut = u[t], yo = y[t], y2o = y2[t], z = s[t]; }
+				int xt1 = __shfl_up(xo, 1), vt1 = __shfl_up(vo, 1), x2t1 = __shfl_up(x2o, 1);
+				if (lane == 0) xt1 = x1, vt1 = v1, x2t1 = x21;
+				x1 = __shfl(xo, 63), v1 = __shfl(vo, 63), x21 = __shfl(x2o, 63);
+				if (act) {
+					int a = sx8(xt1 + vt1), b = sx8(yo + ut), a2 = sx8(x2t1 + vt1), b2 = sx8(y2o + ut), d;
+					if (!right) { // ties keep the earlier state (ksw2_extd2_sse.c:238-258)
+						d = 0;
+						if (a > z) d = 1, z = a;
+						if (b > z) d = 2, z = b;
+						if (a2 > z) d = 3, z = a2;
+						if (b2 > z) d = 4, z = b2;
+					} else {      // ties move to the later state (ksw2_extd2_sse.c:285-305)
+						d = z > a ? 0 : 1;  z = z > a ? z : a;
+						d = z > b ? d : 2;  z = z > b ? z : b;
+						d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+						d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+					}
+					if (sc_mch < z) z = sc_mch;
+					u[t] = (int8_t)(z - vt1), v[t] = (int8_t)(z - ut);
+					int tmp = sx8(z - q); a = sx8(a - tmp), b = sx8(b - tmp);
+					tmp = sx8(z - q2); a2 = sx8(a2 - tmp), b2 = sx8(b2 - tmp);
+					if (!right) {
+						x[t]  = (int8_t)((a  > 0 ? a  : 0) - qe);  if (a  > 0) d |= 0x08;
+						y[t]  = (int8_t)((b  > 0 ? b  : 0) - qe);  if (b  > 0) d |= 0x10;
+						x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - qe2); if (a2 > 0) d |= 0x20;
+						y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - qe2); if (b2 > 0) d |= 0x40;
+					} else {
+						x[t]  = (int8_t)((0 > a  ? 0 : a)  - qe);  if (!(0 > a))  d |= 0x08;
+						y[t]  = (int8_t)((0 > b  ? 0 : b)  - qe);  if (!(0 > b))  d |= 0x10;
+						x2[t] = (int8_t)((0 > a2 ? 0 : a2) - qe2); if (!(0 > a2)) d |= 0x20;
+						y2[t] = (int8_t)((0 > b2 ? 0 : b2) - qe2); if (!(0 > b2)) d |= 0x40;
+					}
+					prow[t - st] = (uint8_t)d;
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			__syncthreads();
+			bool stop = false;
+			if (!approx_max) { // ksw2_extd2_sse.c:322-366
+				int max_H, max_t;
+				if (r > 0) {
+					const int Hen = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + v[en0];
+					__syncthreads();
+					const int en1 = st0 + (en0 - st0) / 4 * 4;
+					long long best = ((long long)Hen << 32) | 0xffffffffu;                // the last cell wins every tie
+					for (int t = st0 + lane; t < en0; t += 64) {
+						const int h = H[t] + v[t];
+						H[t] = h;
+						const unsigned ord = t < en1 ? 1u + ((unsigned)((t - st0) & 3) << 28) + (unsigned)t : 1u + (4u << 28) + (unsigned)t;
+						const long long key = ((long long)h << 32) | (0xffffffffu - ord);
+						best = key > best ? key : best;
+					}
+					if (lane == 0) H[en0] = Hen;
+					best = wave_max64(best);
+					max_H = (int)(best >> 32);
+					const unsigned ord = 0xffffffffu - (unsigned)(best & 0xffffffffLL);
+					max_t = ord == 0 ? en0 : (int)((ord - 1) & 0x0fffffffu);
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+					__syncthreads();
+				} else {
+					if (lane == 0) H[0] = v[0] - qe_h;
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+					__syncthreads();
+					max_H = H[0], max_t = 0;
+				}
+				if (en0 == tlen - 1) { const int h = H[en0]; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
+				if (r - st0 == qlen - 1) { const int h = H[st0]; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+				// ksw_apply_zdrop (ksw2.h:168-184)
+				if (max_H > ez_max) ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+				else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+					if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
+				}
+				if (!stop && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H[tlen - 1];
+			} else {            // ksw2_extd2_sse.c:367-384: one tracked cell per diagonal
+				if (r > 0) {
+					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+						const int d0 = v[last_H0_t], d1 = u[last_H0_t + 1];
+						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += v[last_H0_t];
+					else ++last_H0_t, H0 += u[last_H0_t];
+				} else H0 = v[0] - qe_h, last_H0_t = 0;
+				if (flag & EZ_APPROX_DROP) {
+					if (H0 > ez_max) ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
+					else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
+						const int tl = last_H0_t - ez_max_t, ql = (r - last_H0_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+						if (zdrop >= 0 && ez_max - H0 > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
+					}
+				}
+				if (!stop && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H0;
+			}
+			if (stop) break;
+			last_st = st, last_en = en;
+		}
+
+		// ---- backtrack (ksw2.h:127-159, is_rot=1) by lane 0; off/off_end are recomputed from r ----
+		int n_cigar = 0;
+		int bi = -1, bj = -1;
+		if (!ez_zdropped && !(flag & EZ_EXTZ_ONLY)) bi = tlen - 1, bj = qlen - 1;
+		else if (!ez_zdropped && (flag & EZ_EXTZ_ONLY) && ez_mqe + end_bonus > ez_max) ez_reach_end = 1, bi = ez_mqe_t, bj = qlen - 1;
+		else if (ez_max_t >= 0 && ez_max_q >= 0) bi = ez_max_t, bj = ez_max_q;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__syncthreads();
+		if (lane == 0 && bi >= 0 && bj >= 0) {
+			int i = bi, j = bj, state = 0;
+			uint32_t last_op = 0xffffffffu;
+			auto push = [&](uint32_t op, uint32_t len) {
+				if (n_cigar == 0 || op != last_op) { cig_tmp[n_cigar++] = len << 4 | op; last_op = op; }
+				else cig_tmp[n_cigar - 1] += len << 4;
+			};
+			while (i >= 0 && j >= 0) {
+				const int r = i + j;
+				int st0, en0, force_state = -1;
+				diag_range(r, qlen, tlen, w, st0, en0);
+				const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
+				if (i < off) force_state = 2;
+				if (i > off_end) force_state = 1;
+				const uint32_t tmp = force_state < 0 ? pmat[(size_t)r * n_col + i - off] : 0;
+				if (state == 0) state = tmp & 7;
+				else if (!(tmp >> (state + 2) & 1)) state = 0;
+				if (state == 0) state = tmp & 7;
+				if (force_state >= 0) state = force_state;
+				if (state == 0) push(0, 1), --i, --j;
+				else if (state == 1 || state == 3) push(2, 1), --i;
+				else push(1, 1), --j;
+			}
+			if (i >= 0) push(2, (uint32_t)(i + 1));
+			if (j >= 0) push(1, (uint32_t)(j + 1));
+		}
+		n_cigar = __shfl(n_cigar, 0);
+		unsigned long long base = 0;
+		if (lane == 0 && n_cigar > 0) base = atomicAdd(pool_cursor, (unsigned long long)n_cigar);
+		base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), 0) << 32) | (unsigned)__shfl((int)(base & 0xffffffffULL), 0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__syncthreads();
+		const bool rev_cigar = flag & EZ_REV_CIGAR;
+		if (base + (unsigned long long)n_cigar <= pool_cap)
+			for (int c = lane; c < n_cigar; c += 64) cigar_pool[base + c] = rev_cigar ? cig_tmp[c] : cig_tmp[n_cigar - 1 - c];
+		if (lane == 0) {
+			DpRes R;
+			R.max = ez_max, R.max_q = ez_max_q, R.max_t = ez_max_t, R.mqe = ez_mqe, R.mqe_t = ez_mqe_t, R.mte = ez_mte, R.mte_q = ez_mte_q;
+			R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = n_cigar, R.cigar_off = base;
+			res[jid] = R;
+		}
+		__syncthreads();
+	}
+}
+
+size_t dp_slab_bytes(int qlen, int tlen, int w)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	size_t tlen16 = ((size_t)tlen + 15) / 16 * 16;
+	size_t n_col = (size_t)(qlen < tlen ? qlen : tlen);
+	n_col = (((n_col < (size_t)w + 1 ? n_col : (size_t)w + 1) + 15) / 16 + 1) * 16;
+	size_t b = 0;
+	if (tlen16 > LDS_T) b += ((7 * tlen16 + 15) & ~(size_t)15) + 4 * tlen16;
+	b += (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15);
+	b += 4 * ((size_t)qlen + tlen + 8);
+	return (b + 255) & ~(size_t)255;
+}
+
+void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st)
+{
+	res.clear(); cigars.clear();
+	const size_t n = jobs.size();
+	if (n == 0) return;
+	// two size classes so that the per-wave HBM slabs of the many small problems stay small
+	std::vector<uint32_t> cls[2];
+	size_t slab_max[2] = {0, 0};
+	const size_t small_limit = (size_t)1 << 20;
+	std::vector<size_t> need(n);
+	unsigned long long cig_total = 0;
+	for (size_t i = 0; i < n; ++i) {
+		need[i] = dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
+		int c = need[i] <= small_limit ? 0 : 1;
+		cls[c].push_back((uint32_t)i);
+		if (need[i] > slab_max[c]) slab_max[c] = need[i];
+		cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;
+	}
+	res.resize(n);
+	DBuf<DpRes> d_res(n);
+	DBuf<uint32_t> d_pool((size_t)cig_total);
+	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
+	std::vector<uint32_t> order; order.reserve(n);
+	for (int c = 0; c < 2; ++c) {
+		if (cls[c].empty()) continue;
+		// biggest problems first: the persistent waves then finish together
+		std::vector<uint32_t> &ids = cls[c];
+		std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return need[a] > need[b]; });
+		std::vector<DpJob> jb(ids.size());
+		for (size_t i = 0; i < ids.size(); ++i) jb[i] = jobs[ids[i]];
+		DBuf<DpJob> d_jobs; d_jobs.upload(jb, st);
+		DBuf<DpRes> d_r(ids.size());
+		DBuf<uint32_t> d_cnt(1); d_cnt.zero(st);
+		size_t n_waves = c == 0 ? 256 * 16 : 256 * 2;
+		if (n_waves > ids.size()) n_waves = ids.size();
+		size_t budget = (size_t)24 << 30;
+		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
+		DBuf<uint8_t> d_slab(n_waves * slab_max[c]);
+		hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
+		                   d_r.p, d_pool.p, d_cursor.p, cig_total);
+		PGA_HIP(hipGetLastError());
+		std::vector<DpRes> r = d_r.download(st);
+		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];
+	}
+	unsigned long long used = d_cursor.download(st)[0];
+	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");
+	cigars.resize((size_t)used);
+	if (used) { PGA_HIP(hipMemcpyAsync(cigars.data(), d_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st)); }
+}
+
+} // namespace pga

@@ -1,0 +1,38 @@
+// pga_pipeline.h -- stage interfaces of the batch pipeline (host orchestration in pga_api.cpp).
+#pragma once
+#include "pga_common.h"
+#include <memory>
+#include <mutex>
+
+namespace pga {
+
+// One alignment record while it is being built (mm_reg1_t + mm_extra_t, minimap.h:94-119).
+struct Reg {
+	int32_t id = 0, cnt = 0, rid = 0, score = 0, qs = 0, qe = 0, rs = 0, re = 0, parent = 0, subsc = 0, as = 0;
+	int32_t mlen = 0, blen = 0, n_sub = 0, score0 = 0;
+	uint32_t mapq = 0, split = 0, rev = 0, inv = 0, split_inv = 0, hash = 0;
+	bool has_p = false;
+	int32_t dp_score = 0, dp_max = 0, dp_max2 = 0; uint32_t n_ambi = 0;
+	std::vector<uint32_t> cigar;
+};
+
+struct ChainResult {
+	std::vector<int32_t> n_u, n_v;   // per query
+	std::vector<uint64_t> u;         // chain i of query q at q_aoff[q]+i: score<<32|cnt
+	std::vector<u128> a;             // compacted anchors of query q at q_aoff[q] .. +n_v[q]
+};
+
+struct SeedResult {
+	DBuf<u128> a; DBuf<uint64_t> q_aoff;
+	std::vector<uint64_t> h_q_aoff; std::vector<int32_t> h_rep_len;
+	uint64_t n_a = 0;
+};
+
+void build_index_ex(const Minimizers &M, int w, int k, Index &I, DBuf<uint32_t> &grp_of_mz, hipStream_t st);
+void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<uint32_t> &grp_of_mz, const mm_mapopt_t &opt,
+              const DBuf<int32_t> &d_name_rank, SeedResult &O, hipStream_t st);
+void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st);
+void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vector<uint64_t> &q_aoff, ChainResult &C, const std::vector<int32_t> &rep_len,
+                 std::vector<std::vector<Reg>> &out, int n_threads, Timers *tm, hipStream_t st);
+
+} // namespace pga

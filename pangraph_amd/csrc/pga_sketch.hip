@@ -1,0 +1,402 @@
+// pga_sketch.hip -- kernel #1: (w,k) symmetric minimizers of every sequence of a batch.
+//
+// Replaces mm_sketch() (reference: packages/minimap2-sys/minimap2/sketch.c:77-143), which the reference
+// calls once per sequence at index time (index.c:449) and again per query (map.c:66).  Bit-exact output:
+// the same records x = hash64(min(fwd,rev))<<8 | k, y = rid<<32 | lastPos<<1 | strand, in the same order.
+//
+// CDNA4 design.  The reference is a streaming state machine; here the emission rules are evaluated per
+// base position, independently (the position-parallel definition is spelled out in oracle/pgo_sketch.c):
+//   * one 256-thread workgroup per tile of TILE bases (+ a w+k halo), bases read with coalesced 16-byte
+//     loads and packed to 2 bits/base + 1 N-bit/base in LDS;
+//   * the forward/reverse k-mer words of a position are bit-field extracts of the packed LDS image
+//     (reverse strand = complement of the little-endian extract; forward = its 2-bit-group reversal);
+//   * the run length of valid bases (reset by N) is a count-leading-zeros on the N-bit window;
+//   * the window minimum (rightmost on ties, sketch.c:123,131) is a w-wide scan of 64-bit hashes in LDS;
+//   * emitted records are counted, block-scanned (wave64 shuffles) and written in position order to a
+//     per-tile staging slab; a second kernel compacts slabs into the final array.
+// HBM traffic: 1 B/base in + 16 B/minimizer staged + 16 B/minimizer re-read + 16 B/minimizer out.
+// The fast path needs an odd k (no k-mer equals its reverse complement, so every base is a window slot)
+// and w+k <= 64; any other (w,k) runs the serial kernel at the bottom (one lane per sequence), exact for
+// all inputs, slow, and never hit by pangraph's presets except through -K with an even k.
+#include "pga_common.h"
+#include <rocprim/rocprim.hpp>
+
+namespace pga {
+
+__device__ __forceinline__ uint64_t hash64(uint64_t key, uint64_t mask) // sketch.c:28-38
+{
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask;
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask;
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+__global__ void k_ascii_to_nt4(uint8_t *s, uint64_t n)
+{
+	// sketch.c:9-26: A/a=0 C/c=1 G/g=2 T/t/U/u=3, everything else 4.  16 bytes per lane per iteration.
+	uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16, stride = (uint64_t)gridDim.x * blockDim.x * 16;
+	for (; i < n; i += stride) {
+		if (i + 16 <= n) {
+			uint4 v = *reinterpret_cast<const uint4*>(s + i);
+			uint32_t in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				uint32_t o = 0;
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					uint32_t c = (in[j] >> (8 * b)) & 0xdf; // fold case
+					uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
+					if (((in[j] >> (8 * b)) & 0xff) < 0x40) code = 4; // digits/punctuation that fold onto letters
+					o |= code << (8 * b);
+				}
+				out[j] = o;
+			}
+			*reinterpret_cast<uint4*>(s + i) = make_uint4(out[0], out[1], out[2], out[3]);
+		} else {
+			for (uint64_t j = i; j < n; ++j) {
+				uint32_t r = s[j], c = r & 0xdf;
+				uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
+				if (r < 0x40) code = 4;
+				s[j] = (uint8_t)code;
+			}
+		}
+	}
+}
+
+static inline uint8_t nt4_host(uint8_t r)
+{
+	uint8_t c = r & 0xdf;
+	uint8_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
+	if (r < 0x40) code = 4;
+	return code;
+}
+
+void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, hipStream_t st)
+{
+	S.n_seq = n;
+	S.off.assign((size_t)n + 1, 0); S.len.assign(len, len + n); S.name.resize(n);
+	for (int i = 0; i < n; ++i) { S.off[i + 1] = S.off[i] + len[i]; S.name[i] = name && name[i] ? name[i] : ""; }
+	S.total = S.off[n];
+	// sequences are padded to a 16-byte multiple so the packing loads never straddle the allocation
+	S.h_nt4.assign(S.total + 64, 4);
+	for (int i = 0; i < n; ++i) {
+		const uint8_t *s = reinterpret_cast<const uint8_t*>(seq[i]);
+		uint8_t *d = S.h_nt4.data() + S.off[i];
+		for (uint32_t j = 0; j < len[i]; ++j) d[j] = nt4_host(s[j]);
+	}
+	S.d_nt4.upload(S.h_nt4, st);
+	S.d_off.upload(S.off, st);
+	S.d_len.upload(S.len, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+#define SK_THREADS 256
+#define SK_PER 8
+#define SK_TILE (SK_THREADS * SK_PER)   // bases per workgroup
+#define SK_HALO 64                      // >= w+k on the fast path
+#define SK_NONE 0xffffffffffffffffULL
+
+struct SkTile { uint32_t rid; uint32_t start; };
+
+// extract `nbits` (<= 57) bits starting at bit offset `bit` from a little-endian bit string held in 32-bit LDS words
+__device__ __forceinline__ uint64_t lds_bits(const uint32_t *w, uint32_t bit, uint32_t nbits)
+{
+	uint32_t i = bit >> 5, sh = bit & 31;
+	uint64_t lo = (uint64_t)w[i] | (uint64_t)w[i + 1] << 32;
+	uint64_t v = lo >> sh;
+	if (sh) v |= (uint64_t)w[i + 2] << (64 - sh);
+	return nbits >= 64 ? v : v & ((1ULL << nbits) - 1);
+}
+
+__device__ __forceinline__ uint64_t rev2(uint64_t x) // reverse the order of the 32 two-bit groups
+{
+	x = __brevll(x);
+	return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+}
+
+template <int W_MAX>
+__global__ __launch_bounds__(SK_THREADS)
+void k_sketch_tiles(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
+                    const SkTile *__restrict__ tiles, int w, int k, u128 *__restrict__ stage, uint32_t stage_cap,
+                    uint32_t *__restrict__ tile_cnt, int *__restrict__ overflow)
+{
+	constexpr int NPOS = SK_TILE + SK_HALO;                 // positions held: [tile_start-HALO, tile_start+TILE)
+	__shared__ uint32_t s_bits[NPOS / 16 + 4];              // 2 bits per base
+	__shared__ uint32_t s_nmask[NPOS / 32 + 4];             // 1 bit per base: 1 = not ACGT (or outside the sequence)
+	__shared__ uint64_t s_hash[SK_TILE + W_MAX + 1];        // hash of the k-mer ENDING at a position, SK_NONE if none; index 0 <-> tile_start-w-... see HB
+	__shared__ uint8_t  s_strand[SK_TILE + W_MAX + 1];
+	__shared__ uint16_t s_cur[SK_TILE + 1];                 // rightmost window minimum after each position, index 0 <-> tile_start-1
+	__shared__ uint32_t s_wsum[SK_THREADS / 64];
+	__shared__ uint32_t s_base;
+
+	const SkTile tl = tiles[blockIdx.x];
+	const uint32_t rid = tl.rid, len = seq_len[rid];
+	const int64_t t0 = tl.start;                            // first position of the tile (sequence coordinates)
+	const uint64_t goff = seq_off[rid];
+	const int tid = threadIdx.x;
+	const uint64_t mask = (1ULL << 2 * k) - 1;
+
+	// ---- 1. pack [t0-HALO, t0+TILE) to 2 bits + N bit.  Global loads are 16 B per lane and 16-B aligned in the
+	//         concatenated array, so the LDS image starts at the aligned address `ga` <= goff+t0-HALO.
+	const int64_t g_lo = (int64_t)goff + t0 - SK_HALO;      // may be negative or belong to the previous sequence
+	const int64_t ga = g_lo >= 0 ? (g_lo & ~15LL) : -(((-g_lo) + 15) & ~15LL);
+	const int pad = (int)(g_lo - ga);                        // 0..15: LDS position of g_lo
+	for (int c = tid; c < NPOS / 16 + 4; c += SK_THREADS) {
+		int64_t g = ga + (int64_t)c * 16;
+		uint32_t bits = 0, nm = 0;
+		uint4 v = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
+		if (g >= 0 && (uint64_t)g < goff + len + 16) v = *reinterpret_cast<const uint4*>(nt4 + g); // array is padded by 64 B
+		uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			uint32_t code = (in[j >> 2] >> (8 * (j & 3))) & 0xff;
+			int64_t p = g + j - (int64_t)goff;               // sequence coordinate
+			bool bad = code > 3 || p < 0 || p >= (int64_t)len;
+			bits |= (bad ? 0u : code) << (2 * j);
+			nm |= (bad ? 1u : 0u) << j;
+		}
+		s_bits[c] = bits;
+		reinterpret_cast<uint16_t*>(s_nmask)[c] = (uint16_t)nm;
+	}
+	__syncthreads();
+
+	// ---- 2. per position: k-mer words, run length, hash.  Local position q <-> sequence position t0-HALO+q;
+	//         hashes are kept for sequence positions [t0-w-1, t0+TILE): HB = index of position t0-w-1.
+	const int nb = w + k;                                     // N-bit window width for the run length
+	const int first = SK_HALO - w - 1;                        // local q of the first hashed position (>= k-1 since HALO >= w+k)
+	for (int h = tid; h < SK_TILE + w + 1; h += SK_THREADS) {
+		int q = first + h;                                    // local position (>= k because HALO >= w+k)
+		int lq = pad + q;                                     // position inside the LDS image
+		uint64_t win = lds_bits(s_bits, 2u * (uint32_t)(lq - k + 1), 2u * (uint32_t)k);   // base j of the k-mer at bits 2j
+		const bool valid = lds_bits(s_nmask, (uint32_t)(lq - k + 1), (uint32_t)k) == 0;  // k ACGT bases end here (run >= k)
+		uint64_t rv = (~win) & mask;                          // sketch.c:109
+		uint64_t fw = rev2(win) >> (64 - 2 * k);              // sketch.c:108
+		uint64_t hv = SK_NONE; uint8_t z = 0;
+		if (valid) { z = fw < rv ? 0 : 1; hv = hash64(z ? rv : fw, mask); }
+		s_hash[h] = hv; s_strand[h] = z;
+	}
+	__syncthreads();
+
+	// ---- 3. rightmost window minimum after each position t0-1 .. t0+TILE-1 (hash index of position p is p-(t0-w-1))
+	for (int c = tid; c < SK_TILE + 1; c += SK_THREADS) {
+		int hi = c + w;                                       // hash index of position t0-1+c
+		int best = hi - w + 1; uint64_t bv = s_hash[best];
+		for (int j = hi - w + 2; j <= hi; ++j) { uint64_t v = s_hash[j]; if (v <= bv) bv = v, best = j; }
+		s_cur[c] = (uint16_t)best;
+	}
+	__syncthreads();
+
+	// ---- 4. emission rules (see oracle/pgo_sketch.c header: rules A-D), two passes: count, then write
+	const int tile_n = (int)min((int64_t)SK_TILE, (int64_t)len - t0);
+	uint32_t running = 0;
+	for (int pass = 0; pass < 2; ++pass) {
+		running = 0;
+		for (int j = 0; j < SK_PER; ++j) {
+			const int c = j * SK_THREADS + tid;               // position t0+c
+			uint32_t cnt = 0;
+			int prev = 0, cur = 0, hi = 0, run = 0;
+			uint64_t xp = SK_NONE, xprev = SK_NONE;
+			bool ruleA = false, ruleB = false, ruleC1 = false, ruleC2 = false, ruleD = false;
+			if (c < tile_n) {
+				hi = c + w + 1;                               // hash index of this position
+				prev = s_cur[c], cur = s_cur[c + 1];
+				xp = s_hash[hi], xprev = s_hash[prev];
+				{   // run length again (cheap): needed for the l-thresholds
+					int lq = pad + SK_HALO + c;
+					uint64_t nwin = lds_bits(s_nmask, (uint32_t)(lq - nb + 1), (uint32_t)nb);
+					uint64_t top = nwin << (64 - nb);
+					run = top == 0 ? nb : __clzll((long long)top);
+				}
+				const bool prev_real = xprev != SK_NONE;
+				ruleA = run == w + k - 1 && prev_real;
+				if (xp <= xprev) ruleB = run >= w + k && prev_real;
+				else if (prev == hi - w) { ruleC1 = run >= w + k - 1 && prev_real; ruleC2 = run >= w + k - 1 && s_hash[cur] != SK_NONE; }
+				ruleD = (t0 + c == (int64_t)len - 1) && s_hash[cur] != SK_NONE;
+				if (ruleA) for (int t = hi - w + 1; t < hi; ++t) cnt += (s_hash[t] == xprev && t != prev);
+				cnt += ruleB + ruleC1;
+				if (ruleC2) { uint64_t xc = s_hash[cur]; for (int t = hi - w + 1; t <= hi; ++t) cnt += (s_hash[t] == xc && t != cur); }
+				cnt += ruleD;
+			}
+			// block-wide exclusive scan of cnt in position order (slab j holds positions j*256 .. j*256+255)
+			uint32_t incl = cnt;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { uint32_t n = __shfl_up(incl, d); if ((tid & 63) >= d) incl += n; }
+			if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+			__syncthreads();
+			uint32_t wbase = 0, total = 0;
+#pragma unroll
+			for (int wv = 0; wv < SK_THREADS / 64; ++wv) { uint32_t s = s_wsum[wv]; if (wv < (tid >> 6)) wbase += s; total += s; }
+			__syncthreads();
+			uint32_t o = running + wbase + incl - cnt;
+			running += total;
+			if (pass == 1 && cnt) {
+				u128 *out = stage + (size_t)blockIdx.x * stage_cap;
+				const uint64_t ybase = (uint64_t)rid << 32;
+				const int64_t pos0 = t0 - w - 1;              // sequence position of hash index 0
+				auto emit = [&](int t) {
+					if (o < stage_cap) { u128 r; r.x = s_hash[t] << 8 | (uint64_t)k; r.y = ybase | (uint64_t)(uint32_t)(pos0 + t) << 1 | s_strand[t]; out[o] = r; }
+					++o;
+				};
+				if (ruleA) for (int t = hi - w + 1; t < hi; ++t) if (s_hash[t] == xprev && t != prev) emit(t);
+				if (ruleB || ruleC1) emit(prev);
+				if (ruleC2) { uint64_t xc = s_hash[cur]; for (int t = hi - w + 1; t <= hi; ++t) if (s_hash[t] == xc && t != cur) emit(t); }
+				if (ruleD) emit(cur);
+			}
+		}
+		if (pass == 0) {
+			if (tid == 0) { tile_cnt[blockIdx.x] = running; if (running > stage_cap) atomicExch(overflow, 1); }
+			if (running == 0) break;
+		}
+	}
+}
+
+// ---- generic serial kernel: one lane per sequence, the streaming formulation (slots, ring of w entries) ----
+__global__ void k_sketch_serial(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
+                                int n_seq, int w, int k, u128 *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ cnt,
+                                u128 *__restrict__ ring_all)
+{
+	int rid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rid >= n_seq) return;
+	const uint8_t *s = nt4 + seq_off[rid];
+	const int len = (int)seq_len[rid];
+	u128 *ring = ring_all + (size_t)rid * 256;
+	u128 *o = out ? out + out_off[rid] : nullptr;
+	const uint64_t mask = (1ULL << 2 * k) - 1, shift1 = 2 * (k - 1);
+	uint64_t fw = 0, rv = 0, n = 0;
+	const u128 none = {SK_NONE, SK_NONE};
+	u128 mn = none;
+	int run = 0, bp = 0, mp = 0;
+	for (int j = 0; j < w; ++j) ring[j] = none;
+	auto push = [&](u128 v) { if (o) o[n] = v; ++n; };
+	for (int i = 0; i < len; ++i) {
+		int c = s[i];
+		u128 info = none;
+		if (c < 4) {
+			fw = (fw << 2 | (uint64_t)c) & mask;
+			rv = (rv >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+			if (fw == rv) continue;                            // not a slot
+			int z = fw < rv ? 0 : 1;
+			++run;
+			if (run >= k) { info.x = hash64(z ? rv : fw, mask) << 8 | (uint64_t)k; info.y = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z; }
+		} else run = 0;
+		ring[bp] = info;
+		if (run == w + k - 1 && mn.x != SK_NONE) {            // rule A
+			for (int j = bp + 1; j < w; ++j) if (mn.x == ring[j].x && ring[j].y != mn.y) push(ring[j]);
+			for (int j = 0; j < bp; ++j) if (mn.x == ring[j].x && ring[j].y != mn.y) push(ring[j]);
+		}
+		if (info.x <= mn.x) {                                  // rule B
+			if (run >= w + k && mn.x != SK_NONE) push(mn);
+			mn = info, mp = bp;
+		} else if (bp == mp) {                                 // rule C
+			if (run >= w + k - 1 && mn.x != SK_NONE) push(mn);
+			mn.x = SK_NONE;
+			for (int j = bp + 1; j < w; ++j) if (mn.x >= ring[j].x) mn = ring[j], mp = j;
+			for (int j = 0; j <= bp; ++j) if (mn.x >= ring[j].x) mn = ring[j], mp = j;
+			if (run >= w + k - 1 && mn.x != SK_NONE) {
+				for (int j = bp + 1; j < w; ++j) if (mn.x == ring[j].x && mn.y != ring[j].y) push(ring[j]);
+				for (int j = 0; j <= bp; ++j) if (mn.x == ring[j].x && mn.y != ring[j].y) push(ring[j]);
+			}
+		}
+		if (++bp == w) bp = 0;
+	}
+	if (mn.x != SK_NONE) push(mn);                              // rule D
+	if (cnt) cnt[rid] = n;
+}
+
+__global__ void k_compact(const u128 *__restrict__ stage, uint32_t stage_cap, const uint32_t *__restrict__ tile_cnt,
+                          const uint64_t *__restrict__ tile_off, u128 *__restrict__ out)
+{
+	const uint32_t n = tile_cnt[blockIdx.x];
+	const u128 *src = stage + (size_t)blockIdx.x * stage_cap;
+	u128 *dst = out + tile_off[blockIdx.x];
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ void k_seq_off_from_tiles(const uint64_t *__restrict__ tile_off, const uint32_t *__restrict__ first_tile, int n_seq, uint64_t total, uint64_t *__restrict__ seq_off)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_seq) seq_off[i] = tile_off[first_tile[i]];
+	if (i == n_seq) seq_off[n_seq] = total;
+}
+
+template <class T> static void exclusive_scan_u64(const T *in, uint64_t *out, size_t n, hipStream_t st)
+{
+	size_t tmp_bytes = 0;
+	auto in_it = rocprim::make_transform_iterator(in, [] __device__ (T v) { return (uint64_t)v; });
+	PGA_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in_it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), st));
+	DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
+	PGA_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, in_it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), st));
+	PGA_HIP(hipStreamSynchronize(st));
+}
+
+void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st)
+{
+	const int n = S.n_seq;
+	M.n = 0;
+	M.h_seq_off.assign((size_t)n + 1, 0);
+	M.seq_off.alloc((size_t)n + 1);
+	if (n == 0) return;
+	const bool fast = (k & 1) && w + k <= 64 && w + k <= SK_HALO && w <= 63;
+	if (fast) {
+		std::vector<SkTile> tiles; std::vector<uint32_t> first_tile((size_t)n);
+		for (int i = 0; i < n; ++i) {
+			first_tile[i] = (uint32_t)tiles.size();
+			for (uint32_t s = 0; s < S.len[i]; s += SK_TILE) tiles.push_back(SkTile{(uint32_t)i, s});
+		}
+		// a sequence with no tiles (len 0) points at the next sequence's first tile; pad with a sentinel tile count
+		const size_t nt = tiles.size();
+		if (nt == 0) { M.seq_off.zero(st); return; }
+		DBuf<SkTile> d_tiles; d_tiles.upload(tiles, st);
+		DBuf<uint32_t> d_first; d_first.upload(first_tile, st);
+		DBuf<uint32_t> d_cnt(nt + 1); d_cnt.zero(st);
+		DBuf<uint64_t> d_toff(nt + 1);
+		DBuf<int> d_ovf(1); d_ovf.zero(st);
+		uint32_t cap = SK_TILE / 4;                           // expected density is 2/(w+1) per base
+		for (;;) {
+			DBuf<u128> stage(nt * (size_t)cap);
+			hipLaunchKernelGGL((k_sketch_tiles<63>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st,
+			                   S.d_nt4.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
+			PGA_HIP(hipGetLastError());
+			int ovf = d_ovf.download(st)[0];
+			if (ovf) { cap *= 4; d_ovf.zero(st); continue; }  // pathological repeats: retry with bigger slabs
+			exclusive_scan_u64(d_cnt.p, d_toff.p, nt + 1, st);
+			uint64_t total = 0;
+			PGA_HIP(hipMemcpyAsync(&total, d_toff.p + nt, 8, hipMemcpyDeviceToHost, st));
+			PGA_HIP(hipStreamSynchronize(st));
+			M.n = total;
+			M.mz.alloc(total ? total : 1);
+			hipLaunchKernelGGL(k_compact, dim3((unsigned)nt), dim3(256), 0, st, stage.p, cap, d_cnt.p, d_toff.p, M.mz.p);
+			// sequences of length 0 have no tile: give them the offset of the next tile (or the total)
+			std::vector<uint32_t> ft = first_tile;
+			for (int i = 0; i < n; ++i) if (S.len[i] == 0) ft[i] = (uint32_t)nt; // d_toff[nt] == total; fixed below for ordering
+			for (int i = n - 2; i >= 0; --i) if (S.len[i] == 0) ft[i] = ft[i + 1];
+			d_first.upload(ft, st);
+			hipLaunchKernelGGL(k_seq_off_from_tiles, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_toff.p, d_first.p, n, total, M.seq_off.p);
+			PGA_HIP(hipGetLastError());
+			PGA_HIP(hipStreamSynchronize(st));
+			break;
+		}
+	} else {
+		DBuf<uint64_t> d_cnt((size_t)n + 1); d_cnt.zero(st);
+		DBuf<u128> ring((size_t)n * 256);
+		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.d_nt4.p, S.d_off.p, S.d_len.p, n, w, k,
+		                   (u128*)nullptr, (const uint64_t*)nullptr, d_cnt.p, ring.p);
+		exclusive_scan_u64(d_cnt.p, M.seq_off.p, (size_t)n + 1, st);
+		uint64_t total = 0;
+		PGA_HIP(hipMemcpyAsync(&total, M.seq_off.p + n, 8, hipMemcpyDeviceToHost, st));
+		PGA_HIP(hipStreamSynchronize(st));
+		M.n = total;
+		M.mz.alloc(total ? total : 1);
+		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.d_nt4.p, S.d_off.p, S.d_len.p, n, w, k,
+		                   M.mz.p, M.seq_off.p, (uint64_t*)nullptr, ring.p);
+		PGA_HIP(hipGetLastError());
+		PGA_HIP(hipStreamSynchronize(st));
+	}
+	M.h_seq_off = M.seq_off.download(st);
+}
+
+} // namespace pga
