@@ -1,5 +1,5 @@
 import sys, time, gzip, re
-sys.path.insert(0, '.')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); os.chdir(ROOT); sys.path.insert(0, ROOT)
 from pangraph_amd.mm2ffi import *
 from pangraph_amd.synth import evolve_population
 def read_fa(path):

@@ -155,6 +155,9 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	double t3 = now_s();
 	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;
 	ix.have_results = true; ix.res_opt = opt;
+	if (getenv("PGA_VERBOSE"))
+		fprintf(stderr, "[pga] n_seq=%d bases=%llu mz=%.0f anchors=%.0f | upload %.3f sketch %.3f index %.3f seed %.3f chain %.3f align %.3f s | dp jobs %.0f cells %.3g\n",
+		        ix.S.n_seq, (unsigned long long)ix.S.total, ix.tm.n_mz, ix.tm.n_anchor, ix.tm.upload, ix.tm.sketch, ix.tm.index, ix.tm.seed, ix.tm.chain, ix.tm.align, ix.tm.dp_jobs, ix.tm.dp_cells);
 }
 
 // ---------------------------------------------------------------- minimap2-sys ABI

