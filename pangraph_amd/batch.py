@@ -1,0 +1,136 @@
+"""Python binding of the native batch entry (include/pga_align.h) -- host-side mirror of
+`align_with_minimap2_lib` (packages/pangraph/src/align/minimap2_lib/align_with_minimap2_lib.rs:15-85) for MANY
+block sets at once: one call aligns every group (one group == one `find_matches` call) of a guide-tree level.
+
+The HIP library is the only implementation: if libpgalign.so is missing or sees no device this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+from .mm2ffi import PafRow, MM_CIGAR_STR
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgalign.so")
+
+
+class pga_params_t(C.Structure):
+    _fields_ = [("sensitivity", C.c_int32), ("kmer_length", C.c_int32), ("indel_len_threshold", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class pga_match_t(C.Structure):
+    _fields_ = [("group", C.c_int32), ("qry", C.c_int32), ("ref", C.c_int32), ("qry_len", C.c_int32), ("qry_start", C.c_int32), ("qry_end", C.c_int32),
+                ("ref_len", C.c_int32), ("ref_start", C.c_int32), ("ref_end", C.c_int32), ("matches", C.c_int32), ("length", C.c_int32),
+                ("quality", C.c_int32), ("reverse", C.c_int32), ("align", C.c_int32), ("n_ambi", C.c_int32), ("inv", C.c_int32),
+                ("divergence", C.c_double), ("cigar_off", C.c_uint64), ("n_cigar", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class pga_stats_t(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("upload", "sketch", "index", "seed", "chain", "align", "total", "n_bases", "n_minimizers", "n_anchors",
+                                          "n_dp_jobs", "n_dp_cells", "n_matches")]
+
+
+class PgaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgaError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+        d = C.CDLL(LIB_PATH)
+        d.pga_align_groups.restype = C.c_int
+        d.pga_align_groups.argtypes = [C.POINTER(pga_params_t), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        d.pga_result_n_matches.restype = C.c_int64
+        d.pga_result_n_matches.argtypes = [C.c_void_p]
+        d.pga_result_matches.restype = C.POINTER(pga_match_t)
+        d.pga_result_matches.argtypes = [C.c_void_p]
+        d.pga_result_cigars.restype = C.POINTER(C.c_uint32)
+        d.pga_result_cigars.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        d.pga_result_stats.restype = C.POINTER(pga_stats_t)
+        d.pga_result_stats.argtypes = [C.c_void_p]
+        d.pga_result_free.argtypes = [C.c_void_p]
+        d.pga_last_error.restype = C.c_char_p
+        d.pga_device_count.restype = C.c_int
+        d.pga_set_device.restype = C.c_int
+        _lib = d
+    return _lib
+
+
+def device_count() -> int:
+    return lib().pga_device_count()
+
+
+def set_device(dev: int) -> None:
+    if lib().pga_set_device(dev) != 0:
+        raise PgaError(lib().pga_last_error().decode())
+
+
+class PreparedBatch:
+    """Flat C arrays of a list of groups, built once (so a benchmark can time only the library call)."""
+
+    def __init__(self, groups: Sequence[Sequence[str]], names: Optional[Sequence[Sequence[str]]] = None):
+        self.n_groups = len(groups)
+        flat, flat_names, off = [], [], [0]
+        for gi, g in enumerate(groups):
+            nm = names[gi] if names is not None else [str(i) for i in range(len(g))]
+            if len(nm) != len(g):
+                raise ValueError("Number of sequences and number of sequence names is expected to be the same")
+            for s, n in zip(g, nm):
+                flat.append(s if isinstance(s, bytes) else s.encode())
+                flat_names.append(n.encode())
+            off.append(len(flat))
+        n = len(flat)
+        self.names = [x.decode() for x in flat_names]
+        self._keep = (flat, flat_names)
+        self.seqs = (C.c_char_p * n)(*flat)
+        self.cnames = (C.c_char_p * n)(*flat_names)
+        self.lens = (C.c_uint32 * n)(*[len(b) for b in flat])
+        self.off = (C.c_int64 * (self.n_groups + 1))(*off)
+        self.total_bases = sum(len(b) for b in flat)
+
+
+@dataclass
+class BatchResult:
+    groups: List[List[PafRow]]
+    stats: dict
+
+
+def align_prepared(pb: PreparedBatch, sensitivity: int = 10, kmer_length: Optional[int] = None, indel_len_threshold: int = 100,
+                   n_threads: int = 0, want_rows: bool = True) -> BatchResult:
+    d = lib()
+    p = pga_params_t(sensitivity, kmer_length or 0, indel_len_threshold, n_threads)
+    out = C.c_void_p()
+    rc = d.pga_align_groups(C.byref(p), pb.n_groups, pb.off, pb.seqs, pb.lens, pb.cnames, C.byref(out))
+    if rc != 0:
+        raise PgaError(d.pga_last_error().decode())
+    try:
+        st = d.pga_result_stats(out).contents
+        stats = {n: getattr(st, n) for n, _ in pga_stats_t._fields_}
+        groups: List[List[PafRow]] = [[] for _ in range(pb.n_groups)]
+        if want_rows:
+            n = d.pga_result_n_matches(out)
+            m = d.pga_result_matches(out)
+            nops = C.c_uint64()
+            cg = d.pga_result_cigars(out, C.byref(nops))
+            for i in range(n):
+                r = m[i]
+                b = pb.off[r.group]
+                cigar = "".join(f"{cg[r.cigar_off + j] >> 4}{MM_CIGAR_STR[cg[r.cigar_off + j] & 0xf]}" for j in range(r.n_cigar))
+                groups[r.group].append(PafRow(qname=pb.names[b + r.qry], qlen=r.qry_len, qs=r.qry_start, qe=r.qry_end, strand="-" if r.reverse else "+",
+                                              tname=pb.names[b + r.ref], tlen=r.ref_len, rs=r.ref_start, re=r.ref_end, mlen=r.matches, blen=r.length,
+                                              mapq=r.quality, AS=r.align, de=r.divergence, cg=cigar, n_ambi=r.n_ambi, inv=r.inv))
+        return BatchResult(groups, stats)
+    finally:
+        d.pga_result_free(out)
+
+
+def align_groups(groups, names=None, **kw) -> BatchResult:
+    return align_prepared(PreparedBatch(groups, names), **kw)

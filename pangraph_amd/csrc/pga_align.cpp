@@ -531,7 +531,7 @@ struct RegTask {
 };
 
 struct QueryCtx {
-	int qid = 0; int32_t qlen = 0;
+	int qid = 0; int32_t qlen = 0; int base = 0;   // base: first sequence of the query's group (record rids are group-relative)
 	std::vector<u128> a; int32_t n_a = 0;
 	std::vector<RegTask*> list;      // the reference's regs[] order, grown by insertions
 	std::vector<std::unique_ptr<RegTask>> pool;
@@ -551,7 +551,7 @@ struct Driver {
 	int request(QueryCtx &Q, int rev, int rid, int32_t qs, int32_t qlen, int32_t ts, int32_t tlen, int seq_rev, int w, int end_bonus, int zdrop, int flag)
 	{
 		DpJob j; memset(&j, 0, sizeof(j));
-		j.t_off = S.off[rid] + (uint64_t)ts; j.q_off = S.off[Q.qid]; j.qlen_full = Q.qlen;
+		j.t_off = S.off[Q.base + rid] + (uint64_t)ts; j.q_off = S.off[Q.qid]; j.qlen_full = Q.qlen;
 		j.qs = qs; j.qlen = qlen; j.tlen = tlen; j.w = w; j.zdrop = zdrop; j.end_bonus = end_bonus; j.flag = flag;
 		j.q_rev = (uint8_t)rev; j.seq_rev = (uint8_t)seq_rev;
 		int id = (int)Q.jobs.size();
@@ -573,7 +573,7 @@ struct Driver {
 		T.planned = true;
 		if (r.cnt == 0) { T.done = true; return; }
 		T.rid = (int32_t)(a[r.as].x << 1 >> 33), T.rev = (int32_t)(a[r.as].x >> 63);
-		const int32_t tlen_ref = (int32_t)S.len[T.rid];
+		const int32_t tlen_ref = (int32_t)S.len[Q.base + T.rid];
 		int32_t bw = (int)(opt.bw * 1.5 + 1.), bw_long = (int)(opt.bw_long * 1.5 + 1.);
 		if (bw_long < bw) bw_long = bw;
 		T.bw = bw;
@@ -677,7 +677,7 @@ struct Driver {
 			T.re1 = sg.re, T.qe1 = sg.qe;
 			int final_job = sg.job1;
 			if (sg.zcode < 0) {
-				acc.query(Q.qid, T.rev, sg.qs, sg.qe, qw); acc.target(T.rid, sg.rs, sg.re, tw);
+				acc.query(Q.qid, T.rev, sg.qs, sg.qe, qw); acc.target(Q.base + T.rid, sg.rs, sg.re, tw);
 				const DpRes &e1 = Q.res[sg.job1];
 				sg.zcode = test_zdrop(opt, qw.data(), tw.data(), (uint32_t)e1.n_cigar, Q.cig[sg.job1].data(), mat);
 				if (sg.zcode != 0) sg.job2 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, sg.zcode == 2 ? opt.zdrop_inv : opt.zdrop, 0);
@@ -711,7 +711,7 @@ struct Driver {
 		r.rs = T.rs1, r.re = T.re1;
 		if (!T.rev) r.qs = T.qs1, r.qe = T.qe1; else r.qs = qlen - T.qe1, r.qe = qlen - T.qs1;
 		if (r.has_p) {
-			acc.target(T.rid, T.rs1, T.re1, tw); acc.query(Q.qid, (int)r.rev, T.qs1, T.qe1, qw);
+			acc.target(Q.base + T.rid, T.rs1, T.re1, tw); acc.query(Q.qid, (int)r.rev, T.qs1, T.qe1, qw);
 			update_extra(r, qw.data(), tw.data(), mat, opt.q, opt.e);
 		}
 		T.done = true;
@@ -733,7 +733,7 @@ struct Driver {
 			if (ql < opt.min_chain_score || ql > opt.max_gap) return 0;
 			if (tl < opt.min_chain_score || tl > opt.max_gap) return 0;
 			std::vector<uint8_t> tw, qw;
-			acc.target(r1.rid, r1.re, r2.rs, tw);
+			acc.target(Q.base + r1.rid, r1.re, r2.rs, tw);
 			// qseq = r1.rev ? &qseq0[0][r2.qe] : &qseq0[1][qlen - r2.qs]
 			const int q_strand = r1.rev ? 0 : 1; const int32_t q_st = r1.rev ? r2.qe : qlen - r2.qs;
 			acc.query(Q.qid, q_strand, q_st, q_st + ql, qw);
@@ -761,7 +761,7 @@ struct Driver {
 			r_inv.rs = r1.re + t_off; r_inv.re = r_inv.rs + ez.max_t + 1;
 			std::vector<uint8_t> tw, qw;
 			const int q_strand = r1.rev ? 0 : 1; const int32_t q_st = r1.rev ? r2.qe : qlen - r2.qs;
-			acc.target(r1.rid, r1.re + t_off, r2.rs, tw);
+			acc.target(Q.base + r1.rid, r1.re + t_off, r2.rs, tw);
 			acc.query(Q.qid, q_strand, q_st + q_off, q_st + T.inv_ql, qw);
 			update_extra(r_inv, qw.data(), tw.data(), mat, opt.q, opt.e);
 			return 2;
@@ -846,7 +846,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	// ---- regions (mm_gen_regs) and plans ----
 	parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
 		QueryCtx &q = Q[qi];
-		q.qid = (int)qi, q.qlen = (int32_t)S.len[qi], q.rep_len = rep_len[qi];
+		q.qid = (int)qi, q.qlen = (int32_t)S.len[qi], q.rep_len = rep_len[qi]; q.base = (int)S.grp_off[S.grp_of_seq[qi]];
 		const int n_u = C.n_u[qi];
 		if (q.qlen == 0 || n_u == 0) { q.finished = true; return; }
 		const uint64_t b = q_aoff[qi];

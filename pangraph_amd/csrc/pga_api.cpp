@@ -75,7 +75,9 @@ extern "C" int mm_check_opt(const mm_idxopt_t *io, const mm_mapopt_t *mo) // opt
 // ---------------------------------------------------------------- the index handle
 struct PgaIdx {
 	mm_idx_t hdr;                    // must stay first: the Rust side reads n_seq, seq[i].name, seq[i].len
-	SeqSet S; Minimizers M; Index I; DBuf<uint32_t> grp; DBuf<int32_t> d_name_rank;
+	SeqSet S; Minimizers M; Index I; DBuf<uint32_t> grp; DBuf<int32_t> d_name_rank, d_mid_occ;
+	std::vector<int32_t> mid_occ_raw;   // mm_idx_cal_max_occ per group (cached per fraction)
+	float mid_occ_frac = -1.0f;
 	std::vector<mm_idx_seq_t> seq_hdr; std::vector<std::string> names;
 	std::map<std::string, int> by_name;
 	std::mutex mtx;
@@ -105,28 +107,35 @@ static void check_supported(const mm_mapopt_t &o, int k, int w)
 	if (o.sdust_thres > 0) throw std::runtime_error("pga: SDUST masking is not implemented");
 }
 
-static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name)
+static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp = 1, const int64_t *grp_off = nullptr)
 {
 	require_device();
 	std::unique_ptr<PgaIdx> ix(new PgaIdx());
 	memset(&ix->hdr, 0, sizeof(ix->hdr));
 	if (w < 1) w = 1;
 	double t0 = now_s();
-	upload_seqs(ix->S, n, seq, len, name, ix->st);
+	const int64_t one_grp[2] = {0, n};
+	if (!grp_off) grp_off = one_grp, n_grp = 1;
+	upload_seqs(ix->S, n, seq, len, name, n_grp, grp_off, ix->st);
 	ix->names = ix->S.name;
 	ix->seq_hdr.resize((size_t)n);
 	for (int i = 0; i < n; ++i) {
 		ix->seq_hdr[i].name = name && name[i] ? const_cast<char*>(ix->names[i].c_str()) : nullptr;
 		ix->seq_hdr[i].offset = ix->S.off[i]; ix->seq_hdr[i].len = len[i]; ix->seq_hdr[i].is_alt = 0;
-		if (name && name[i]) {
-			if (ix->by_name.count(ix->names[i])) throw std::runtime_error("pga: duplicate sequence name '" + ix->names[i] + "' (index.c:436 asserts uniqueness)");
-			ix->by_name[ix->names[i]] = i;
+		if (name && name[i] && n_grp == 1) ix->by_name[ix->names[i]] = i;
+	}
+	// rank of every name under strcmp order inside its group (skip_seed compares names as C strings, map.c:84,89)
+	std::vector<int32_t> rank((size_t)n);
+	for (int g = 0; g < n_grp; ++g) {
+		const int b = (int)grp_off[g], m = (int)(grp_off[g + 1] - grp_off[g]);
+		std::vector<int> ord((size_t)m); for (int i = 0; i < m; ++i) ord[i] = b + i;
+		std::sort(ord.begin(), ord.end(), [&](int a, int c) { return strcmp(ix->names[a].c_str(), ix->names[c].c_str()) < 0; });
+		for (int i = 0; i < m; ++i) {
+			if (i > 0 && ix->names[ord[i]] == ix->names[ord[i - 1]] && name)
+				throw std::runtime_error("pga: duplicate sequence name '" + ix->names[ord[i]] + "' inside a group (index.c:436 asserts uniqueness)");
+			rank[ord[i]] = i;
 		}
 	}
-	// rank of every name under strcmp order (skip_seed compares names as C strings, map.c:84,89)
-	std::vector<int> ord((size_t)n); for (int i = 0; i < n; ++i) ord[i] = i;
-	std::sort(ord.begin(), ord.end(), [&](int a, int b) { return strcmp(ix->names[a].c_str(), ix->names[b].c_str()) < 0; });
-	std::vector<int32_t> rank((size_t)n); for (int i = 0; i < n; ++i) rank[ord[i]] = i;
 	ix->d_name_rank.upload(rank, ix->st);
 	ix->hdr.b = 14 < 2 * k ? 14 : 2 * k, ix->hdr.w = w, ix->hdr.k = k, ix->hdr.flag = name ? 0 : MM_I_NO_NAME;
 	ix->hdr.n_seq = (uint32_t)n; ix->hdr.seq = ix->seq_hdr.data();
@@ -134,18 +143,34 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	double t1 = now_s();
 	sketch_all(ix->S, w, k, ix->M, ix->st);
 	double t2 = now_s();
-	build_index_ex(ix->M, w, k, ix->I, ix->grp, ix->st);
+	build_index_ex(ix->S, ix->M, w, k, ix->I, ix->grp, ix->st);
 	double t3 = now_s();
 	ix->tm.upload = t1 - t0, ix->tm.sketch = t2 - t1, ix->tm.index = t3 - t2; ix->tm.n_mz = (double)ix->M.n;
 	return ix.release();
+}
+
+// mm_mapopt_update (options.c:66-80) for every group of the batch
+static std::vector<int32_t> group_mid_occ(PgaIdx &ix, const mm_mapopt_t &opt)
+{
+	std::vector<int32_t> v((size_t)ix.S.n_grp, opt.mid_occ);
+	if (opt.mid_occ > 0) return v;
+	if (ix.mid_occ_frac != opt.mid_occ_frac) { ix.mid_occ_raw = index_cal_max_occ(ix.S, ix.I, opt.mid_occ_frac, ix.st); ix.mid_occ_frac = opt.mid_occ_frac; }
+	for (int g = 0; g < ix.S.n_grp; ++g) {
+		int32_t m = ix.mid_occ_raw[g];
+		if (m < opt.min_mid_occ) m = opt.min_mid_occ;
+		if (opt.max_mid_occ > opt.min_mid_occ && m > opt.max_mid_occ) m = opt.max_mid_occ;
+		v[g] = m;
+	}
+	return v;
 }
 
 static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 {
 	check_supported(opt, ix.I.k, ix.I.w);
 	double t0 = now_s();
+	ix.d_mid_occ.upload(group_mid_occ(ix, opt), ix.st);
 	SeedResult SR;
-	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, SR, ix.st);
+	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st);
 	double t1 = now_s();
 	ChainResult CR;
 	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st);
@@ -178,10 +203,8 @@ extern "C" void mm_mapopt_update(mm_mapopt_t *opt, const mm_idx_t *mi) // option
 {
 	PgaIdx *ix = reinterpret_cast<PgaIdx*>(const_cast<mm_idx_t*>(mi));
 	if (opt->mid_occ <= 0) {
-		try { opt->mid_occ = index_cal_max_occ(ix->I, opt->mid_occ_frac, ix->st); }
+		try { opt->mid_occ = group_mid_occ(*ix, *opt)[0]; }
 		catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_mapopt_update: %s\n", e.what()); return; }
-		if (opt->mid_occ < opt->min_mid_occ) opt->mid_occ = opt->min_mid_occ;
-		if (opt->max_mid_occ > opt->min_mid_occ && opt->mid_occ > opt->max_mid_occ) opt->mid_occ = opt->max_mid_occ;
 	}
 	if (opt->bw_long < opt->bw) opt->bw_long = opt->bw;
 }
@@ -281,30 +304,44 @@ extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, co
 		std::unique_ptr<pga_result_s> R(new pga_result_s());
 		memset(&R->st, 0, sizeof(R->st));
 		double t_all = now_s();
-		for (int g = 0; g < n_groups; ++g) {
-			const int64_t b = group_off[g], n = group_off[g + 1] - b;
-			if (n <= 0) continue;
-			std::unique_ptr<PgaIdx> ix(idx_build(io.w, io.k, (int)n, seqs + b, seq_lens + b, names + b));
-			mm_mapopt_t mo = mo0;
-			mm_mapopt_update(&mo, &ix->hdr);
-			run_batch(*ix, mo, params->n_threads);
-			for (int q = 0; q < (int)n; ++q) for (const Reg &r : ix->results[q]) {
-				if (!r.has_p) throw std::runtime_error("Unable to find CIGAR string in the result"); // align_with_minimap2_lib.rs:118
-				pga_match_t m; memset(&m, 0, sizeof(m));
-				m.group = g, m.qry = q, m.ref = r.rid, m.qry_len = (int32_t)ix->S.len[q], m.qry_start = r.qs, m.qry_end = r.qe;
-				m.ref_len = (int32_t)ix->S.len[r.rid], m.ref_start = r.rs, m.ref_end = r.re;
-				m.matches = r.mlen, m.length = r.blen, m.quality = (int32_t)r.mapq, m.reverse = (int32_t)r.rev, m.align = r.dp_score;
-				m.n_ambi = (int32_t)r.n_ambi, m.inv = (int32_t)r.inv;
-				int32_t n_gapo = 0, n_gap = 0;
-				for (uint32_t c : r.cigar) { int32_t op = c & 0xf, len = (int32_t)(c >> 4); if (op == 1 || op == 2) ++n_gapo, n_gap += len; }
-				m.divergence = 1.0 - (double)r.mlen / (r.blen + (int32_t)r.n_ambi - n_gap + n_gapo);
-				m.cigar_off = R->cig.size(), m.n_cigar = (uint32_t)r.cigar.size();
-				R->cig.insert(R->cig.end(), r.cigar.begin(), r.cigar.end());
-				R->m.push_back(m);
+		// groups are packed into sub-batches of at most max_bases bases (32-bit minimizer / anchor indices per batch)
+		const uint64_t max_bases = getenv("PGA_MAX_BATCH_BASES") ? strtoull(getenv("PGA_MAX_BATCH_BASES"), 0, 10) : 3000000000ULL;
+		int g0 = 0;
+		while (g0 < n_groups) {
+			int g1 = g0; uint64_t bases = 0;
+			while (g1 < n_groups) {
+				uint64_t gb = 0; for (int64_t i = group_off[g1]; i < group_off[g1 + 1]; ++i) gb += seq_lens[i];
+				if (g1 > g0 && bases + gb > max_bases) break;
+				bases += gb; ++g1;
 			}
-			const Timers &t = ix->tm;
-			R->st.upload += t.upload, R->st.sketch += t.sketch, R->st.index += t.index, R->st.seed += t.seed, R->st.chain += t.chain, R->st.align += t.align;
-			R->st.n_bases += (double)ix->S.total, R->st.n_minimizers += t.n_mz, R->st.n_anchors += t.n_anchor, R->st.n_dp_jobs += t.dp_jobs, R->st.n_dp_cells += t.dp_cells;
+			const int64_t b = group_off[g0], n = group_off[g1] - b;
+			std::vector<int64_t> goff((size_t)(g1 - g0) + 1);
+			for (int g = g0; g <= g1; ++g) goff[g - g0] = group_off[g] - b;
+			if (n > 0) {
+				std::unique_ptr<PgaIdx> ix(idx_build(io.w, io.k, (int)n, seqs + b, seq_lens + b, names + b, g1 - g0, goff.data()));
+				mm_mapopt_t mo = mo0;
+				if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
+				run_batch(*ix, mo, params->n_threads);
+				for (int q = 0; q < (int)n; ++q) for (const Reg &r : ix->results[q]) {
+					if (!r.has_p) throw std::runtime_error("Unable to find CIGAR string in the result"); // align_with_minimap2_lib.rs:118
+					const int g = (int)ix->S.grp_of_seq[q], gb = (int)goff[g];
+					pga_match_t m; memset(&m, 0, sizeof(m));
+					m.group = g0 + g, m.qry = q - gb, m.ref = r.rid, m.qry_len = (int32_t)ix->S.len[q], m.qry_start = r.qs, m.qry_end = r.qe;
+					m.ref_len = (int32_t)ix->S.len[gb + r.rid], m.ref_start = r.rs, m.ref_end = r.re;
+					m.matches = r.mlen, m.length = r.blen, m.quality = (int32_t)r.mapq, m.reverse = (int32_t)r.rev, m.align = r.dp_score;
+					m.n_ambi = (int32_t)r.n_ambi, m.inv = (int32_t)r.inv;
+					int32_t n_gapo = 0, n_gap = 0;
+					for (uint32_t c : r.cigar) { int32_t op = c & 0xf, len = (int32_t)(c >> 4); if (op == 1 || op == 2) ++n_gapo, n_gap += len; }
+					m.divergence = 1.0 - (double)r.mlen / (r.blen + (int32_t)r.n_ambi - n_gap + n_gapo);
+					m.cigar_off = R->cig.size(), m.n_cigar = (uint32_t)r.cigar.size();
+					R->cig.insert(R->cig.end(), r.cigar.begin(), r.cigar.end());
+					R->m.push_back(m);
+				}
+				const Timers &t = ix->tm;
+				R->st.upload += t.upload, R->st.sketch += t.sketch, R->st.index += t.index, R->st.seed += t.seed, R->st.chain += t.chain, R->st.align += t.align;
+				R->st.n_bases += (double)ix->S.total, R->st.n_minimizers += t.n_mz, R->st.n_anchors += t.n_anchor, R->st.n_dp_jobs += t.dp_jobs, R->st.n_dp_cells += t.dp_cells;
+			}
+			g0 = g1;
 		}
 		R->st.total = now_s() - t_all; R->st.n_matches = (double)R->m.size();
 		*out = R.release();
@@ -329,7 +366,8 @@ extern "C" int pga_stage_sketch(int32_t n, const char *const *seqs, const uint32
 	try {
 		require_device();
 		SeqSet S; Minimizers M;
-		upload_seqs(S, n, seqs, lens, nullptr, 0);
+		const int64_t one_grp[2] = {0, n};
+		upload_seqs(S, n, seqs, lens, nullptr, 1, one_grp, 0);
 		sketch_all(S, w, k, M, 0);
 		std::vector<u128> h = M.mz.download(0); h.resize(M.n);
 		std::vector<uint64_t> flat(h.size() * 2);
@@ -349,7 +387,8 @@ extern "C" int pga_stage_chain(const pga_params_t *params, int32_t n, const char
 		mm_mapopt_update(&mo, &ix->hdr);
 		*mid_occ = mo.mid_occ;
 		check_supported(mo, io.k, io.w);
-		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, SR, 0);
+		ix->d_mid_occ.upload(group_mid_occ(*ix, mo), 0);
+		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, ix->d_mid_occ, SR, 0);
 		std::vector<u128> a = SR.a.download(0); a.resize(SR.n_a);
 		std::vector<uint64_t> flat(a.size() * 2);
 		for (size_t i = 0; i < a.size(); ++i) flat[2 * i] = a[i].x, flat[2 * i + 1] = a[i].y;

@@ -57,6 +57,11 @@ struct SeqSet {
 	DBuf<uint8_t> d_nt4;                // 1 byte per base: 0..3 ACGT, 4 other (sketch.c:9-26 table)
 	DBuf<uint64_t> d_off;
 	DBuf<uint32_t> d_len;
+	// groups: independent all-vs-all problems sharing the batch (one group == one find_matches call)
+	int n_grp = 1;
+	std::vector<int64_t> grp_off;       // n_grp+1 offsets into the sequence arrays
+	std::vector<uint32_t> grp_of_seq;   // n_seq
+	DBuf<uint32_t> d_grp_of_seq, d_grp_base;   // per sequence: its group, and the first sequence of that group
 };
 
 // ---- minimizers of a SeqSet (sorted by sequence, then by position == mm_sketch output order) ----
@@ -74,14 +79,14 @@ struct Index {
 	DBuf<uint64_t> key;
 	DBuf<uint32_t> occ_off;             // n_keys+1
 	DBuf<uint64_t> occ;
-	int32_t mid_occ_raw = 0;            // mm_idx_cal_max_occ(2e-4) before clamping
+	DBuf<uint32_t> key_grp;             // group of every key (keys are sorted by (group, hash))
 };
 
 struct Timers { double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0; };
 
 // stage entry points (each in its own .hip/.cpp)
-void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, hipStream_t st);
+void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st);
 void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st);
-int32_t index_cal_max_occ(const Index &I, float f, hipStream_t st);
+std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f, hipStream_t st);
 
 } // namespace pga

@@ -50,31 +50,75 @@ __global__ void k_counts(const uint32_t *__restrict__ occ_off, uint64_t n_keys, 
 	if (i < n_keys) cnt[i] = occ_off[i + 1] - occ_off[i];
 }
 
-void build_index_ex(const Minimizers &M, int w, int k, Index &I, DBuf<uint32_t> &grp_of_mz, hipStream_t st)
+__global__ void k_group_keys(const uint64_t *__restrict__ vy, const uint32_t *__restrict__ orig, const uint32_t *__restrict__ grp_of_seq, uint64_t n,
+                             uint32_t *__restrict__ gk, uint32_t *__restrict__ idx)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { gk[i] = grp_of_seq[vy[orig[i]] >> 32]; idx[i] = (uint32_t)i; }
+}
+__global__ void k_apply_perm(const uint64_t *__restrict__ kx, const uint32_t *__restrict__ orig, const uint32_t *__restrict__ perm, uint64_t n,
+                             uint64_t *__restrict__ kx_out, uint32_t *__restrict__ orig_out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { uint32_t p = perm[i]; kx_out[i] = kx[p]; orig_out[i] = orig[p]; }
+}
+__global__ void k_head_flags_g(const uint64_t *__restrict__ kx, const uint32_t *__restrict__ gk, uint64_t n, uint32_t *__restrict__ flag)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flag[i] = (i == 0 || (kx[i] >> 8) != (kx[i - 1] >> 8) || (gk && gk[i] != gk[i - 1])) ? 1u : 0u;
+}
+__global__ void k_groups_g(const uint64_t *__restrict__ kx, const uint32_t *__restrict__ gk, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ gid_incl,
+                           const uint32_t *__restrict__ orig, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ occ_off, uint32_t *__restrict__ key_grp,
+                           uint32_t *__restrict__ grp_of_mz)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t g = gid_incl[i] - 1;
+	if (flag[i]) { key[g] = kx[i] >> 8; occ_off[g] = (uint32_t)i; key_grp[g] = gk ? gk[i] : 0u; }
+	grp_of_mz[orig[i]] = g;
+}
+
+// Sort minimizers by (group, x) keeping y ascending inside a key: a stable sort on x, then -- when the batch
+// holds several groups -- a stable sort on the group id (LSD order).
+void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I, DBuf<uint32_t> &grp_of_mz, hipStream_t st)
 {
 	I.w = w, I.k = k; I.n_occ = M.n; I.n_keys = 0;
 	const uint64_t n = M.n;
 	grp_of_mz.alloc(n ? n : 1);
 	I.occ.alloc(n ? n : 1);
-	if (n == 0) { I.key.alloc(1); I.occ_off.alloc(1); I.occ_off.zero(st); return; }
+	if (n == 0) { I.key.alloc(1); I.occ_off.alloc(1); I.occ_off.zero(st); I.key_grp.alloc(1); return; }
 	if (n >= (1ULL << 32)) throw std::runtime_error("pga: more than 2^32 minimizers in one batch");
 	const unsigned nb = (unsigned)((n + 255) / 256);
 	DBuf<uint64_t> kx(n), kx2(n), vy(n);
-	DBuf<uint32_t> orig(n), orig2(n);
+	DBuf<uint32_t> orig(n), orig2(n), gk;
 	hipLaunchKernelGGL(k_split, dim3(nb), dim3(256), 0, st, M.mz.p, n, kx.p, vy.p);
 	hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, st, orig.p, n);
-	// stable LSD radix sort on the 64-bit minimizer word; the permutation is carried as the value
-	size_t tmp_bytes = 0;
-	PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, 0, 64, st));
-	DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
-	PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, 0, 64, st));
-	// occ[i] = y of the i-th sorted minimizer
 	{
-		auto gather = rocprim::make_transform_iterator(orig2.p, [vyp = vy.p] __device__ (uint32_t o) { return vyp[o]; });
+		size_t tmp_bytes = 0;
+		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, 0, 64, st));
+		DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
+		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, 0, 64, st));
+	}
+	uint64_t *kxs = kx2.p; uint32_t *origs = orig2.p; const uint32_t *gks = nullptr;
+	if (S.n_grp > 1) {
+		DBuf<uint32_t> gk0(n), idx0(n), idx1(n);
+		gk.alloc(n);
+		hipLaunchKernelGGL(k_group_keys, dim3(nb), dim3(256), 0, st, vy.p, orig2.p, S.d_grp_of_seq.p, n, gk0.p, idx0.p);
+		int bits = 1; while ((1LL << bits) < S.n_grp) ++bits;
+		size_t tmp_bytes = 0;
+		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, gk0.p, gk.p, idx0.p, idx1.p, n, 0, bits, st));
+		DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
+		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, gk0.p, gk.p, idx0.p, idx1.p, n, 0, bits, st));
+		hipLaunchKernelGGL(k_apply_perm, dim3(nb), dim3(256), 0, st, kx2.p, orig2.p, idx1.p, n, kx.p, orig.p);
+		kxs = kx.p, origs = orig.p, gks = gk.p;
+		PGA_HIP(hipStreamSynchronize(st));
+	}
+	{   // occ[i] = y of the i-th sorted minimizer
+		auto gather = rocprim::make_transform_iterator(origs, [vyp = vy.p] __device__ (uint32_t o) { return vyp[o]; });
 		PGA_HIP(rocprim::transform(gather, I.occ.p, n, rocprim::identity<uint64_t>(), st));
 	}
 	DBuf<uint32_t> flag(n), gid(n);
-	hipLaunchKernelGGL(k_head_flags, dim3(nb), dim3(256), 0, st, kx2.p, n, flag.p);
+	hipLaunchKernelGGL(k_head_flags_g, dim3(nb), dim3(256), 0, st, kxs, gks, n, flag.p);
 	size_t tmp2 = 0;
 	PGA_HIP(rocprim::inclusive_scan(nullptr, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
 	DBuf<uint8_t> tmpb(tmp2 ? tmp2 : 1);
@@ -85,30 +129,51 @@ void build_index_ex(const Minimizers &M, int w, int k, Index &I, DBuf<uint32_t> 
 	I.n_keys = n_keys;
 	I.key.alloc(n_keys);
 	I.occ_off.alloc((size_t)n_keys + 1);
-	hipLaunchKernelGGL(k_groups, dim3(nb), dim3(256), 0, st, kx2.p, flag.p, gid.p, orig2.p, n, I.key.p, I.occ_off.p, grp_of_mz.p);
+	I.key_grp.alloc(n_keys);
+	hipLaunchKernelGGL(k_groups_g, dim3(nb), dim3(256), 0, st, kxs, gks, flag.p, gid.p, origs, n, I.key.p, I.occ_off.p, I.key_grp.p, grp_of_mz.p);
 	uint32_t n32 = (uint32_t)n;
 	PGA_HIP(hipMemcpyAsync(I.occ_off.p + n_keys, &n32, 4, hipMemcpyHostToDevice, st));
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipStreamSynchronize(st));
 }
 
-// mm_idx_cal_max_occ (index.c:186-207): the (uint32)((1-f)*n)-th smallest occurrence count, plus one.
-int32_t index_cal_max_occ(const Index &I, float f, hipStream_t st)
+__global__ void k_grp_cnt_keys(const uint32_t *__restrict__ occ_off, const uint32_t *__restrict__ key_grp, uint64_t n_keys, uint64_t *__restrict__ comp)
 {
-	if (f <= 0.) return INT32_MAX;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_keys) comp[i] = (uint64_t)key_grp[i] << 32 | (uint64_t)(occ_off[i + 1] - occ_off[i]);
+}
+__global__ void k_grp_quantile(const uint64_t *__restrict__ comp, uint64_t n_keys, int n_grp, float f, int32_t *__restrict__ out)
+{
+	int g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_grp) return;
+	uint64_t lo = 0, hi = n_keys, a, b;
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (comp[m] < ((uint64_t)g << 32)) lo = m + 1; else hi = m; }
+	a = lo; hi = n_keys;
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (comp[m] < ((uint64_t)(g + 1) << 32)) lo = m + 1; else hi = m; }
+	b = lo;
+	const uint64_t n = b - a;
+	if (n == 0) { out[g] = 1; return; }
+	const uint64_t kk = (uint32_t)((1. - (double)f) * (double)n);      // index.c:204: double arithmetic on the float fraction
+	out[g] = (int32_t)((uint32_t)comp[a + kk] + 1u);
+}
+
+// mm_idx_cal_max_occ (index.c:186-207) of every group: the (uint32)((1-f)*n)-th smallest occurrence count, plus one.
+std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f, hipStream_t st)
+{
+	std::vector<int32_t> out((size_t)S.n_grp, INT32_MAX);
+	if (f <= 0.) return out;
 	const uint64_t n = I.n_keys;
-	if (n == 0) return 1;
-	DBuf<uint32_t> cnt(n), cnt2(n);
-	hipLaunchKernelGGL(k_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, I.occ_off.p, n, cnt.p);
+	if (n == 0) { std::fill(out.begin(), out.end(), 1); return out; }
+	DBuf<uint64_t> comp(n), comp2(n);
+	hipLaunchKernelGGL(k_grp_cnt_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, I.occ_off.p, I.key_grp.p, n, comp.p);
 	size_t tmp_bytes = 0;
-	PGA_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, cnt.p, cnt2.p, n, 0, 32, st));
+	PGA_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, comp.p, comp2.p, n, 0, 64, st));
 	DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
-	PGA_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, cnt.p, cnt2.p, n, 0, 32, st));
-	size_t kk = (uint32_t)((1. - f) * n);
-	uint32_t v = 0;
-	PGA_HIP(hipMemcpyAsync(&v, cnt2.p + kk, 4, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
-	return (int32_t)(v + 1);
+	PGA_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, comp.p, comp2.p, n, 0, 64, st));
+	DBuf<int32_t> d_out((size_t)S.n_grp);
+	hipLaunchKernelGGL(k_grp_quantile, dim3((unsigned)((S.n_grp + 255) / 256)), dim3(256), 0, st, comp2.p, n, S.n_grp, f, d_out.p);
+	PGA_HIP(hipGetLastError());
+	return d_out.download(st);
 }
 
 } // namespace pga

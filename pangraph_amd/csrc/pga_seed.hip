@@ -22,8 +22,11 @@ namespace pga {
 
 struct SeedParams {
 	int64_t flag;
-	int32_t mid_occ, max_max_occ, occ_dist;
+	const int32_t *mid_occ_of_grp;      // mm_mapopt_t::mid_occ is per index, i.e. per group
+	const uint32_t *grp_of_seq, *grp_base;
+	int32_t max_max_occ, occ_dist;
 	float q_occ_frac;
+	__device__ __forceinline__ int32_t mid_occ(uint32_t qid) const { return mid_occ_of_grp[grp_of_seq[qid]]; }
 };
 
 __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t n, uint64_t v)
@@ -42,12 +45,13 @@ __global__ void k_mz_keep(const u128 *__restrict__ mz, uint64_t n, const uint64_
 	uint32_t kp = 1;
 	const uint32_t qid = (uint32_t)(mz[i].y >> 32);
 	const uint64_t n_mv = seq_off[qid + 1] - seq_off[qid];
-	if (n_mv > (uint64_t)P.mid_occ && P.q_occ_frac > 0.0f && P.mid_occ > 0) {
+	const int32_t mid_occ = P.mid_occ(qid);
+	if (n_mv > (uint64_t)mid_occ && P.q_occ_frac > 0.0f && mid_occ > 0) {
 		const uint32_t g = grp[i], o0 = occ_off[g], cn = occ_off[g + 1] - o0;
-		if (cn > (uint32_t)P.mid_occ) {
+		if (cn > (uint32_t)mid_occ) {
 			const uint64_t *cr = occ + o0;
 			int32_t cnt = (int32_t)(lower_bound_u64(cr, cn, (uint64_t)(qid + 1) << 32) - lower_bound_u64(cr, cn, (uint64_t)qid << 32));
-			if (cnt > P.mid_occ && (float)cnt > (float)n_mv * P.q_occ_frac) kp = 0; // seed.c:17 compares in float
+			if (cnt > mid_occ && (float)cnt > (float)n_mv * P.q_occ_frac) kp = 0; // seed.c:17 compares in float
 		}
 	}
 	keep[i] = kp;
@@ -75,7 +79,7 @@ __global__ void k_seed_make(const u128 *__restrict__ mz, const uint32_t *__restr
 	if (j > lo) { uint32_t ip = kept_idx ? kept_idx[j - 1] : (uint32_t)(j - 1); if (mz[ip].x >> 8 == m.x >> 8) fl = 1; }
 	if (j + 1 < hi) { uint32_t in = kept_idx ? kept_idx[j + 1] : (uint32_t)(j + 1); if (mz[in].x >> 8 == m.x >> 8) fl = 1; }
 	sd_n[j] = cn, sd_occ[j] = o0, sd_qpos[j] = (uint32_t)m.y, sd_flag[j] = fl;   // bit0 = tandem, bit1 = filtered
-	if (cn > (uint32_t)P.mid_occ) atomicOr(&q_has_high[qid], 1u);
+	if (cn > (uint32_t)P.mid_occ(qid)) atomicOr(&q_has_high[qid], 1u);
 }
 
 // seed.c:56-96 + the rep_len accounting of seed.c:107-128; one lane per query that has high-occurrence seeds
@@ -91,8 +95,8 @@ __global__ void k_seed_select(int n_seq, const uint64_t *__restrict__ seq_off2, 
 	const int32_t n = (int32_t)(seq_off2[q + 1] - seq_off2[q]);
 	const uint32_t *a_n = sd_n + base, *a_qp = sd_qpos + base;
 	uint8_t *a_fl = sd_flag + base;
-	const uint32_t max_occ = (uint32_t)P.mid_occ;
-	if (P.occ_dist > 0 && P.max_max_occ > P.mid_occ) {
+	const uint32_t max_occ = (uint32_t)P.mid_occ((uint32_t)q);
+	if (P.occ_dist > 0 && P.max_max_occ > (int32_t)max_occ) {
 		if (n > 1) {
 			uint64_t heap[128];
 			int32_t last0 = -1;
@@ -141,7 +145,7 @@ __global__ void k_seed_select(int n_seq, const uint64_t *__restrict__ seq_off2, 
 	rep_len[q] = rl;
 }
 
-struct SkipCtx { int64_t flag; const int32_t *name_rank; const uint32_t *seq_len; };
+struct SkipCtx { int64_t flag; const int32_t *name_rank; const uint32_t *seq_len; const uint32_t *grp_base; };
 
 __device__ __forceinline__ bool skip_seed(const SkipCtx &C, uint64_t r, uint32_t q_pos, uint32_t qid, uint32_t qlen, bool *is_self) // map.c:78-100
 {
@@ -178,12 +182,13 @@ __global__ void k_anchors(const u128 *__restrict__ mz, const uint32_t *__restric
 		const uint64_t *cr = occ + sd_occ[j];
 		u128 *out = WRITE ? a + a_off[j] : nullptr;
 		for (uint32_t t = 0; t < n; ++t) {
-			const uint64_t r = cr[t];
+			uint64_t r = cr[t];
 			bool is_self;
 			if (skip_seed(C, r, q_pos, qid, qlen, &is_self)) continue;
 			if (WRITE) {
 				u128 p;
 				const uint64_t rpos = (uint32_t)r >> 1;
+				r -= (uint64_t)C.grp_base[qid] << 32;                     // target id relative to the group, as in a per-group index
 				if ((r & 1) == (q_pos & 1)) {
 					p.x = (r & 0xffffffff00000000ULL) | rpos;
 					p.y = (uint64_t)k_span << 32 | (q_pos >> 1);
@@ -251,14 +256,14 @@ template <class T> static void excl_scan(const T *in, uint64_t *out, size_t n, h
 }
 
 void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<uint32_t> &grp_of_mz, const mm_mapopt_t &opt,
-              const DBuf<int32_t> &d_name_rank, SeedResult &O, hipStream_t st)
+              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st)
 {
 	const int n_seq = S.n_seq;
 	const uint64_t n = M.n;
 	O.n_a = 0; O.h_q_aoff.assign((size_t)n_seq + 1, 0); O.h_rep_len.assign((size_t)n_seq, 0);
 	O.q_aoff.alloc((size_t)n_seq + 1); O.q_aoff.zero(st);
 	if (n == 0) { O.a.alloc(1); return; }
-	SeedParams P{opt.flag, opt.mid_occ, opt.max_max_occ, opt.occ_dist, opt.q_occ_frac};
+	SeedParams P{opt.flag, d_mid_occ.p, S.d_grp_of_seq.p, S.d_grp_base.p, opt.max_max_occ, opt.occ_dist, opt.q_occ_frac};
 	const unsigned nb = (unsigned)((n + 255) / 256), nbq = (unsigned)((n_seq + 1 + 255) / 256);
 
 	// 1. query-side filter + order-preserving compaction
@@ -309,7 +314,7 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	                   sd_n.p, sd_qpos.p, sd_flag.p, P, (int32_t)I.k, rep_len.p);
 
 	// 3. anchors: count, scan, write
-	SkipCtx C{opt.flag, d_name_rank.p, S.d_len.p};
+	SkipCtx C{opt.flag, d_name_rank.p, S.d_len.p, S.d_grp_base.p};
 	DBuf<uint32_t> cnt(n_kept + 1); cnt.zero(st);
 	DBuf<uint64_t> a_off(n_kept + 1);
 	hipLaunchKernelGGL((k_anchors<false>), dim3(nbk), dim3(256), 0, st, M.mz.p, kept_p, n_kept, sd_n.p, sd_occ.p, sd_qpos.p, sd_flag.p, I.occ.p, C,

@@ -75,7 +75,7 @@ static inline uint8_t nt4_host(uint8_t r)
 	return code;
 }
 
-void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, hipStream_t st)
+void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st)
 {
 	S.n_seq = n;
 	S.off.assign((size_t)n + 1, 0); S.len.assign(len, len + n); S.name.resize(n);
@@ -91,6 +91,13 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	S.d_nt4.upload(S.h_nt4, st);
 	S.d_off.upload(S.off, st);
 	S.d_len.upload(S.len, st);
+	S.n_grp = n_grp;
+	S.grp_off.assign(grp_off, grp_off + n_grp + 1);
+	S.grp_of_seq.assign((size_t)n, 0);
+	std::vector<uint32_t> base((size_t)n, 0);
+	for (int g = 0; g < n_grp; ++g) for (int64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) S.grp_of_seq[i] = (uint32_t)g, base[i] = (uint32_t)grp_off[g];
+	S.d_grp_of_seq.upload(S.grp_of_seq, st);
+	S.d_grp_base.upload(base, st);
 }
 
 // ------------------------------------------------------------------------------------------------
