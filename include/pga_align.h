@@ -42,15 +42,25 @@ typedef struct {
 
 typedef struct pga_result_s pga_result_t;
 
-typedef struct {                 /* stage timings and work counters of the last call, seconds / counts */
+typedef struct {                 /* stage wall times (s) and work counters of a call */
 	double upload, sketch, index, seed, chain, align, total;
-	double n_bases, n_minimizers, n_anchors, n_dp_jobs, n_dp_cells, n_matches;
+	double n_bases, n_minimizers, n_anchors, n_dp_jobs, n_dp_cells, n_matches, n_dp_bases;
+	/* the path's own kernels, device time from HIP events on the launch stream:
+	 * [0] k_sketch_tiles  [1] k_chain_segments  [2] k_backtrack  [3] k_extd2 */
+	double kern_ms[4], kern_launches[4], kern_alg_bytes[4];
 } pga_stats_t;
 
 /* seqs: n_seqs sequences, ASCII, NOT necessarily NUL-terminated (lengths in seq_lens); names: NUL-terminated
  * decimal BlockId strings (unique inside a group); group_off: n_groups+1 offsets into the sequence arrays. */
 int pga_align_groups(const pga_params_t *params, int32_t n_groups, const int64_t *group_off,
                      const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_result_t **out);
+/* Same work split in two: pga_batch_create() copies the sequences to the device (2-step hand-over for callers
+ * that keep block sequences resident across self-merge rounds); pga_batch_align() runs sketch -> index -> seed ->
+ * chain -> extend on the resident bases and may be called repeatedly. */
+typedef struct pga_batch_s pga_batch_t;
+int pga_batch_create(int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out);
+int pga_batch_align(pga_batch_t *batch, const pga_params_t *params, pga_result_t **out);
+void pga_batch_free(pga_batch_t *batch);
 int64_t pga_result_n_matches(const pga_result_t *r);
 const pga_match_t *pga_result_matches(const pga_result_t *r);
 const uint32_t *pga_result_cigars(const pga_result_t *r, uint64_t *n_ops);

@@ -29,7 +29,11 @@ class pga_match_t(C.Structure):
 
 class pga_stats_t(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("upload", "sketch", "index", "seed", "chain", "align", "total", "n_bases", "n_minimizers", "n_anchors",
-                                          "n_dp_jobs", "n_dp_cells", "n_matches")]
+                                          "n_dp_jobs", "n_dp_cells", "n_matches", "n_dp_bases")] + \
+               [("kern_ms", C.c_double * 4), ("kern_launches", C.c_double * 4), ("kern_alg_bytes", C.c_double * 4)]
+
+
+KERNELS = ("k_sketch_tiles", "k_chain_segments", "k_backtrack", "k_extd2")
 
 
 class PgaError(RuntimeError):
@@ -48,6 +52,11 @@ def lib():
         d.pga_align_groups.restype = C.c_int
         d.pga_align_groups.argtypes = [C.POINTER(pga_params_t), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        d.pga_batch_create.restype = C.c_int
+        d.pga_batch_create.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        d.pga_batch_align.restype = C.c_int
+        d.pga_batch_align.argtypes = [C.c_void_p, C.POINTER(pga_params_t), C.POINTER(C.c_void_p)]
+        d.pga_batch_free.argtypes = [C.c_void_p]
         d.pga_result_n_matches.restype = C.c_int64
         d.pga_result_n_matches.argtypes = [C.c_void_p]
         d.pga_result_matches.restype = C.POINTER(pga_match_t)
@@ -101,6 +110,46 @@ class PreparedBatch:
 class BatchResult:
     groups: List[List[PafRow]]
     stats: dict
+    raw_matches: Optional[bytes] = None   # packed pga_match_t[] (for the multi-GPU gather)
+    raw_cigars: Optional[bytes] = None
+
+
+def _stats_dict(st) -> dict:
+    out = {}
+    for n, t in pga_stats_t._fields_:
+        v = getattr(st, n)
+        out[n] = list(v) if hasattr(v, "__len__") else v
+    return out
+
+
+class ResidentBatch:
+    """Sequences of a PreparedBatch copied to HBM once (pga_batch_create); align() runs the whole hot path on them."""
+
+    def __init__(self, pb: PreparedBatch):
+        self.pb = pb
+        self.h = C.c_void_p()
+        if lib().pga_batch_create(pb.n_groups, pb.off, pb.seqs, pb.lens, pb.cnames, C.byref(self.h)) != 0:
+            raise PgaError(lib().pga_last_error().decode())
+
+    def align(self, sensitivity: int = 10, kmer_length: Optional[int] = None, indel_len_threshold: int = 100, n_threads: int = 0,
+              want_rows: bool = False, want_raw: bool = False) -> BatchResult:
+        d = lib()
+        p = pga_params_t(sensitivity, kmer_length or 0, indel_len_threshold, n_threads)
+        out = C.c_void_p()
+        if d.pga_batch_align(self.h, C.byref(p), C.byref(out)) != 0:
+            raise PgaError(d.pga_last_error().decode())
+        return _unpack(self.pb, out, want_rows, want_raw)
+
+    def close(self):
+        if self.h:
+            lib().pga_batch_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def align_prepared(pb: PreparedBatch, sensitivity: int = 10, kmer_length: Optional[int] = None, indel_len_threshold: int = 100,
@@ -111,9 +160,14 @@ def align_prepared(pb: PreparedBatch, sensitivity: int = 10, kmer_length: Option
     rc = d.pga_align_groups(C.byref(p), pb.n_groups, pb.off, pb.seqs, pb.lens, pb.cnames, C.byref(out))
     if rc != 0:
         raise PgaError(d.pga_last_error().decode())
+    return _unpack(pb, out, want_rows, False)
+
+
+def _unpack(pb: PreparedBatch, out, want_rows: bool, want_raw: bool) -> BatchResult:
+    d = lib()
     try:
         st = d.pga_result_stats(out).contents
-        stats = {n: getattr(st, n) for n, _ in pga_stats_t._fields_}
+        stats = _stats_dict(st)
         groups: List[List[PafRow]] = [[] for _ in range(pb.n_groups)]
         if want_rows:
             n = d.pga_result_n_matches(out)
@@ -127,7 +181,14 @@ def align_prepared(pb: PreparedBatch, sensitivity: int = 10, kmer_length: Option
                 groups[r.group].append(PafRow(qname=pb.names[b + r.qry], qlen=r.qry_len, qs=r.qry_start, qe=r.qry_end, strand="-" if r.reverse else "+",
                                               tname=pb.names[b + r.ref], tlen=r.ref_len, rs=r.ref_start, re=r.ref_end, mlen=r.matches, blen=r.length,
                                               mapq=r.quality, AS=r.align, de=r.divergence, cg=cigar, n_ambi=r.n_ambi, inv=r.inv))
-        return BatchResult(groups, stats)
+        raw_m = raw_c = None
+        if want_raw:
+            n = d.pga_result_n_matches(out)
+            nops = C.c_uint64()
+            cg = d.pga_result_cigars(out, C.byref(nops))
+            raw_m = C.string_at(d.pga_result_matches(out), n * C.sizeof(pga_match_t)) if n else b""
+            raw_c = C.string_at(cg, nops.value * 4) if nops.value else b""
+        return BatchResult(groups, stats, raw_m, raw_c)
     finally:
         d.pga_result_free(out)
 

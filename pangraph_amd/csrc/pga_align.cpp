@@ -874,7 +874,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 				if (!jb.empty()) {
 					std::vector<DpRes> rs; std::vector<uint32_t> cg;
 					double t_dp = getenv("PGA_VERBOSE") ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
-					dp_run(S.d_nt4.p, jb, P, rs, cg, st);
+					dp_run(S.d_nt4.p, jb, P, rs, cg, st, tm);
 					if (t_dp > 0) fprintf(stderr, "[pga]   round %d: %zu DP problems in %.3f s\n", round, jb.size(), std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dp);
 					if (tm) { tm->dp_jobs += (double)jb.size(); for (auto &j : jb) tm->dp_cells += (double)j.qlen * j.tlen; }
 					for (size_t i = 0; i < rs.size(); ++i) {

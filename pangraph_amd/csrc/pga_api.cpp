@@ -81,7 +81,7 @@ struct PgaIdx {
 	std::vector<mm_idx_seq_t> seq_hdr; std::vector<std::string> names;
 	std::map<std::string, int> by_name;
 	std::mutex mtx;
-	bool have_results = false; mm_mapopt_t res_opt;
+	bool have_results = false, indexed = false; mm_mapopt_t res_opt;
 	std::vector<std::vector<Reg>> results;
 	Timers tm;
 	hipStream_t st = 0;
@@ -107,7 +107,19 @@ static void check_supported(const mm_mapopt_t &o, int k, int w)
 	if (o.sdust_thres > 0) throw std::runtime_error("pga: SDUST masking is not implemented");
 }
 
-static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp = 1, const int64_t *grp_off = nullptr)
+static void idx_sketch_index(PgaIdx &ix)
+{
+	const int w = ix.hdr.w, k = ix.hdr.k;
+	double t1 = now_s();
+	sketch_all(ix.S, w, k, ix.M, ix.st, &ix.tm);
+	double t2 = now_s();
+	build_index_ex(ix.S, ix.M, w, k, ix.I, ix.grp, ix.st);
+	double t3 = now_s();
+	ix.tm.sketch = t2 - t1, ix.tm.index = t3 - t2; ix.tm.n_mz = (double)ix.M.n;
+	ix.indexed = true;
+}
+
+static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp = 1, const int64_t *grp_off = nullptr, bool do_index = true)
 {
 	require_device();
 	std::unique_ptr<PgaIdx> ix(new PgaIdx());
@@ -140,12 +152,8 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	ix->hdr.b = 14 < 2 * k ? 14 : 2 * k, ix->hdr.w = w, ix->hdr.k = k, ix->hdr.flag = name ? 0 : MM_I_NO_NAME;
 	ix->hdr.n_seq = (uint32_t)n; ix->hdr.seq = ix->seq_hdr.data();
 	PGA_HIP(hipStreamSynchronize(ix->st));
-	double t1 = now_s();
-	sketch_all(ix->S, w, k, ix->M, ix->st);
-	double t2 = now_s();
-	build_index_ex(ix->S, ix->M, w, k, ix->I, ix->grp, ix->st);
-	double t3 = now_s();
-	ix->tm.upload = t1 - t0, ix->tm.sketch = t2 - t1, ix->tm.index = t3 - t2; ix->tm.n_mz = (double)ix->M.n;
+	ix->tm.upload = now_s() - t0;
+	if (do_index) idx_sketch_index(*ix);
 	return ix.release();
 }
 
@@ -173,7 +181,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st);
 	double t1 = now_s();
 	ChainResult CR;
-	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st);
+	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st, &ix.tm);
 	double t2 = now_s();
 	if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 1; }
 	align_batch(ix.S, opt, ix.I.k, SR.h_q_aoff, CR, SR.h_rep_len, ix.results, n_threads, &ix.tm, ix.st);
@@ -280,6 +288,32 @@ extern "C" double mm_event_identity(const mm_reg1_t *r) // align.c:897-917
 // ---------------------------------------------------------------- native batch entry
 struct pga_result_s { std::vector<pga_match_t> m; std::vector<uint32_t> cig; pga_stats_t st; };
 
+static void collect_results(PgaIdx &ixr, int g0, const std::vector<int64_t> &goff, pga_result_s &R)
+{
+	PgaIdx *ix = &ixr;
+	const int n = ix->S.n_seq;
+	for (int q = 0; q < n; ++q) for (const Reg &r : ix->results[q]) {
+		if (!r.has_p) throw std::runtime_error("Unable to find CIGAR string in the result"); // align_with_minimap2_lib.rs:118
+		const int g = (int)ix->S.grp_of_seq[q], gb = (int)goff[g];
+		pga_match_t m; memset(&m, 0, sizeof(m));
+		m.group = g0 + g, m.qry = q - gb, m.ref = r.rid, m.qry_len = (int32_t)ix->S.len[q], m.qry_start = r.qs, m.qry_end = r.qe;
+		m.ref_len = (int32_t)ix->S.len[gb + r.rid], m.ref_start = r.rs, m.ref_end = r.re;
+		m.matches = r.mlen, m.length = r.blen, m.quality = (int32_t)r.mapq, m.reverse = (int32_t)r.rev, m.align = r.dp_score;
+		m.n_ambi = (int32_t)r.n_ambi, m.inv = (int32_t)r.inv;
+		int32_t n_gapo = 0, n_gap = 0;
+		for (uint32_t c : r.cigar) { int32_t op = c & 0xf, len = (int32_t)(c >> 4); if (op == 1 || op == 2) ++n_gapo, n_gap += len; }
+		m.divergence = 1.0 - (double)r.mlen / (r.blen + (int32_t)r.n_ambi - n_gap + n_gapo);
+		m.cigar_off = R.cig.size(), m.n_cigar = (uint32_t)r.cigar.size();
+		R.cig.insert(R.cig.end(), r.cigar.begin(), r.cigar.end());
+		R.m.push_back(m);
+	}
+	const Timers &t = ix->tm;
+	R.st.upload += t.upload, R.st.sketch += t.sketch, R.st.index += t.index, R.st.seed += t.seed, R.st.chain += t.chain, R.st.align += t.align;
+	R.st.n_bases += (double)ix->S.total, R.st.n_minimizers += t.n_mz, R.st.n_anchors += t.n_anchor, R.st.n_dp_jobs += t.dp_jobs, R.st.n_dp_cells += t.dp_cells;
+	R.st.n_dp_bases += t.dp_bases;
+	for (int i = 0; i < K_COUNT; ++i) R.st.kern_ms[i] += t.kern[i].ms, R.st.kern_launches[i] += t.kern[i].launches, R.st.kern_alg_bytes[i] += t.kern[i].alg_bytes;
+}
+
 static void params_to_opts(const pga_params_t &p, mm_idxopt_t &io, mm_mapopt_t &mo) // align_with_minimap2_lib.rs:35-57 + options_args.rs:273-325
 {
 	const char *preset = p.sensitivity == 5 ? "asm5" : p.sensitivity == 10 ? "asm10" : p.sensitivity == 20 ? "asm20" : nullptr;
@@ -322,24 +356,7 @@ extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, co
 				mm_mapopt_t mo = mo0;
 				if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
 				run_batch(*ix, mo, params->n_threads);
-				for (int q = 0; q < (int)n; ++q) for (const Reg &r : ix->results[q]) {
-					if (!r.has_p) throw std::runtime_error("Unable to find CIGAR string in the result"); // align_with_minimap2_lib.rs:118
-					const int g = (int)ix->S.grp_of_seq[q], gb = (int)goff[g];
-					pga_match_t m; memset(&m, 0, sizeof(m));
-					m.group = g0 + g, m.qry = q - gb, m.ref = r.rid, m.qry_len = (int32_t)ix->S.len[q], m.qry_start = r.qs, m.qry_end = r.qe;
-					m.ref_len = (int32_t)ix->S.len[gb + r.rid], m.ref_start = r.rs, m.ref_end = r.re;
-					m.matches = r.mlen, m.length = r.blen, m.quality = (int32_t)r.mapq, m.reverse = (int32_t)r.rev, m.align = r.dp_score;
-					m.n_ambi = (int32_t)r.n_ambi, m.inv = (int32_t)r.inv;
-					int32_t n_gapo = 0, n_gap = 0;
-					for (uint32_t c : r.cigar) { int32_t op = c & 0xf, len = (int32_t)(c >> 4); if (op == 1 || op == 2) ++n_gapo, n_gap += len; }
-					m.divergence = 1.0 - (double)r.mlen / (r.blen + (int32_t)r.n_ambi - n_gap + n_gapo);
-					m.cigar_off = R->cig.size(), m.n_cigar = (uint32_t)r.cigar.size();
-					R->cig.insert(R->cig.end(), r.cigar.begin(), r.cigar.end());
-					R->m.push_back(m);
-				}
-				const Timers &t = ix->tm;
-				R->st.upload += t.upload, R->st.sketch += t.sketch, R->st.index += t.index, R->st.seed += t.seed, R->st.chain += t.chain, R->st.align += t.align;
-				R->st.n_bases += (double)ix->S.total, R->st.n_minimizers += t.n_mz, R->st.n_anchors += t.n_anchor, R->st.n_dp_jobs += t.dp_jobs, R->st.n_dp_cells += t.dp_cells;
+				collect_results(*ix, g0, goff, *R);
 			}
 			g0 = g1;
 		}
@@ -348,6 +365,69 @@ extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, co
 		return 0;
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
+
+// ---- resident batches: upload once, align (possibly many times) with the bases already in HBM ----
+struct pga_batch_s { std::vector<std::unique_ptr<PgaIdx>> parts; std::vector<int> g0; std::vector<std::vector<int64_t>> goff; int w = 0, k = 0; uint64_t bases = 0; };
+
+extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out)
+{
+	*out = nullptr;
+	try {
+		std::unique_ptr<pga_batch_s> B(new pga_batch_s());
+		const uint64_t max_bases = getenv("PGA_MAX_BATCH_BASES") ? strtoull(getenv("PGA_MAX_BATCH_BASES"), 0, 10) : 3000000000ULL;
+		int g0 = 0;
+		while (g0 < n_groups) {
+			int g1 = g0; uint64_t bases = 0;
+			while (g1 < n_groups) {
+				uint64_t gb = 0; for (int64_t i = group_off[g1]; i < group_off[g1 + 1]; ++i) gb += seq_lens[i];
+				if (g1 > g0 && bases + gb > max_bases) break;
+				bases += gb; ++g1;
+			}
+			const int64_t b = group_off[g0], n = group_off[g1] - b;
+			std::vector<int64_t> goff((size_t)(g1 - g0) + 1);
+			for (int g = g0; g <= g1; ++g) goff[g - g0] = group_off[g] - b;
+			if (n > 0) {
+				// w,k are not known yet: upload only (w=k=1 placeholders are overwritten by pga_batch_align)
+				B->parts.emplace_back(idx_build(1, 1, (int)n, seqs + b, seq_lens + b, names + b, g1 - g0, goff.data(), false));
+				B->g0.push_back(g0); B->goff.push_back(goff); B->bases += bases;
+			}
+			g0 = g1;
+		}
+		*out = B.release();
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_result_t **out)
+{
+	*out = nullptr;
+	try {
+		mm_idxopt_t io; mm_mapopt_t mo0;
+		params_to_opts(*params, io, mo0);
+		std::unique_ptr<pga_result_s> R(new pga_result_s());
+		memset(&R->st, 0, sizeof(R->st));
+		double t_all = now_s();
+		for (size_t p = 0; p < B->parts.size(); ++p) {
+			PgaIdx &ix = *B->parts[p];
+			if (!ix.indexed || ix.hdr.w != io.w || ix.hdr.k != io.k) {
+				ix.hdr.w = io.w, ix.hdr.k = io.k, ix.hdr.b = 14 < 2 * io.k ? 14 : 2 * io.k;
+				ix.mid_occ_frac = -1.0f; ix.have_results = false;
+			}
+			const double up = ix.tm.upload; ix.tm = Timers(); ix.tm.upload = up;
+			idx_sketch_index(ix);          // the index is part of the hot path: rebuilt on every call, like every find_matches does
+			mm_mapopt_t mo = mo0;
+			if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
+			run_batch(ix, mo, params->n_threads);
+			collect_results(ix, B->g0[p], B->goff[p], *R);
+			ix.results.clear(); ix.have_results = false;
+		}
+		R->st.total = now_s() - t_all; R->st.n_matches = (double)R->m.size();
+		*out = R.release();
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+extern "C" void pga_batch_free(pga_batch_t *B) { delete B; }
+
 extern "C" int64_t pga_result_n_matches(const pga_result_t *r) { return (int64_t)r->m.size(); }
 extern "C" const pga_match_t *pga_result_matches(const pga_result_t *r) { return r->m.data(); }
 extern "C" const uint32_t *pga_result_cigars(const pga_result_t *r, uint64_t *n_ops) { if (n_ops) *n_ops = r->cig.size(); return r->cig.data(); }

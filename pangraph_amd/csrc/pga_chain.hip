@@ -415,7 +415,7 @@ __global__ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, cons
 }
 
 
-void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st)
+void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm)
 {
 	const int n_seq = S.n_seq;
 	O.n_u.assign((size_t)n_seq, 0); O.n_v.assign((size_t)n_seq, 0); O.u.clear(); O.a.clear();
@@ -466,13 +466,23 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	DBuf<CNode> nd_main(n_a), nd_inner(n_a);
 	DBuf<int32_t> f(n_a), pp(n_a), t(n_a), v(n_a);
 	t.zero(st);
-	hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+	{
+		EventTimer et(st);
+		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+		const double ms = et.stop();
+		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
+	}
 	hipLaunchKernelGGL(k_fix_pred, dim3(nba), dim3(256), 0, st, seg_start.p, n_seg, n_a, q_aoff.p, n_seq, seg_incl.p, pp.p);
 	// backtrack + compact, one lane per query
 	DBuf<u128> z(n_a), w(n_a), out(n_a);
 	DBuf<uint64_t> u(n_a), u2(n_a);
 	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
-	hipLaunchKernelGGL(k_backtrack, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p);
+	{
+		EventTimer et(st);
+		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p);
+		const double ms = et.stop();
+		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
+	}
 	PGA_HIP(hipGetLastError());
 	O.n_u = n_u.download(st); O.n_v = n_v.download(st);
 	O.u = u.download(st);

@@ -82,11 +82,23 @@ struct Index {
 	DBuf<uint32_t> key_grp;             // group of every key (keys are sorted by (group, hash))
 };
 
-struct Timers { double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0; };
+enum { K_SKETCH = 0, K_CHAIN = 1, K_BACKTRACK = 2, K_EXTD2 = 3, K_COUNT = 4 };
+struct KernelStat { double ms = 0, launches = 0, alg_bytes = 0; };
+struct Timers {
+	double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0, dp_bases = 0, dp_cigar_ops = 0;
+	KernelStat kern[K_COUNT];   // device time of the path's own kernels, measured with HIP events on the launch stream
+};
+// times everything enqueued on `st` between construction and stop()
+struct EventTimer {
+	hipEvent_t a, b; hipStream_t st;
+	explicit EventTimer(hipStream_t s) : st(s) { PGA_HIP(hipEventCreate(&a)); PGA_HIP(hipEventCreate(&b)); PGA_HIP(hipEventRecord(a, st)); }
+	double stop() { float ms = 0; PGA_HIP(hipEventRecord(b, st)); PGA_HIP(hipEventSynchronize(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); return ms; }
+	~EventTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
 
 // stage entry points (each in its own .hip/.cpp)
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st);
-void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st);
+void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm = nullptr);
 std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f, hipStream_t st);
 
 } // namespace pga

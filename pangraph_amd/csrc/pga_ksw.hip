@@ -325,7 +325,7 @@ size_t dp_slab_bytes(int qlen, int tlen, int w)
 	return (b + 255) & ~(size_t)255;
 }
 
-void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st)
+void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
@@ -363,14 +363,21 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		size_t budget = (size_t)24 << 30;
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
 		DBuf<uint8_t> d_slab(n_waves * slab_max[c]);
+		EventTimer et(st);
 		hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
 		                   d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
+		const double ms = et.stop();
+		if (tm) {
+			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
+			tm->kern[K_EXTD2].ms += ms; tm->kern[K_EXTD2].launches += 1; tm->kern[K_EXTD2].alg_bytes += 0.5 * bases; tm->dp_bases += bases; // 2-bit packed q+t reads; CIGAR bytes added below
+		}
 		std::vector<DpRes> r = d_r.download(st);
 		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];
 	}
 	unsigned long long used = d_cursor.download(st)[0];
 	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");
+	if (tm) { tm->kern[K_EXTD2].alg_bytes += 4.0 * (double)used; tm->dp_cigar_ops += (double)used; }
 	cigars.resize((size_t)used);
 	if (used) { PGA_HIP(hipMemcpyAsync(cigars.data(), d_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st)); }
 }

@@ -340,7 +340,7 @@ template <class T> static void exclusive_scan_u64(const T *in, uint64_t *out, si
 	PGA_HIP(hipStreamSynchronize(st));
 }
 
-void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st)
+void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm)
 {
 	const int n = S.n_seq;
 	M.n = 0;
@@ -365,9 +365,11 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st)
 		uint32_t cap = SK_TILE / 4;                           // expected density is 2/(w+1) per base
 		for (;;) {
 			DBuf<u128> stage(nt * (size_t)cap);
+			EventTimer et(st);
 			hipLaunchKernelGGL((k_sketch_tiles<63>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st,
 			                   S.d_nt4.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
 			PGA_HIP(hipGetLastError());
+			const double k_ms = et.stop();
 			int ovf = d_ovf.download(st)[0];
 			if (ovf) { cap *= 4; d_ovf.zero(st); continue; }  // pathological repeats: retry with bigger slabs
 			exclusive_scan_u64(d_cnt.p, d_toff.p, nt + 1, st);
@@ -375,6 +377,7 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st)
 			PGA_HIP(hipMemcpyAsync(&total, d_toff.p + nt, 8, hipMemcpyDeviceToHost, st));
 			PGA_HIP(hipStreamSynchronize(st));
 			M.n = total;
+			if (tm) { tm->kern[K_SKETCH].ms += k_ms; tm->kern[K_SKETCH].launches += 1; tm->kern[K_SKETCH].alg_bytes += (double)S.total + 16.0 * (double)total; }
 			M.mz.alloc(total ? total : 1);
 			hipLaunchKernelGGL(k_compact, dim3((unsigned)nt), dim3(256), 0, st, stage.p, cap, d_cnt.p, d_toff.p, M.mz.p);
 			// sequences of length 0 have no tile: give them the offset of the next tile (or the total)
