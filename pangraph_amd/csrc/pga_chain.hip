@@ -17,6 +17,7 @@
 #include "pga_sort_exact.h"
 #include "pga_pipeline.h"
 #include <rocprim/rocprim.hpp>
+#include <cstdio>
 
 namespace pga {
 
@@ -219,15 +220,191 @@ template <bool RMQ> struct Tree {
 
 struct Iter { int32_t stack[CMAXD]; int top; };
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast path: one WAVE per segment, no tree.  The range-min query of lchain.c:311 is a masked minimum over the
+// live window [st,i0) kept in LDS rings; it is exact whenever the minimum priority is unique.  If two live
+// candidates inside the query range tie on the minimum, the reference's answer depends on its AVL shape, so the
+// wave gives up and flags the segment; flagged segments are re-run by k_chain_segments (the tree re-enactment).
+// The inner scan of lchain.c:322-349 is evaluated without the t[] array: t[j]==i holds exactly when some
+// candidate visited earlier in the scan (one with a larger key, hence any candidate at all) has p[]==j and
+// passes the bandwidth test, so "marked" is a set-membership stamp; the n_skip walk itself stays sequential.
+#define CF_W 2048          // main-window ring capacity (anchors)
+#define CF_WI 512          // inner-window ring capacity
+#define CF_MAXIN 256       // inner candidates handled by the fast path
+
+__global__ __launch_bounds__(64)
+void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
+                  uint64_t n_total, const uint64_t *__restrict__ q_aoff, int n_seq, ChainParams P,
+                  int32_t *__restrict__ f, int32_t *__restrict__ pp, uint32_t *__restrict__ seg_flag)
+{
+	__shared__ double r_pri[CF_W];
+	__shared__ int32_t r_y[CF_W];
+	__shared__ int32_t r_f[CF_W];
+	__shared__ int32_t r_p[CF_WI];
+	__shared__ int32_t r_t[CF_WI];
+	__shared__ int32_t s_sc[CF_MAXIN], s_j[CF_MAXIN];
+	__shared__ uint8_t s_fl[CF_MAXIN];
+	const int lane = threadIdx.x;
+	const uint32_t sidx = blockIdx.x;
+	if (sidx >= n_seg) return;
+	const uint32_t sg = seg_order[sidx];
+	const uint64_t b = seg_start[sg], e = sg + 1 < n_seg ? seg_start[sg + 1] : n_total;
+	const int32_t n = (int32_t)(e - b);
+	const u128 *A = a + b;
+	int32_t *F = f + b, *PP = pp + b;
+	// query-local index of the segment's first anchor: the RMQ upper key is (y_i, 0) in QUERY numbering (lchain.c:310)
+	int qlo = 0, qhi = n_seq;
+	while (qlo < qhi) { int m = (qlo + qhi) >> 1; if (q_aoff[m + 1] <= b) qlo = m + 1; else qhi = m; }
+	const bool seg_is_query_start = (q_aoff[qlo] == b);
+	int32_t max_dist = P.max_dist, max_dist_inner = P.max_dist_inner;
+	if (max_dist < P.bw) max_dist = P.bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	for (int k = lane; k < CF_WI; k += 64) r_t[k] = -1;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	int32_t st = 0, st_in = 0, i0 = 0;
+	bool bail = false;
+	for (int32_t i = 0; i < n && !bail; ++i) {
+		const u128 ai = A[i];
+		const int32_t yi = (int32_t)ai.y, q_span = (int32_t)(ai.y >> 32 & 0xff);
+		int32_t max_f = q_span, max_j = -1;
+		// 1. late insertion of the anchors that did not share x with their successors (lchain.c:281-293)
+		if (i0 < i && A[i0].x != ai.x) {
+			for (int32_t j = i0 + lane; j < i; j += 64) {
+				const u128 aj = A[j];
+				const int32_t fj = r_f[j & (CF_W - 1)];
+				r_pri[j & (CF_W - 1)] = -((double)fj + 0.5 * (double)P.pen_gap * (double)((int32_t)aj.x + (int32_t)aj.y));
+				r_y[j & (CF_W - 1)] = (int32_t)aj.y;
+			}
+			i0 = i;
+		}
+		// 2. eviction (lchain.c:295-309): x is ascending inside a segment, so the new start is a forward search
+		for (;;) {
+			const int32_t j = st + lane;
+			const bool keep = j >= i0 || !(ai.x > A[j < n ? j : n - 1].x + (uint64_t)max_dist);
+			const unsigned long long m = __ballot(keep);
+			if (m) { st += __ffsll((long long)m) - 1; break; }
+			st += 64;
+		}
+		if (st > i0) st = i0;
+		if (i0 - st > P.cap) st = i0 - P.cap;
+		if (max_dist_inner > 0) {
+			for (;;) {
+				const int32_t j = st_in + lane;
+				const bool keep = j >= i0 || !(ai.x > A[j < n ? j : n - 1].x + (uint64_t)max_dist_inner);
+				const unsigned long long m = __ballot(keep);
+				if (m) { st_in += __ffsll((long long)m) - 1; break; }
+				st_in += 64;
+			}
+			if (st_in > i0) st_in = i0;
+			if (i0 - st_in > P.cap) st_in = i0 - P.cap;
+		} else st_in = i0;
+		if (i0 - st > CF_W) { bail = true; break; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		// 3. range-min over the live window with keys in ((y_i-max_dist, +inf), (y_i, query anchor 0)]
+		double best = 1e300; int32_t best_j = -1; bool tie = false;
+		for (int32_t j = st + lane; j < i0; j += 64) {
+			const int32_t yj = r_y[j & (CF_W - 1)];
+			const bool in = yj > yi - max_dist && (yj < yi || (yj == yi && seg_is_query_start && j == 0));
+			if (in) {
+				const double pj = r_pri[j & (CF_W - 1)];
+				if (pj < best) best = pj, best_j = j, tie = false;
+				else if (pj == best) tie = true;
+			}
+		}
+		{
+			double wb = best;
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) {
+				const double o = __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(wb) >> 32), d) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(wb) & 0xffffffffLL), d));
+				wb = o < wb ? o : wb;
+			}
+			const unsigned long long who = __ballot(best_j >= 0 && best == wb);
+			if (who == 0) best_j = -1;
+			else {
+				if (__popcll(who) > 1 || __ballot(tie && best == wb)) { bail = true; break; }
+				best_j = __shfl(best_j, __ffsll((long long)who) - 1);
+			}
+		}
+		if (best_j >= 0) {
+			int32_t exact, width, n_skip = 0, j = best_j;
+			int32_t sc = r_f[j & (CF_W - 1)] + score_pair(ai, A[j], P.pen_gap, P.pen_skip, &exact, &width);
+			if (width <= P.bw && sc > max_f) max_f = sc, max_j = j;
+			if (!exact && st_in < i0 && yi > 0) {
+				const int32_t n_in = i0 - st_in;
+				if (n_in > CF_MAXIN) { bail = true; break; }
+				// per candidate: score, bandwidth test, validity (y in [y_i - inner, y_i - 1]); marks for predecessors
+				int32_t c_sc[CF_MAXIN / 64], c_y[CF_MAXIN / 64]; bool c_ok[CF_MAXIN / 64], c_val[CF_MAXIN / 64];
+#pragma unroll
+				for (int k = 0; k < CF_MAXIN / 64; ++k) {
+					const int32_t jc = st_in + lane + 64 * k;
+					c_val[k] = false; c_ok[k] = false; c_sc[k] = 0; c_y[k] = 0;
+					if (jc < i0) {
+						const int32_t yj = r_y[jc & (CF_W - 1)];
+						c_y[k] = yj;
+						if (yj <= yi - 1 && yj >= yi - max_dist_inner) {
+							int32_t wdt;
+							c_val[k] = true;
+							c_sc[k] = r_f[jc & (CF_W - 1)] + score_pair(ai, A[jc], P.pen_gap, P.pen_skip, nullptr, &wdt);
+							c_ok[k] = wdt <= P.bw;
+							if (c_ok[k]) { const int32_t pj = r_p[jc & (CF_WI - 1)]; if (pj >= st_in) r_t[pj & (CF_WI - 1)] = i; }
+						}
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				// rank by descending (y, j) among valid candidates (all-pairs count), then scatter in scan order
+				int32_t n_valid = 0;
+#pragma unroll
+				for (int k = 0; k < CF_MAXIN / 64; ++k) n_valid += __popcll(__ballot(c_val[k]));
+#pragma unroll
+				for (int k = 0; k < CF_MAXIN / 64; ++k) {
+					const int32_t jc = st_in + lane + 64 * k;
+					if (c_val[k]) {
+						int32_t rank = 0;
+						for (int32_t jo = st_in; jo < i0; ++jo) {
+							const int32_t yo = r_y[jo & (CF_W - 1)];
+							const bool vo = yo <= yi - 1 && yo >= yi - max_dist_inner;
+							rank += (vo && (yo > c_y[k] || (yo == c_y[k] && jo > jc))) ? 1 : 0;
+						}
+						s_sc[rank] = c_sc[k]; s_j[rank] = jc;
+						s_fl[rank] = (uint8_t)((c_ok[k] ? 1 : 0) | (r_t[jc & (CF_WI - 1)] == i ? 2 : 0));
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				for (int32_t c = 0; c < n_valid; ++c) {                       // lchain.c:330-346, wave-uniform
+					const int32_t fl = s_fl[c];
+					if (fl & 1) {
+						const int32_t scc = s_sc[c];
+						if (scc > max_f) { max_f = scc, max_j = s_j[c]; if (n_skip > 0) --n_skip; }
+						else if (fl & 2) { if (++n_skip > P.max_skip) break; }
+					}
+				}
+			}
+		}
+		if (lane == 0) {
+			F[i] = max_f, PP[i] = max_j;
+			r_f[i & (CF_W - 1)] = max_f; r_p[i & (CF_WI - 1)] = max_j;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	if (lane == 0) seg_flag[sg] = bail ? 1u : 0u;
+}
+
 // one lane per segment: the sweep of lchain.c:276-357 restricted to anchors [b,e) (tree empty at b)
 __global__ void k_chain_segments(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
-                                 uint64_t n_total, ChainParams P, CNode *__restrict__ nd_main, CNode *__restrict__ nd_inner,
+                                 uint64_t n_total, const uint64_t *__restrict__ q_aoff, int n_seq, const uint32_t *__restrict__ seg_flag,
+                                 ChainParams P, CNode *__restrict__ nd_main, CNode *__restrict__ nd_inner,
                                  int32_t *__restrict__ f, int32_t *__restrict__ pp, int32_t *__restrict__ t)
 {
 	uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sidx >= n_seg) return;
 	const uint32_t sg = seg_order[sidx];
+	if (seg_flag && !seg_flag[sg]) return;                     // the fast path already chained this segment
 	const uint64_t b = seg_start[sg], e = sg + 1 < n_seg ? seg_start[sg + 1] : n_total;
+	// the RMQ upper key (y_i, 0) is in QUERY numbering (lchain.c:310): only the query's very first anchor may equal y_i
+	int qlo = 0, qhi = n_seq;
+	while (qlo < qhi) { int m = (qlo + qhi) >> 1; if (q_aoff[m + 1] <= b) qlo = m + 1; else qhi = m; }
+	const int32_t hi_i = -(int32_t)(b - q_aoff[qlo]);
 	const int32_t n = (int32_t)(e - b);
 	const u128 *A = a + b;
 	int32_t *F = f + b, *PP = pp + b, *T = t + b;            // PP holds segment-local predecessor indices (-1 none)
@@ -262,7 +439,7 @@ __global__ void k_chain_segments(const u128 *__restrict__ a, const uint64_t *__r
 			}
 		}
 		const int32_t yi = (int32_t)ai.y;
-		int32_t q = Tm.rmq(yi - max_dist, INT32_MAX, yi, 0);
+		int32_t q = Tm.rmq(yi - max_dist, INT32_MAX, yi, hi_i);
 		if (q >= 0) {
 			int32_t sc, exact, width, n_skip = 0, j = q;
 			sc = F[j] + score_pair(ai, A[j], P.pen_gap, P.pen_skip, &exact, &width);
@@ -467,9 +644,18 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	DBuf<int32_t> f(n_a), pp(n_a), t(n_a), v(n_a);
 	t.zero(st);
 	{
+		DBuf<uint32_t> seg_flag(n_seg);
 		EventTimer et(st);
-		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
+		if (use_fast) hipLaunchKernelGGL(k_chain_fast, dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p);
+		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
+		                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+		PGA_HIP(hipGetLastError());
 		const double ms = et.stop();
+		if (getenv("PGA_VERBOSE") && use_fast) {
+			std::vector<uint32_t> fl = seg_flag.download(st); size_t nf = 0; for (uint32_t v : fl) nf += v;
+			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel, %.3f ms\n", n_seg, nf, ms);
+		}
 		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
 	}
 	hipLaunchKernelGGL(k_fix_pred, dim3(nba), dim3(256), 0, st, seg_start.p, n_seg, n_a, q_aoff.p, n_seq, seg_incl.p, pp.p);

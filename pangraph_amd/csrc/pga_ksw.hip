@@ -17,6 +17,7 @@
 // Persistent launch: a fixed grid of waves pulls problems from an atomic queue (problem sizes are ragged).
 #include "pga_common.h"
 #include "pga_dp.h"
+#include <cstdio>
 
 namespace pga {
 
@@ -325,52 +326,66 @@ size_t dp_slab_bytes(int qlen, int tlen, int w)
 	return (b + 255) & ~(size_t)255;
 }
 
+void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+                       DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
+
+// Problem classes (each is one persistent launch):
+//   0,1  register-resident kernel (pga_ksw_fast.hip), target <= 256 / <= 512 lanes, band never binding
+//   2    general kernel, LDS rows, small HBM slab          3    general kernel, rows in the HBM slab (wide targets)
+static int dp_class(const DpJob &j, size_t need)
+{
+	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
+	if (unbanded && j.tlen <= 256) return 0;
+	if (unbanded && j.tlen <= 512) return 1;
+	return need <= ((size_t)1 << 20) ? 2 : 3;
+}
+
 void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
 	if (n == 0) return;
-	// two size classes so that the per-wave HBM slabs of the many small problems stay small
-	std::vector<uint32_t> cls[2];
-	size_t slab_max[2] = {0, 0};
-	const size_t small_limit = (size_t)1 << 20;
+	std::vector<uint32_t> cls[4];
+	size_t slab_max[4] = {0, 0, 0, 0};
 	std::vector<size_t> need(n);
 	unsigned long long cig_total = 0;
 	for (size_t i = 0; i < n; ++i) {
 		need[i] = dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
-		int c = need[i] <= small_limit ? 0 : 1;
+		const int c = dp_class(jobs[i], need[i]);
 		cls[c].push_back((uint32_t)i);
 		if (need[i] > slab_max[c]) slab_max[c] = need[i];
 		cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;
 	}
 	res.resize(n);
-	DBuf<DpRes> d_res(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total);
 	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
-	std::vector<uint32_t> order; order.reserve(n);
-	for (int c = 0; c < 2; ++c) {
+	for (int c = 0; c < 4; ++c) {
 		if (cls[c].empty()) continue;
-		// biggest problems first: the persistent waves then finish together
 		std::vector<uint32_t> &ids = cls[c];
-		std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return need[a] > need[b]; });
+		// biggest problems first: the persistent waves then finish together
+		std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
 		std::vector<DpJob> jb(ids.size());
 		for (size_t i = 0; i < ids.size(); ++i) jb[i] = jobs[ids[i]];
 		DBuf<DpJob> d_jobs; d_jobs.upload(jb, st);
 		DBuf<DpRes> d_r(ids.size());
 		DBuf<uint32_t> d_cnt(1); d_cnt.zero(st);
-		size_t n_waves = c == 0 ? 256 * 16 : 256 * 2;
+		size_t n_waves = c == 3 ? 256 * 2 : c == 2 ? 256 * 7 : 256 * 16;
 		if (n_waves > ids.size()) n_waves = ids.size();
-		size_t budget = (size_t)24 << 30;
+		const size_t budget = (size_t)32 << 30;
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
 		DBuf<uint8_t> d_slab(n_waves * slab_max[c]);
+		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launching dp class %d: %zu problems on %zu waves, slab %zu B\n", c, ids.size(), n_waves, slab_max[c]); fflush(stderr); }
 		EventTimer et(st);
-		hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
-		                   d_r.p, d_pool.p, d_cursor.p, cig_total);
+		if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)n_waves, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
+		else hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
+		                        d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
+		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launched\n"); fflush(stderr); }
 		const double ms = et.stop();
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
 			tm->kern[K_EXTD2].ms += ms; tm->kern[K_EXTD2].launches += 1; tm->kern[K_EXTD2].alg_bytes += 0.5 * bases; tm->dp_bases += bases; // 2-bit packed q+t reads; CIGAR bytes added below
+			if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms, slab %.1f KB x %zu waves\n", c, ids.size(), ms, slab_max[c] / 1024.0, n_waves);
 		}
 		std::vector<DpRes> r = d_r.download(st);
 		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];
