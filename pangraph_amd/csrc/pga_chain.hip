@@ -539,58 +539,73 @@ __device__ inline int32_t bk_end(int32_t max_drop, const u128 *z, const int32_t 
 	return max_i;
 }
 
-// one lane per query: lchain.c:27-111.  Outputs u[] (score<<32|cnt) and the compacted anchors.
-__global__ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
-                            const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, u128 *__restrict__ z_all,
-                            uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
-                            ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out)
+// one WAVE per query: lchain.c:27-111.  Streaming passes (candidate list, mark reset, copies) use all 64 lanes;
+// the two inherently sequential walks -- the cycle-leader permutation of the unstable sort and the chain
+// backtrack -- run on lane 0.  Outputs u[] (score<<32|cnt) and the compacted anchors.
+__global__ __launch_bounds__(64)
+void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
+                 const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, u128 *__restrict__ z_all,
+                 uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
+                 ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out)
 {
-	int q = blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ uint32_t head[256], tail[256];
+	__shared__ int64_t s_nz; __shared__ int32_t s_nu; __shared__ int64_t s_nv;
+	const int q = blockIdx.x, lane = threadIdx.x;
 	if (q >= n_seq) return;
 	const uint64_t b = q_aoff[q];
 	const int64_t n = (int64_t)(q_aoff[q + 1] - b);
-	n_u_out[q] = 0, n_v_out[q] = 0;
+	if (lane == 0) n_u_out[q] = 0, n_v_out[q] = 0;
 	if (n == 0) return;
-	uint32_t head[256], tail[256];
 	const u128 *A = a + b; const int32_t *f = f_all + b, *p = p_all + b;
 	int32_t *t = t_all + b, *v = v_all + b;
 	u128 *z = z_all + b, *w = w_all + b, *out = out_all + b;
 	uint64_t *u = u_all + b, *u2 = u2_all + b;
-	int64_t n_z = 0, k, i, n_v = 0; int32_t n_u = 0;
-	for (i = 0; i < n; ++i) if (f[i] >= P.min_sc) { z[n_z].x = (uint64_t)f[i], z[n_z].y = (uint64_t)i; ++n_z; }
+	// candidate ends in index order (order-preserving compaction), marks cleared
+	int64_t n_z = 0;
+	for (int64_t i0 = 0; i0 < n; i0 += 64) {
+		const int64_t i = i0 + lane;
+		const bool keep = i < n && f[i] >= P.min_sc;
+		if (i < n) t[i] = 0;
+		const unsigned long long m = __ballot(keep);
+		if (keep) { const int64_t o = n_z + __popcll(m & ((1ULL << lane) - 1)); z[o].x = (uint64_t)f[i]; z[o].y = (uint64_t)i; }
+		n_z += __popcll(m);
+	}
+	__threadfence_block();
 	if (n_z == 0) return;
-	radix_sort_128x_exact(z, z + n_z, head, tail);
-	for (i = 0; i < n; ++i) t[i] = 0;
-	const int32_t max_drop = P.bw;
-	for (k = n_z - 1; k >= 0; --k) {
-		if (t[z[k].y] != 0) continue;
-		int64_t n_v0 = n_v; int32_t end_i, sc, ii;
-		end_i = bk_end(max_drop, z, f, p, t, k);
-		for (ii = (int32_t)z[k].y; ii != end_i; ii = p[ii]) v[n_v++] = ii, t[ii] = 1;
-		sc = ii < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[ii];
-		if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
-		else n_v = n_v0;
+	if (lane == 0) {
+		int64_t k, i, n_v = 0; int32_t n_u = 0;
+		radix_sort_128x_exact(z, z + n_z, head, tail);
+		const int32_t max_drop = P.bw;
+		for (k = n_z - 1; k >= 0; --k) {
+			if (t[z[k].y] != 0) continue;
+			int64_t n_v0 = n_v; int32_t end_i, sc, ii;
+			end_i = bk_end(max_drop, z, f, p, t, k);
+			for (ii = (int32_t)z[k].y; ii != end_i; ii = p[ii]) v[n_v++] = ii, t[ii] = 1;
+			sc = ii < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[ii];
+			if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
+			else n_v = n_v0;
+		}
+		n_u_out[q] = n_u, n_v_out[q] = (int32_t)n_v;
+		// chains are ordered by the target position of their first anchor (compact_a, lchain.c:96-99)
+		int64_t kk = 0;
+		for (i = 0; i < n_u; ++i) { const int32_t ni = (int32_t)u[i]; w[i].x = A[v[kk + ni - 1]].x; w[i].y = (uint64_t)kk << 32 | (uint64_t)i; kk += ni; }
+		if (n_u > 0) radix_sort_128x_exact(w, w + n_u, head, tail);
+		// output offsets of the chains in their final order, stashed in u2 (low 32 bits) next to the chain word
+		kk = 0;
+		for (i = 0; i < n_u; ++i) { const int32_t j = (int32_t)w[i].y; u2[i] = u[j]; w[i].x = (uint64_t)kk; kk += (int32_t)u[j]; }
+		s_nu = n_u, s_nv = n_v;
 	}
-	n_u_out[q] = n_u, n_v_out[q] = (int32_t)n_v;
-	if (n_u == 0) return;
-	// compact_a: chains to ascending anchor order (into z, reused as scratch b[]), then order chains by first target position
-	u128 *bb = z;
-	for (i = 0, k = 0; i < n_u; ++i) {
-		int32_t k0 = (int32_t)k, ni = (int32_t)u[i];
-		for (int32_t j = 0; j < ni; ++j) bb[k++] = A[v[k0 + (ni - j - 1)]];
+	__threadfence_block();
+	__syncthreads();
+	const int32_t n_u = s_nu;
+	// copy every chain, reversed to ascending anchor order, to its slot (all lanes)
+	for (int32_t c = 0; c < n_u; ++c) {
+		const int64_t src0 = (int64_t)(w[c].y >> 32), dst0 = (int64_t)w[c].x; const int32_t ni = (int32_t)u2[c];
+		for (int32_t m = lane; m < ni; m += 64) out[dst0 + m] = A[v[src0 + (ni - m - 1)]];
 	}
-	for (i = k = 0; i < n_u; ++i) { w[i].x = bb[k].x, w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
-	radix_sort_128x_exact(w, w + n_u, head, tail);
-	for (i = k = 0; i < n_u; ++i) {
-		int32_t j = (int32_t)w[i].y, nn = (int32_t)u[j];
-		u2[i] = u[j];
-		const u128 *src = bb + (w[i].y >> 32);
-		for (int32_t m = 0; m < nn; ++m) out[k + m] = src[m];
-		k += nn;
-	}
-	for (i = 0; i < n_u; ++i) u[i] = u2[i];
+	__syncthreads();
+	for (int32_t c = lane; c < n_u; c += 64) u[c] = u2[c];
 }
-
 
 void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm)
 {
@@ -665,7 +680,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
 	{
 		EventTimer et(st);
-		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p);
+		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p);
 		const double ms = et.stop();
 		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
 	}

@@ -14,6 +14,7 @@
 #include "pga_sort_exact.h"
 #include "pga_pipeline.h"
 #include <rocprim/rocprim.hpp>
+#include <cstdio>
 
 namespace pga {
 
@@ -212,6 +213,25 @@ __global__ void k_query_anchor_off(const uint64_t *__restrict__ a_off, const uin
 	if (q <= n_seq) { uint64_t o = seq_off2[q]; q_aoff[q] = o < n_kept ? a_off[o] : total; }
 }
 
+__global__ void k_iota32(uint32_t *v, uint64_t n)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] = (uint32_t)i;
+}
+__global__ void k_query_of_anchor(const uint32_t *__restrict__ idx, const uint64_t *__restrict__ q_aoff, int n_seq, uint64_t n, uint32_t *__restrict__ qk)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t o = idx[i];
+	int lo = 0, hi = n_seq;
+	while (lo < hi) { int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= o) lo = m + 1; else hi = m; }
+	qk[i] = (uint32_t)lo;
+}
+__global__ void k_gather_xy(const uint64_t *__restrict__ x, const uint64_t *__restrict__ y, const uint32_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ xo, uint64_t *__restrict__ yo)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { const uint32_t o = idx[i]; xo[i] = x[o]; yo[i] = y[o]; }
+}
 __global__ void k_split128(const u128 *__restrict__ a, uint64_t n, uint64_t *__restrict__ x, uint64_t *__restrict__ y)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,10 +359,25 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	DBuf<uint64_t> x0(n_a), y0(n_a), x1(n_a), y1(n_a);
 	hipLaunchKernelGGL(k_split128, dim3(nba), dim3(256), 0, st, a_raw.p, n_a, x0.p, y0.p);
 	{
+		// anchors are already grouped by query, so a device-wide stable sort by x followed by a stable sort by the
+		// query id (LSD order) equals a per-query sort, without the one-block-per-segment cost of a segmented sort
+		DBuf<uint32_t> idx0(n_a), idx1(n_a), qk0(n_a), qk1(n_a), idx2(n_a);
+		hipLaunchKernelGGL(k_iota32, dim3(nba), dim3(256), 0, st, idx0.p, n_a);
 		size_t tb = 0;
-		PGA_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, x0.p, x1.p, y0.p, y1.p, (unsigned)n_a, (unsigned)n_seq, O.q_aoff.p, O.q_aoff.p + 1, 0, 64, st));
+		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, x0.p, x1.p, idx0.p, idx1.p, n_a, 0, 64, st));
 		DBuf<uint8_t> tmp(tb ? tb : 1);
-		PGA_HIP(rocprim::segmented_radix_sort_pairs(tmp.p, tb, x0.p, x1.p, y0.p, y1.p, (unsigned)n_a, (unsigned)n_seq, O.q_aoff.p, O.q_aoff.p + 1, 0, 64, st));
+		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, x0.p, x1.p, idx0.p, idx1.p, n_a, 0, 64, st));
+		if (n_seq > 1) {
+			hipLaunchKernelGGL(k_query_of_anchor, dim3(nba), dim3(256), 0, st, idx1.p, O.q_aoff.p, n_seq, n_a, qk0.p);
+			int bits = 1; while ((1LL << bits) < n_seq) ++bits;
+			size_t tb2 = 0;
+			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb2, qk0.p, qk1.p, idx1.p, idx2.p, n_a, 0, bits, st));
+			DBuf<uint8_t> tmp2(tb2 ? tb2 : 1);
+			PGA_HIP(rocprim::radix_sort_pairs(tmp2.p, tb2, qk0.p, qk1.p, idx1.p, idx2.p, n_a, 0, bits, st));
+			hipLaunchKernelGGL(k_gather_xy, dim3(nba), dim3(256), 0, st, x0.p, y0.p, idx2.p, n_a, x1.p, y1.p);
+		} else {
+			hipLaunchKernelGGL(k_gather_xy, dim3(nba), dim3(256), 0, st, x0.p, y0.p, idx1.p, n_a, x1.p, y1.p);
+		}
 	}
 	hipLaunchKernelGGL(k_join128, dim3(nba), dim3(256), 0, st, x1.p, y1.p, n_a, O.a.p);
 	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
@@ -350,6 +385,10 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	hipLaunchKernelGGL(k_sort_exact, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipStreamSynchronize(st));
+	if (getenv("PGA_VERBOSE")) {
+		std::vector<uint32_t> tf = q_tie.download(st); size_t nt = 0; for (uint32_t v : tf) nt += v;
+		fprintf(stderr, "[pga]   seed: %llu anchors, %zu of %d queries hold equal anchor keys (sequential sort replay)\n", (unsigned long long)n_a, nt, n_seq);
+	}
 }
 
 } // namespace pga
