@@ -15,6 +15,7 @@
 // per query (they depend on the reference's unstable sort of the per-anchor scores, pga_sort_exact.h).
 #include "pga_common.h"
 #include "pga_sort_exact.h"
+#include "pga_sort_wave.h"
 #include "pga_pipeline.h"
 #include <rocprim/rocprim.hpp>
 #include <cstdio>
@@ -572,9 +573,10 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 	}
 	__threadfence_block();
 	if (n_z == 0) return;
+	radix_sort_128x_wave(z, n_z, head, tail, lane);
+	__threadfence_block();
 	if (lane == 0) {
 		int64_t k, i, n_v = 0; int32_t n_u = 0;
-		radix_sort_128x_exact(z, z + n_z, head, tail);
 		const int32_t max_drop = P.bw;
 		for (k = n_z - 1; k >= 0; --k) {
 			if (t[z[k].y] != 0) continue;
@@ -589,7 +591,7 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 		// chains are ordered by the target position of their first anchor (compact_a, lchain.c:96-99)
 		int64_t kk = 0;
 		for (i = 0; i < n_u; ++i) { const int32_t ni = (int32_t)u[i]; w[i].x = A[v[kk + ni - 1]].x; w[i].y = (uint64_t)kk << 32 | (uint64_t)i; kk += ni; }
-		if (n_u > 0) radix_sort_128x_exact(w, w + n_u, head, tail);
+		if (n_u > 0) { uint32_t h2[256], t2[256]; radix_sort_128x_exact(w, w + n_u, h2, t2); }
 		// output offsets of the chains in their final order, stashed in u2 (low 32 bits) next to the chain word
 		kk = 0;
 		for (i = 0; i < n_u; ++i) { const int32_t j = (int32_t)w[i].y; u2[i] = u[j]; w[i].x = (uint64_t)kk; kk += (int32_t)u[j]; }
