@@ -320,7 +320,7 @@ size_t dp_slab_bytes(int qlen, int tlen, int w)
 	size_t n_col = (size_t)(qlen < tlen ? qlen : tlen);
 	n_col = (((n_col < (size_t)w + 1 ? n_col : (size_t)w + 1) + 15) / 16 + 1) * 16;
 	size_t b = 0;
-	if (tlen16 > LDS_T) b += ((7 * tlen16 + 15) & ~(size_t)15) + 4 * tlen16;
+	if (tlen16 > LDS_T) b += ((7 * tlen16 + 15) & ~(size_t)15) + 4 * tlen16;   // only the single-wave fallback kernel keeps rows here
 	b += (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15);
 	b += 4 * ((size_t)qlen + tlen + 8);
 	return (b + 255) & ~(size_t)255;
@@ -329,15 +329,23 @@ size_t dp_slab_bytes(int qlen, int tlen, int w)
 void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
+void launch_extd2_wide(unsigned n_blocks, int t_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+                       DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
+
 // Problem classes (each is one persistent launch):
 //   0,1  register-resident kernel (pga_ksw_fast.hip), target <= 256 / <= 512 lanes, band never binding
-//   2    general kernel, LDS rows, small HBM slab          3    general kernel, rows in the HBM slab (wide targets)
+//   2,3  workgroup kernel with LDS rows (pga_ksw_wide.hip), target <= 2048 / <= 10240 columns
+//   4    single-wave kernel with rows in the HBM slab (targets wider than LDS can hold; not reached by pangraph's windows)
+#define DP_NCLASS 5
 static int dp_class(const DpJob &j, size_t need)
 {
+	(void)need;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
-	return need <= ((size_t)1 << 20) ? 2 : 3;
+	if (j.tlen <= 2048) return 2;
+	if (j.tlen <= 10240) return 3;
+	return 4;
 }
 
 void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st, Timers *tm)
@@ -345,8 +353,8 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
 	if (n == 0) return;
-	std::vector<uint32_t> cls[4];
-	size_t slab_max[4] = {0, 0, 0, 0};
+	std::vector<uint32_t> cls[DP_NCLASS];
+	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0};
 	std::vector<size_t> need(n);
 	unsigned long long cig_total = 0;
 	for (size_t i = 0; i < n; ++i) {
@@ -359,7 +367,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total);
 	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
-	for (int c = 0; c < 4; ++c) {
+	for (int c = 0; c < DP_NCLASS; ++c) {
 		if (cls[c].empty()) continue;
 		std::vector<uint32_t> &ids = cls[c];
 		// biggest problems first: the persistent waves then finish together
@@ -369,7 +377,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		DBuf<DpJob> d_jobs; d_jobs.upload(jb, st);
 		DBuf<DpRes> d_r(ids.size());
 		DBuf<uint32_t> d_cnt(1); d_cnt.zero(st);
-		size_t n_waves = c == 3 ? 256 * 2 : c == 2 ? 256 * 7 : 256 * 16;
+		size_t n_waves = c == 4 ? 256 * 2 : c == 3 ? 256 : c == 2 ? 256 * 4 : 256 * 16;
 		if (n_waves > ids.size()) n_waves = ids.size();
 		const size_t budget = (size_t)32 << 30;
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
@@ -377,7 +385,11 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launching dp class %d: %zu problems on %zu waves, slab %zu B\n", c, ids.size(), n_waves, slab_max[c]); fflush(stderr); }
 		EventTimer et(st);
 		if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)n_waves, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
-		else hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
+		else if (c <= 3) {
+			int tmax = 0; bool exact = false;
+			for (uint32_t id : ids) { tmax = std::max(tmax, (jobs[id].tlen + 15) / 16 * 16); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
+			launch_extd2_wide((unsigned)n_waves, tmax, exact, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
+		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
 		                        d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launched\n"); fflush(stderr); }

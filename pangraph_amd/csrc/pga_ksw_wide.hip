@@ -1,0 +1,309 @@
+// pga_ksw_wide.hip -- kernel #5b: the dual-affine DP for WIDE or BANDED problems (end extensions up to
+// max_gap x max_gap with band 1.5*bw, second exact passes, long-join segments): everything pga_ksw_fast.hip
+// does not take.  Same per-lane int8 recurrence and the same 16-lane rounding / stale-profile behaviour as
+// ksw2_extd2_sse.c:131-386 (see pga_ksw.hip), laid out for a 256-thread workgroup:
+//   * all rows live in LDS (dynamic, 10 B/column + 4 B/column of H in exact mode, up to 10240 columns = 143 KB):
+//     one workgroup per CU for the widest problems, several for narrow ones;
+//   * x, v and x2 -- the rows a cell reads at t-1 -- are double-buffered by diagonal parity, so the four waves
+//     sweep a diagonal's band in parallel without a read/write hazard.  Band ranges only move right, so a
+//     column that enters the band was never computed before and both buffers still hold its initial value:
+//     the stale-lane semantics of the reference are preserved;
+//   * 3 workgroup barriers per diagonal (5 in exact-max mode); the exact maximum with the reference's tie order
+//     is a wave reduction + 4 LDS partials;
+//   * wave 0 walks the direction matrix back through a 64x64 LDS window (fences only, as in the fast kernel).
+#include "pga_common.h"
+#include "pga_dp.h"
+
+namespace pga {
+
+#define KSW_NEG_INF (-0x40000000)
+#define EZ_RIGHT      0x02
+#define EZ_APPROX_MAX 0x08
+#define EZ_APPROX_DROP 0x10
+#define EZ_EXTZ_ONLY  0x40
+#define EZ_REV_CIGAR  0x80
+#define WIDE_NT 256
+#define WBT 64
+
+__device__ __forceinline__ int sx8w(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
+
+__device__ __forceinline__ void diag_range_w(int r, int qlen, int tlen, int w, int &st0, int &en0)
+{
+	int st = 0, en = tlen - 1;
+	if (st < r - qlen + 1) st = r - qlen + 1;
+	if (en > r) en = r;
+	if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+	if (en > (r + w) >> 1) en = (r + w) >> 1;
+	st0 = st, en0 = en;
+}
+
+__global__ __launch_bounds__(WIDE_NT)
+void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+                  uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes, int t_cap,
+                  DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
+{
+	extern __shared__ __align__(16) uint8_t dyn[];
+	__shared__ uint32_t s_job;
+	__shared__ long long s_part[WIDE_NT / 64];
+	__shared__ uint8_t s_win[WBT * WBT];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint8_t *slab = slab_all + (size_t)blockIdx.x * slab_bytes;
+	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+	const int qe_h = q + e;
+	if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t, t = e, e = e2, e2 = t; }
+	const int qe = q + e, qe2 = q2 + e2;
+	const int sc_mch = P.sc_mch, sc_mis = P.sc_mis, sc_N = P.sc_ambi == 0 ? -e2 : P.sc_ambi;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+	for (;;) {
+		__syncthreads();
+		if (tid == 0) s_job = atomicAdd(job_counter, 1u);
+		__syncthreads();
+		const uint32_t jid = s_job;
+		if (jid >= n_jobs) break;
+		const DpJob J = jobs[jid];
+		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
+		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
+		const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
+		int w = J.w;
+		if (w < 0) w = tlen > qlen ? tlen : qlen;
+		const int T = (tlen + 15) / 16 * 16;
+		int n_col = qlen < tlen ? qlen : tlen;
+		n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
+		auto target_at = [&](int i) -> int { return i < tlen ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 0; };
+		auto query_at = [&](int j) -> int {
+			if (j < 0 || j >= qlen) return 0;
+			int pj = J.qs + (J.seq_rev ? qlen - 1 - j : j);
+			if (!J.q_rev) return q_base[pj];
+			int c = q_base[J.qlen_full - 1 - pj];
+			return c < 4 ? 3 - c : 4;
+		};
+		// LDS rows (T <= t_cap is guaranteed by the launcher)
+		int8_t *u = (int8_t*)dyn, *y = u + t_cap, *y2 = y + t_cap, *s = y2 + t_cap;
+		int8_t *xb[2] = { s + t_cap, s + 2 * t_cap }, *vb[2] = { s + 3 * t_cap, s + 4 * t_cap }, *x2b[2] = { s + 5 * t_cap, s + 6 * t_cap };
+		int32_t *H = (int32_t*)(s + 7 * t_cap);
+		uint8_t *pmat = slab;
+		uint32_t *cig_tmp = (uint32_t*)(pmat + (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15));
+		for (int t = tid; t < T; t += WIDE_NT) {
+			u[t] = y[t] = (int8_t)(-q - e); y2[t] = (int8_t)(-q2 - e2); s[t] = 0;
+			xb[0][t] = xb[1][t] = vb[0][t] = vb[1][t] = (int8_t)(-q - e);
+			x2b[0][t] = x2b[1][t] = (int8_t)(-q2 - e2);
+			if (!approx_max) H[t] = KSW_NEG_INF;
+		}
+		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
+		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
+		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
+		const int n_diag = qlen + tlen - 1;
+		__syncthreads();
+
+		for (int r = 0; r < n_diag; ++r) {
+			int st0, en0;
+			diag_range_w(r, qlen, tlen, w, st0, en0);
+			if (st0 > en0) { ez_zdropped = 1; break; }
+			const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+			const int8_t *xr = xb[r & 1], *vr = vb[r & 1], *x2r = x2b[r & 1];
+			int8_t *xw = xb[(r + 1) & 1], *vw = vb[(r + 1) & 1], *x2w = x2b[(r + 1) & 1];
+			int x1, x21, v1;
+			if (st > 0) {
+				if (st - 1 >= last_st && st - 1 <= last_en) x1 = xr[st - 1], x21 = x2r[st - 1], v1 = vr[st - 1];
+				else x1 = sx8w(-q - e), x21 = sx8w(-q2 - e2), v1 = sx8w(-q - e);
+			} else {
+				x1 = sx8w(-q - e), x21 = sx8w(-q2 - e2);
+				v1 = r == 0 ? sx8w(-q - e) : r < long_thres ? sx8w(-e) : r == long_thres ? sx8w(long_diff) : sx8w(-e2);
+			}
+			if (en >= r && tid == 0) {
+				y[r] = (int8_t)(-q - e), y2[r] = (int8_t)(-q2 - e2);
+				u[r] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+			}
+			{
+				const int span = ((en0 - st0) / 16 + 1) * 16;
+				for (int o = tid; o < span; o += WIDE_NT) {
+					const int t = st0 + o;
+					if (t < T) {
+						const int a = target_at(t), b = query_at(r - t);
+						int sc = a == b ? sc_mch : sc_mis;
+						if (a == 4 || b == 4) sc = sc_N;
+						s[t] = (int8_t)sc;
+					}
+				}
+			}
+			__syncthreads();
+			uint8_t *prow = pmat + (size_t)r * n_col - st;
+			for (int t = st + tid; t <= en; t += WIDE_NT) {
+				const int xt1 = t == st ? x1 : (int)xr[t - 1], vt1 = t == st ? v1 : (int)vr[t - 1], x2t1 = t == st ? x21 : (int)x2r[t - 1];
+				const int ut = u[t], yo = y[t], y2o = y2[t];
+				int z = s[t];
+				int a = sx8w(xt1 + vt1), b = sx8w(yo + ut), a2 = sx8w(x2t1 + vt1), b2 = sx8w(y2o + ut), d;
+				if (!right) {
+					d = 0;
+					if (a > z) d = 1, z = a;
+					if (b > z) d = 2, z = b;
+					if (a2 > z) d = 3, z = a2;
+					if (b2 > z) d = 4, z = b2;
+				} else {
+					d = z > a ? 0 : 1;  z = z > a ? z : a;
+					d = z > b ? d : 2;  z = z > b ? z : b;
+					d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+					d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+				}
+				if (sc_mch < z) z = sc_mch;
+				u[t] = (int8_t)(z - vt1), vw[t] = (int8_t)(z - ut);
+				int tmp = sx8w(z - q); a = sx8w(a - tmp), b = sx8w(b - tmp);
+				tmp = sx8w(z - q2); a2 = sx8w(a2 - tmp), b2 = sx8w(b2 - tmp);
+				if (!right) {
+					xw[t]  = (int8_t)((a  > 0 ? a  : 0) - qe);  if (a  > 0) d |= 0x08;
+					y[t]   = (int8_t)((b  > 0 ? b  : 0) - qe);  if (b  > 0) d |= 0x10;
+					x2w[t] = (int8_t)((a2 > 0 ? a2 : 0) - qe2); if (a2 > 0) d |= 0x20;
+					y2[t]  = (int8_t)((b2 > 0 ? b2 : 0) - qe2); if (b2 > 0) d |= 0x40;
+				} else {
+					xw[t]  = (int8_t)((0 > a  ? 0 : a)  - qe);  if (!(0 > a))  d |= 0x08;
+					y[t]   = (int8_t)((0 > b  ? 0 : b)  - qe);  if (!(0 > b))  d |= 0x10;
+					x2w[t] = (int8_t)((0 > a2 ? 0 : a2) - qe2); if (!(0 > a2)) d |= 0x20;
+					y2[t]  = (int8_t)((0 > b2 ? 0 : b2) - qe2); if (!(0 > b2)) d |= 0x40;
+				}
+				prow[t] = (uint8_t)d;
+			}
+			__syncthreads();
+			bool stop = false;
+			if (!approx_max) {
+				int max_H, max_t;
+				if (r > 0) {
+					const int Hen = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + vw[en0];
+					__syncthreads();
+					const int en1 = st0 + (en0 - st0) / 4 * 4;
+					long long best = ((long long)Hen << 32) | 0xffffffffu;
+					for (int t = st0 + tid; t < en0; t += WIDE_NT) {
+						const int h = H[t] + vw[t];
+						H[t] = h;
+						const unsigned ord = t < en1 ? 1u + ((unsigned)((t - st0) & 3) << 28) + (unsigned)t : 1u + (4u << 28) + (unsigned)t;
+						const long long key = ((long long)h << 32) | (0xffffffffu - ord);
+						best = key > best ? key : best;
+					}
+					if (tid == 0) H[en0] = Hen;
+#pragma unroll
+					for (int dd = 32; dd >= 1; dd >>= 1) {
+						int lo = __shfl_xor((int)(best & 0xffffffffLL), dd), hi = __shfl_xor((int)(best >> 32), dd);
+						long long o = ((long long)hi << 32) | (unsigned int)lo;
+						best = o > best ? o : best;
+					}
+					if (lane == 0) s_part[wave] = best;
+					__syncthreads();
+#pragma unroll
+					for (int k = 0; k < WIDE_NT / 64; ++k) { const long long o = s_part[k]; best = o > best ? o : best; }
+					max_H = (int)(best >> 32);
+					const unsigned ord = 0xffffffffu - (unsigned)(best & 0xffffffffLL);
+					max_t = ord == 0 ? en0 : (int)((ord - 1) & 0x0fffffffu);
+				} else {
+					if (tid == 0) H[0] = vw[0] - qe_h;
+					__syncthreads();
+					max_H = H[0], max_t = 0;
+				}
+				if (en0 == tlen - 1) { const int h = H[en0]; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
+				if (r - st0 == qlen - 1) { const int h = H[st0]; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+				if (max_H > ez_max) ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+				else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+					if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
+				}
+				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = H[tlen - 1];
+			} else {
+				if (r > 0) {
+					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+						const int d0 = vw[last_H0_t], d1 = u[last_H0_t + 1];
+						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += vw[last_H0_t];
+					else ++last_H0_t, H0 += u[last_H0_t];
+				} else H0 = vw[0] - qe_h, last_H0_t = 0;
+				if (flag & EZ_APPROX_DROP) {
+					if (H0 > ez_max) ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
+					else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
+						const int tl = last_H0_t - ez_max_t, ql = (r - last_H0_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+						if (zdrop >= 0 && ez_max - H0 > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
+					}
+				}
+				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = H0;
+			}
+			if (stop) break;
+			last_st = st, last_en = en;
+			__syncthreads();       // the H / profile reads of this diagonal are done before the next one rewrites them
+		}
+
+		// ---- backtrack by wave 0 (ksw2.h:127-159), LDS window, fences only ----
+		int n_cigar = 0, bi = -1, bj = -1;
+		if (!ez_zdropped && !(flag & EZ_EXTZ_ONLY)) bi = tlen - 1, bj = qlen - 1;
+		else if (!ez_zdropped && (flag & EZ_EXTZ_ONLY) && ez_mqe + end_bonus > ez_max) ez_reach_end = 1, bi = ez_mqe_t, bj = qlen - 1;
+		else if (ez_max_t >= 0 && ez_max_q >= 0) bi = ez_max_t, bj = ez_max_q;
+		__threadfence_block();
+		__syncthreads();
+		if (wave == 0) {
+			int i = bi, j = bj, state = 0; long long guard = 0;
+			uint32_t last_op = 0xffffffffu;
+			while (i >= 0 && j >= 0) {
+				if (++guard > 4000000) { n_cigar = -7; break; }
+				const int r_hi = i + j, c_lo = i - (WBT - 1);
+				for (int row = 0; row < WBT; ++row) {
+					const int r = r_hi - row, col = c_lo + lane;
+					uint8_t val = 0;
+					if (r >= 0 && col >= 0) {
+						int st0, en0; diag_range_w(r, qlen, tlen, w, st0, en0);
+						const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
+						if (st0 <= en0 && col >= off && col <= off_end) val = pmat[(size_t)r * n_col + (col - off)];
+					}
+					s_win[row * WBT + lane] = val;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				while (i >= 0 && j >= 0) {
+					const int r = i + j, row = r_hi - r;
+					if (row >= WBT || i < c_lo) break;
+					int st0, en0; diag_range_w(r, qlen, tlen, w, st0, en0);
+					const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
+					int force_state = -1;
+					if (i < off) force_state = 2;
+					if (i > off_end) force_state = 1;
+					const uint32_t tmp = force_state < 0 ? s_win[row * WBT + (i - c_lo)] : 0;
+					if (state == 0) state = tmp & 7;
+					else if (!(tmp >> (state + 2) & 1)) state = 0;
+					if (state == 0) state = tmp & 7;
+					if (force_state >= 0) state = force_state;
+					uint32_t op;
+					if (state == 0) op = 0, --i, --j;
+					else if (state == 1 || state == 3) op = 2, --i;
+					else op = 1, --j;
+					if (op != last_op) { if (lane == 0) cig_tmp[n_cigar] = 1u << 4 | op; ++n_cigar; last_op = op; }
+					else if (lane == 0) cig_tmp[n_cigar - 1] += 1u << 4;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			}
+			if (bi >= 0 && bj >= 0 && n_cigar >= 0) {
+				if (i >= 0) { if (2u != last_op) { if (lane == 0) cig_tmp[n_cigar] = (uint32_t)(i + 1) << 4 | 2u; ++n_cigar; last_op = 2; } else if (lane == 0) cig_tmp[n_cigar - 1] += (uint32_t)(i + 1) << 4; }
+				if (j >= 0) { if (1u != last_op) { if (lane == 0) cig_tmp[n_cigar] = (uint32_t)(j + 1) << 4 | 1u; ++n_cigar; last_op = 1; } else if (lane == 0) cig_tmp[n_cigar - 1] += (uint32_t)(j + 1) << 4; }
+			}
+			unsigned long long base = 0;
+			if (lane == 0 && n_cigar > 0) base = atomicAdd(pool_cursor, (unsigned long long)n_cigar);
+			base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), 0) << 32) | (unsigned)__shfl((int)(base & 0xffffffffULL), 0);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			const bool rev_cigar = flag & EZ_REV_CIGAR;
+			if (n_cigar > 0 && base + (unsigned long long)n_cigar <= pool_cap)
+				for (int c = lane; c < n_cigar; c += 64) cigar_pool[base + c] = rev_cigar ? cig_tmp[c] : cig_tmp[n_cigar - 1 - c];
+			if (lane == 0) {
+				DpRes R;
+				R.max = ez_max, R.max_q = ez_max_q, R.max_t = ez_max_t, R.mqe = ez_mqe, R.mqe_t = ez_mqe_t, R.mte = ez_mte, R.mte_q = ez_mte_q;
+				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = n_cigar, R.pad = 0, R.cigar_off = base;
+				res[jid] = R;
+			}
+		}
+	}
+}
+
+void launch_extd2_wide(unsigned n_blocks, int t_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+                       DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
+{
+	const size_t lds = (size_t)t_cap * 10 + (exact ? (size_t)t_cap * 4 : 0);
+	static bool attr_set = false;
+	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+	hipLaunchKernelGGL(k_extd2_wide, dim3(n_blocks), dim3(WIDE_NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, t_cap, res, pool, cursor, pool_cap);
+}
+
+} // namespace pga
