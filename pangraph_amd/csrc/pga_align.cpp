@@ -17,6 +17,7 @@
 #include <thread>
 #include <atomic>
 #include <cassert>
+#include <list>
 #include <chrono>
 #include <cstdio>
 
@@ -538,7 +539,7 @@ struct QueryCtx {
 	int rep_len = 0;
 	bool finished = false;
 	// DP problems of this query (ids are per query; filled between the threaded phases)
-	std::vector<DpJob> jobs; std::vector<DpRes> res; std::vector<std::vector<uint32_t>> cig; std::vector<int> pending;
+	std::vector<DpJob> jobs; std::vector<DpRes> res; std::vector<const uint32_t*> cig; std::vector<int> pending;   // cig[id] points into a per-round CIGAR pool
 };
 
 struct Driver {
@@ -561,7 +562,7 @@ struct Driver {
 		r.max_q = r.max_t = r.mqe_t = r.mte_q = -1; r.score = r.mqe = r.mte = NEG_INF;
 		if (opt.max_sw_mat > 0 && (int64_t)tlen * qlen > opt.max_sw_mat) { r.zdropped = 1; r.pad = 1; }
 		else if (qlen <= 0 || tlen <= 0) r.pad = 1;
-		Q.res.push_back(r); Q.cig.emplace_back();
+		Q.res.push_back(r); Q.cig.push_back(nullptr);
 		if (!r.pad) Q.pending.push_back(id);
 		return id;
 	}
@@ -664,7 +665,7 @@ struct Driver {
 		if (!T.left_done) {
 			if (!have(Q, T.left_job)) return false;
 			const DpRes &ez = Q.res[T.left_job];
-			if (ez.n_cigar > 0) { cigar_append(r, (uint32_t)ez.n_cigar, Q.cig[T.left_job].data()); r.dp_score += ez.max; }
+			if (ez.n_cigar > 0) { cigar_append(r, (uint32_t)ez.n_cigar, Q.cig[T.left_job]); r.dp_score += ez.max; }
 			T.rs1 = T.rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
 			T.qs1 = T.qs - (ez.reach_end ? T.qs - T.qs0 : ez.max_q + 1);
 			T.left_done = true;
@@ -679,12 +680,12 @@ struct Driver {
 			if (sg.zcode < 0) {
 				acc.query(Q.qid, T.rev, sg.qs, sg.qe, qw); acc.target(Q.base + T.rid, sg.rs, sg.re, tw);
 				const DpRes &e1 = Q.res[sg.job1];
-				sg.zcode = test_zdrop(opt, qw.data(), tw.data(), (uint32_t)e1.n_cigar, Q.cig[sg.job1].data(), mat);
+				sg.zcode = test_zdrop(opt, qw.data(), tw.data(), (uint32_t)e1.n_cigar, Q.cig[sg.job1], mat);
 				if (sg.zcode != 0) sg.job2 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, sg.zcode == 2 ? opt.zdrop_inv : opt.zdrop, 0);
 			}
 			if (sg.zcode != 0) { if (!have(Q, sg.job2)) return false; final_job = sg.job2; }
 			const DpRes &ez = Q.res[final_job];
-			if (ez.n_cigar > 0) cigar_append(r, (uint32_t)ez.n_cigar, Q.cig[final_job].data());
+			if (ez.n_cigar > 0) cigar_append(r, (uint32_t)ez.n_cigar, Q.cig[final_job]);
 			if (ez.zdropped) {
 				r.has_p = true;
 				int j;
@@ -704,7 +705,7 @@ struct Driver {
 		if (!T.dropped && T.qe < T.qe0 && T.re < T.re0) {
 			if (!have(Q, T.right_job)) return false;
 			const DpRes &ez = Q.res[T.right_job];
-			if (ez.n_cigar > 0) { cigar_append(r, (uint32_t)ez.n_cigar, Q.cig[T.right_job].data()); r.dp_score += ez.max; }
+			if (ez.n_cigar > 0) { cigar_append(r, (uint32_t)ez.n_cigar, Q.cig[T.right_job]); r.dp_score += ez.max; }
 			T.re1 = T.re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
 			T.qe1 = T.qe + (ez.reach_end ? T.qe0 - T.qe : ez.max_q + 1);
 		}
@@ -752,7 +753,7 @@ struct Driver {
 			const DpRes &ez = Q.res[T.inv_job];
 			if (ez.n_cigar == 0) return 0;
 			r_inv = Reg();
-			cigar_append(r_inv, (uint32_t)ez.n_cigar, Q.cig[T.inv_job].data());
+			cigar_append(r_inv, (uint32_t)ez.n_cigar, Q.cig[T.inv_job]);
 			r_inv.dp_score = ez.max;
 			r_inv.id = -1, r_inv.parent = -1, r_inv.inv = 1, r_inv.rev = !r1.rev, r_inv.rid = r1.rid;
 			const int q_off = T.inv_q_off, t_off = T.inv_t_off;
@@ -840,6 +841,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
                  std::vector<std::vector<Reg>> &out, int n_threads, Timers *tm, hipStream_t st)
 {
 	const int n_seq = S.n_seq;
+	const double t_align0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	out.assign((size_t)n_seq, {});
 	Driver D(S, opt, k);
 	std::vector<QueryCtx> Q((size_t)n_seq);
@@ -861,29 +863,42 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 		q.n_a = squeeze_a(q.list, q.a);
 		for (RegTask *t : q.list) D.plan(q, *t);
 	});
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   align: regions+plans %.3f s (%d threads)\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_align0, n_threads);
 	// ---- rounds ----
 	if (opt.flag & MM_F_CIGAR) {
 		DpParams P{opt.q, opt.e, opt.q2, opt.e2, D.mat[0], D.mat[1], D.mat[24]};
 		size_t n_requested = 0;
+		std::list<std::vector<uint32_t>> pools;
 		for (int round = 0; round < 100000; ++round) {
 			// run what was requested
 			{
+				size_t n_pend = 0;
+				for (int qi = 0; qi < n_seq; ++qi) n_pend += Q[qi].pending.size();
 				std::vector<DpJob> jb; std::vector<std::pair<int,int>> owner;
+				jb.reserve(n_pend); owner.reserve(n_pend);
 				for (int qi = 0; qi < n_seq; ++qi) { for (int id : Q[qi].pending) { jb.push_back(Q[qi].jobs[id]); owner.emplace_back(qi, id); } Q[qi].pending.clear(); }
 				n_requested = jb.size();
 				if (!jb.empty()) {
-					std::vector<DpRes> rs; std::vector<uint32_t> cg;
+					std::vector<DpRes> rs;
+					pools.emplace_back();
+					std::vector<uint32_t> &cg = pools.back();          // stays alive until the batch is done: results point into it
 					double t_dp = getenv("PGA_VERBOSE") ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
 					dp_run(S.d_nt4.p, jb, P, rs, cg, st, tm);
 					if (t_dp > 0) fprintf(stderr, "[pga]   round %d: %zu DP problems in %.3f s\n", round, jb.size(), std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dp);
 					if (tm) { tm->dp_jobs += (double)jb.size(); for (auto &j : jb) tm->dp_cells += (double)j.qlen * j.tlen; }
-					for (size_t i = 0; i < rs.size(); ++i) {
-						QueryCtx &q = Q[owner[i].first]; const int id = owner[i].second;
-						q.res[id] = rs[i]; q.res[id].pad = 1;
-						q.cig[id].assign(cg.begin() + rs[i].cigar_off, cg.begin() + rs[i].cigar_off + rs[i].n_cigar);
-					}
+					const uint32_t *base = cg.data();
+					parallel_for((rs.size() + 65535) / 65536, n_threads, [&](size_t blk) {
+						const size_t lo = blk * 65536, hi = std::min(rs.size(), lo + 65536);
+						for (size_t i = lo; i < hi; ++i) {
+							QueryCtx &q = Q[owner[i].first]; const int id = owner[i].second;
+							if (rs[i].n_cigar < 0) throw std::runtime_error("pga: DP backtrack did not terminate");
+							q.res[id] = rs[i]; q.res[id].pad = 1;
+							q.cig[id] = base + rs[i].cigar_off;
+						}
+					});
 				}
 			}
+			const double t_adv0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 			std::atomic<int> unfinished(0);
 			parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
 				QueryCtx &q = Q[qi];
@@ -924,6 +939,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 				out[qi] = std::move(regs);
 				q.finished = true; q.pool.clear(); q.list.clear(); q.a.clear(); q.a.shrink_to_fit();
 			});
+			if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   round %d: host advance %.3f s\n", round, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_adv0);
 			if (unfinished.load() == 0) break;
 			bool any_pending = false; for (auto &q : Q) any_pending |= !q.pending.empty();
 			if (!any_pending) throw std::runtime_error("pga: alignment driver stalled");

@@ -362,7 +362,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		const int c = dp_class(jobs[i], need[i]);
 		cls[c].push_back((uint32_t)i);
 		if (need[i] > slab_max[c]) slab_max[c] = need[i];
-		cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;
+		cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
 	}
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total);
@@ -370,8 +370,10 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	for (int c = 0; c < DP_NCLASS; ++c) {
 		if (cls[c].empty()) continue;
 		std::vector<uint32_t> &ids = cls[c];
-		// biggest problems first: the persistent waves then finish together
-		std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
+		// biggest problems first, so that the persistent waves finish together (the many small tiles of the
+		// register-resident classes are uniform enough to skip the sort)
+		if (c >= 2 || ids.size() < 100000)
+			std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
 		std::vector<DpJob> jb(ids.size());
 		for (size_t i = 0; i < ids.size(); ++i) jb[i] = jobs[ids[i]];
 		DBuf<DpJob> d_jobs; d_jobs.upload(jb, st);
