@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=int(os.environ.get("PGA_BENCH_GENOMES", 32)), help="genomes PER GPU at the leaf level")
+    ap.add_argument("--genomes", type=int, default=int(os.environ.get("PGA_BENCH_GENOMES", 128)), help="genomes PER GPU at the leaf level")
     ap.add_argument("--length", type=int, default=int(os.environ.get("PGA_BENCH_LENGTH", 5_000_000)))
     ap.add_argument("--divergence", type=float, default=0.01)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 disables)")
