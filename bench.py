@@ -42,6 +42,18 @@ def make_groups(seed: int, n_genomes: int, length: int, div: float):
     return groups, names
 
 
+def usable_cpus() -> int:
+    """CPUs this process can really use: affinity mask capped by the cgroup v2 quota (the GPU box shows 256 but grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _cpu_worker(args):
     so, seqs, names = args
     from pangraph_amd.mm2ffi import Mm2Lib
@@ -58,7 +70,7 @@ def cpu_baseline(groups, names, budget_s: float):
     kind = "reference"
     if not os.path.exists(so):
         so, kind = os.path.join(ROOT, "oracle", "libpgoracle.so"), "port"
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     n = min(cores, len(groups))
     # calibrate on one group, then size the sample to the budget
     t1, b1, _ = _cpu_worker((so, groups[0], names[0]))

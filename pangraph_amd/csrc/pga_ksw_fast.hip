@@ -37,9 +37,6 @@ __device__ __forceinline__ long long wave_max64f(long long v)
 	return v;
 }
 
-#ifndef PGA_DBG
-#define PGA_DBG 0
-#endif
 #define BT_ROWS 64
 #define BT_COLS 64
 
@@ -68,7 +65,6 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		jid = (uint32_t)__shfl((int)jid, 0);
 		if (jid >= n_jobs) break;
 		const DpJob J = jobs[jid];
-		if (PGA_DBG && lane == 0) printf("[fast] job %u q=%d t=%d w=%d flag=%d\n", jid, J.qlen, J.tlen, J.w, J.flag);
 		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
 		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
 		const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
@@ -244,7 +240,6 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			}
 		}
 
-		if (PGA_DBG && lane == 0) printf("[fast] fwd done score=%d max=%d zd=%d\n", ez_score, ez_max, ez_zdropped);
 		// ---- backtrack (ksw2.h:127-159): lane 0 walks an LDS window refilled by the whole wave ----
 		int n_cigar = 0, bi = -1, bj = -1;
 		if (!ez_zdropped && !(flag & EZ_EXTZ_ONLY)) bi = tlen - 1, bj = qlen - 1;
@@ -297,7 +292,6 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 				if (j >= 0) { if (1u != last_op) { if (lane == 0) cig[n_cigar] = (uint32_t)(j + 1) << 4 | 1u; ++n_cigar; last_op = 1; } else if (lane == 0) cig[n_cigar - 1] += (uint32_t)(j + 1) << 4; }
 			}
 		}
-		if (PGA_DBG && lane == 0) printf("[fast] bt done n_cigar=%d\n", n_cigar);
 		unsigned long long base = 0;
 		if (lane == 0 && n_cigar > 0) base = atomicAdd(pool_cursor, (unsigned long long)n_cigar);
 		base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), 0) << 32) | (unsigned)__shfl((int)(base & 0xffffffffULL), 0);

@@ -19,6 +19,11 @@
 // and w+k <= 64; any other (w,k) runs the serial kernel at the bottom (one lane per sequence), exact for
 // all inputs, slow, and never hit by pangraph's presets except through -K with an even k.
 #include "pga_common.h"
+#include <sched.h>
+#include <unistd.h>
+#include <atomic>
+#include <thread>
+#include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 namespace pga {
@@ -35,36 +40,24 @@ __device__ __forceinline__ uint64_t hash64(uint64_t key, uint64_t mask) // sketc
 	return key;
 }
 
-__global__ void k_ascii_to_nt4(uint8_t *s, uint64_t n)
+int usable_cpus()
 {
-	// sketch.c:9-26: A/a=0 C/c=1 G/g=2 T/t/U/u=3, everything else 4.  16 bytes per lane per iteration.
-	uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16, stride = (uint64_t)gridDim.x * blockDim.x * 16;
-	for (; i < n; i += stride) {
-		if (i + 16 <= n) {
-			uint4 v = *reinterpret_cast<const uint4*>(s + i);
-			uint32_t in[4] = {v.x, v.y, v.z, v.w}, out[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				uint32_t o = 0;
-#pragma unroll
-				for (int b = 0; b < 4; ++b) {
-					uint32_t c = (in[j] >> (8 * b)) & 0xdf; // fold case
-					uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
-					if (((in[j] >> (8 * b)) & 0xff) < 0x40) code = 4; // digits/punctuation that fold onto letters
-					o |= code << (8 * b);
-				}
-				out[j] = o;
-			}
-			*reinterpret_cast<uint4*>(s + i) = make_uint4(out[0], out[1], out[2], out[3]);
-		} else {
-			for (uint64_t j = i; j < n; ++j) {
-				uint32_t r = s[j], c = r & 0xdf;
-				uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
-				if (r < 0x40) code = 4;
-				s[j] = (uint8_t)code;
-			}
-		}
+	// the smallest of: PGA_THREADS, the affinity mask, the online CPUs, the cgroup v2 CPU quota
+	if (const char *e = getenv("PGA_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+	int c = (int)std::thread::hardware_concurrency();
+	if (c <= 0) c = 1;
+	cpu_set_t set;
+	CPU_ZERO(&set);
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < c) c = a; }
+	const long onl = sysconf(_SC_NPROCESSORS_ONLN);
+	if (onl > 0 && onl < c) c = (int)onl;
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		long long quota = -1, period = -1;
+		char q[64];
+		if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { quota = atoll(q); const int lim = (int)((quota + period - 1) / period); if (lim > 0 && lim < c) c = lim; }
+		fclose(f);
 	}
+	return c;
 }
 
 static inline uint8_t nt4_host(uint8_t r)
@@ -82,11 +75,36 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	for (int i = 0; i < n; ++i) { S.off[i + 1] = S.off[i] + len[i]; S.name[i] = name && name[i] ? name[i] : ""; }
 	S.total = S.off[n];
 	// sequences are padded to a 16-byte multiple so the packing loads never straddle the allocation
-	S.h_nt4.assign(S.total + 64, 4);
-	for (int i = 0; i < n; ++i) {
-		const uint8_t *s = reinterpret_cast<const uint8_t*>(seq[i]);
-		uint8_t *d = S.h_nt4.data() + S.off[i];
-		for (uint32_t j = 0; j < len[i]; ++j) d[j] = nt4_host(s[j]);
+	S.h_nt4.resize(S.total + 64);
+	memset(S.h_nt4.data() + S.total, 4, 64);
+	{
+		uint8_t lut[256];
+		for (int c = 0; c < 256; ++c) lut[c] = nt4_host((uint8_t)c);
+		// byte ranges of ~4 MB over the concatenation, converted by the usable host cores
+		const uint64_t chunk = 4u << 20;
+		const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
+		std::atomic<uint64_t> next{0};
+		auto work = [&]() {
+			for (;;) {
+				const uint64_t c = next.fetch_add(1);
+				if (c >= n_chunks) break;
+				const uint64_t b = c * chunk, e = std::min<uint64_t>(S.total, b + chunk);
+				int i = (int)(std::upper_bound(S.off.begin(), S.off.end(), b) - S.off.begin()) - 1;
+				for (uint64_t p = b; p < e; ) {
+					while (S.off[i + 1] <= p) ++i;
+					const uint64_t stop = std::min<uint64_t>(e, S.off[i + 1]);
+					const uint8_t *src = reinterpret_cast<const uint8_t*>(seq[i]) + (p - S.off[i]);
+					uint8_t *d = S.h_nt4.data() + p;
+					for (uint64_t j = 0; j < stop - p; ++j) d[j] = lut[src[j]];
+					p = stop;
+				}
+			}
+		};
+		const int nt = (int)std::min<uint64_t>(n_chunks, (uint64_t)usable_cpus());
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(work);
+		work();
+		for (auto &t : th) t.join();
 	}
 	S.d_nt4.upload(S.h_nt4, st);
 	S.d_off.upload(S.off, st);
