@@ -524,39 +524,30 @@ __global__ void k_fix_pred(const uint64_t *__restrict__ seg_start, uint32_t n_se
 	pp[i] = (int32_t)(sb + (uint64_t)p - q_aoff[lo]);
 }
 
-__device__ inline int32_t bk_end(int32_t max_drop, const u128 *z, const int32_t *f, const int32_t *p, int32_t *t, int64_t k) // lchain.c:9-25
-{
-	int32_t i = (int32_t)z[k].y, end_i = -1, max_i = i, max_s = 0;
-	if (i < 0 || t[i] != 0) return i;
-	do {
-		int32_t s;
-		t[i] = 2;
-		end_i = i = p[i];
-		s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
-		if (s > max_s) max_s = s, max_i = i;
-		else if (max_s - s > max_drop) break;
-	} while (i >= 0 && t[i] == 0);
-	for (i = (int32_t)z[k].y; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
-	return max_i;
-}
+// The backtrack of lchain.c:27-111 for one query, by one WAVE.
+//   * candidate list, mark reset, chain copies: streaming, 64 lanes;
+//   * the unstable sort of the candidates: radix_sort_128x_wave (exact replay);
+//   * the walks along p[] (mg_chain_bk_end, lchain.c:9-25, and the collection loop lchain.c:72-76): sequential by
+//     definition, but a walk almost always steps to an anchor a few slots below, so the wave keeps p/f/t of 64
+//     consecutive anchors in registers (one coalesced load) and follows the links with readlane -- memory latency
+//     is paid once per window instead of once per step.  t[]==2 of the reference is never observable (p[i] < i, a
+//     walk cannot meet itself), so one walk records the path, finds the cut (max_i) and marks only the kept part.
+__device__ __forceinline__ int32_t rl(int32_t v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 
-// one WAVE per query: lchain.c:27-111.  Streaming passes (candidate list, mark reset, copies) use all 64 lanes;
-// the two inherently sequential walks -- the cycle-leader permutation of the unstable sort and the chain
-// backtrack -- run on lane 0.  Outputs u[] (score<<32|cnt) and the compacted anchors.
 __global__ __launch_bounds__(64)
 void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
                  const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, u128 *__restrict__ z_all,
                  uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
-                 ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out)
+                 ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out, unsigned long long *__restrict__ prof)
 {
 	__shared__ uint32_t head[256], tail[256];
-	__shared__ int64_t s_nz; __shared__ int32_t s_nu; __shared__ int64_t s_nv;
 	const int q = blockIdx.x, lane = threadIdx.x;
 	if (q >= n_seq) return;
 	const uint64_t b = q_aoff[q];
 	const int64_t n = (int64_t)(q_aoff[q + 1] - b);
 	if (lane == 0) n_u_out[q] = 0, n_v_out[q] = 0;
 	if (n == 0) return;
+	const unsigned long long c0 = wall_clock64();
 	const u128 *A = a + b; const int32_t *f = f_all + b, *p = p_all + b;
 	int32_t *t = t_all + b, *v = v_all + b;
 	u128 *z = z_all + b, *w = w_all + b, *out = out_all + b;
@@ -571,42 +562,90 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 		if (keep) { const int64_t o = n_z + __popcll(m & ((1ULL << lane) - 1)); z[o].x = (uint64_t)f[i]; z[o].y = (uint64_t)i; }
 		n_z += __popcll(m);
 	}
-	__threadfence_block();
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	if (n_z == 0) return;
 	radix_sort_128x_wave(z, n_z, head, tail, lane);
-	__threadfence_block();
-	if (lane == 0) {
-		int64_t k, i, n_v = 0; int32_t n_u = 0;
-		const int32_t max_drop = P.bw;
-		for (k = n_z - 1; k >= 0; --k) {
-			if (t[z[k].y] != 0) continue;
-			int64_t n_v0 = n_v; int32_t end_i, sc, ii;
-			end_i = bk_end(max_drop, z, f, p, t, k);
-			for (ii = (int32_t)z[k].y; ii != end_i; ii = p[ii]) v[n_v++] = ii, t[ii] = 1;
-			sc = ii < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[ii];
-			if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
-			else n_v = n_v0;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	const unsigned long long c1 = wall_clock64();
+	// ---- walks (every lane executes the same control flow) ----
+	const int32_t max_drop = P.bw;
+	int64_t n_v = 0; int32_t n_u = 0;
+	for (int64_t kb = n_z; kb > 0; kb -= 64) {
+		// a batch of 64 candidates, highest rank in lane 0
+		const int64_t k_mine = kb - 1 - lane;
+		int32_t zf = 0, zi = -1;
+		if (k_mine >= 0) { zf = (int32_t)z[k_mine].x; zi = (int32_t)z[k_mine].y; }
+		unsigned long long todo = __ballot(zi >= 0);
+		while (todo) {
+			// marks of the remaining candidates as of now (the previous chain may have covered some of them)
+			const bool open = zi >= 0 && ((todo >> lane) & 1) && t[zi] == 0;
+			todo = __ballot(open);
+			if (!todo) break;
+			const int src = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			const int32_t e0 = rl(zi, src), zx = rl(zf, src);
+			// walk
+			int32_t wb = e0 - 63; if (wb < 0) wb = 0;
+			int32_t wp = -1, wf = 0, wt = 1;
+			{ const int32_t idx = wb + lane; if (idx <= e0) wp = p[idx], wf = f[idx], wt = t[idx]; }
+			int32_t cur = e0, m = 0, kept = 0, max_s = 0, myv = 0;
+			const int64_t n_v0 = n_v;
+			for (;;) {
+				const int32_t nxt = rl(wp, cur - wb);
+				if ((m & 63) == lane) myv = cur;
+				++m;
+				if ((m & 63) == 0) v[n_v0 + m - 64 + lane] = myv;
+				int32_t sv, tn = 1;
+				if (nxt < 0) sv = zx;
+				else {
+					if (nxt < wb) {
+						wb = nxt - 63; if (wb < 0) wb = 0;
+						const int32_t idx = wb + lane;
+						wp = -1, wf = 0, wt = 1;
+						if (idx <= nxt) wp = p[idx], wf = f[idx], wt = t[idx];
+					}
+					sv = zx - rl(wf, nxt - wb);
+					tn = rl(wt, nxt - wb);
+				}
+				if (sv > max_s) max_s = sv, kept = m;
+				else if (max_s - sv > max_drop) break;
+				if (nxt < 0 || tn != 0) break;
+				cur = nxt;
+			}
+			if ((m & 63) != 0 && lane < (m & 63)) v[n_v0 + (m & ~63) + lane] = myv;
+			// kept part: the first `kept` path elements (the walk stops before max_i, lchain.c:72); marks stay even if the chain is dropped
+			for (int32_t c = lane; c < kept; c += 64) t[v[n_v0 + c]] = 1;
+			// score of the chain: z.x - f[max_i]; max_i is the path element number `kept` (or -1 past the root)
+			const int32_t sc = max_s;
+			if (kept > 0 && sc >= P.min_sc && kept >= P.min_cnt) { if (lane == 0) u[n_u] = (uint64_t)sc << 32 | (uint64_t)kept; ++n_u; n_v += kept; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		}
-		n_u_out[q] = n_u, n_v_out[q] = (int32_t)n_v;
-		// chains are ordered by the target position of their first anchor (compact_a, lchain.c:96-99)
-		int64_t kk = 0;
-		for (i = 0; i < n_u; ++i) { const int32_t ni = (int32_t)u[i]; w[i].x = A[v[kk + ni - 1]].x; w[i].y = (uint64_t)kk << 32 | (uint64_t)i; kk += ni; }
-		if (n_u > 0) { uint32_t h2[256], t2[256]; radix_sort_128x_exact(w, w + n_u, h2, t2); }
-		// output offsets of the chains in their final order, stashed in u2 (low 32 bits) next to the chain word
-		kk = 0;
-		for (i = 0; i < n_u; ++i) { const int32_t j = (int32_t)w[i].y; u2[i] = u[j]; w[i].x = (uint64_t)kk; kk += (int32_t)u[j]; }
-		s_nu = n_u, s_nv = n_v;
 	}
-	__threadfence_block();
-	__syncthreads();
-	const int32_t n_u = s_nu;
+	if (lane == 0) n_u_out[q] = n_u, n_v_out[q] = (int32_t)n_v;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	const unsigned long long c2 = wall_clock64();
+	// chains are ordered by the target position of their first anchor (compact_a, lchain.c:96-99)
+	if (lane == 0) {
+		int64_t kk = 0;
+		for (int32_t i = 0; i < n_u; ++i) { const int32_t ni = (int32_t)u[i]; w[i].x = A[v[kk + ni - 1]].x; w[i].y = (uint64_t)kk << 32 | (uint64_t)i; kk += ni; }
+		if (n_u > 0) { uint32_t h2[256], t2[256]; radix_sort_128x_exact(w, w + n_u, h2, t2); }
+		// output offsets of the chains in their final order, stashed in w.x next to the chain word
+		kk = 0;
+		for (int32_t i = 0; i < n_u; ++i) { const int32_t j = (int32_t)w[i].y; u2[i] = u[j]; w[i].x = (uint64_t)kk; kk += (int32_t)u[j]; }
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	// copy every chain, reversed to ascending anchor order, to its slot (all lanes)
 	for (int32_t c = 0; c < n_u; ++c) {
 		const int64_t src0 = (int64_t)(w[c].y >> 32), dst0 = (int64_t)w[c].x; const int32_t ni = (int32_t)u2[c];
 		for (int32_t m = lane; m < ni; m += 64) out[dst0 + m] = A[v[src0 + (ni - m - 1)]];
 	}
-	__syncthreads();
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	for (int32_t c = lane; c < n_u; c += 64) u[c] = u2[c];
+	if (prof && lane == 0) {
+		const unsigned long long c3 = wall_clock64();
+		atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2);
+		atomicMax(&prof[3], c1 - c0); atomicMax(&prof[4], c2 - c1); atomicMax(&prof[5], c3 - c2);
+	}
 }
 
 void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm)
@@ -682,8 +721,16 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
 	{
 		EventTimer et(st);
-		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p);
+		DBuf<unsigned long long> prof(8); prof.zero(st);
+		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
+		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
+		                   verbose ? prof.p : (unsigned long long*)nullptr);
 		const double ms = et.stop();
+		if (verbose) {
+			std::vector<unsigned long long> pr = prof.download(st);   // wall_clock64 ticks at 100 MHz
+			fprintf(stderr, "[pga]   backtrack: %.3f ms; per-query max (ms): list+sort %.2f, walks %.2f, compact %.2f; sums %.1f %.1f %.1f\n", ms,
+			        pr[3] * 1e-5, pr[4] * 1e-5, pr[5] * 1e-5, pr[0] * 1e-5, pr[1] * 1e-5, pr[2] * 1e-5);
+		}
 		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
 	}
 	PGA_HIP(hipGetLastError());
