@@ -230,20 +230,96 @@ struct Iter { int32_t stack[CMAXD]; int top; };
 // The inner scan of lchain.c:322-349 is evaluated without the t[] array: t[j]==i holds exactly when some
 // candidate visited earlier in the scan (one with a larger key, hence any candidate at all) has p[]==j and
 // passes the bandwidth test, so "marked" is a set-membership stamp; the n_skip walk itself stays sequential.
-#define CF_W 2048          // main-window ring capacity (anchors)
+#define CF_W 2048          // ring capacity (anchors): live window + the staged block
 #define CF_WI 512          // inner-window ring capacity
 #define CF_MAXIN 256       // inner candidates handled by the fast path
+#define CF_M (CF_W - 1)
 
+// lchain.c:232-248 on unpacked fields (segment-local: x is the 32-bit target position)
+__device__ __forceinline__ int32_t score_pair32(int32_t xi, int32_t yi, int32_t xj, int32_t yj, int32_t span_j, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)
+{
+	const int32_t dq = yi - yj, dr = xi - xj;
+	const int32_t dd = dr > dq ? dr - dq : dq - dr;
+	const int32_t dg = dr < dq ? dr : dq;
+	int32_t sc = span_j < dg ? span_j : dg;
+	*width = dd;
+	if (exact) *exact = (dd == 0 && dg <= span_j);
+	if (dd || dq > span_j) {
+		float lin_pen = __fadd_rn(__fmul_rn(pen_gap, (float)dd), __fmul_rn(pen_skip, (float)dg));
+		float log_pen = dd >= 1 ? mg_log2((float)(dd + 1)) : 0.0f;
+		sc -= (int)__fadd_rn(lin_pen, __fmul_rn(.5f, log_pen));
+	}
+	return sc;
+}
+
+// minimum of a double over the wave with DPP moves only (no LDS traffic); the result is uniform
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_min_step(double v)
+{
+	const long long b = __double_as_longlong(v);
+	const int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+	const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+	const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+	const double o = __longlong_as_double(((long long)ohi << 32) | (unsigned)olo);
+	return o < v ? o : v;
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+	v = dpp_min_step<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+	v = dpp_min_step<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+	v = dpp_min_step<0x141, 0xf>(v);     // row_half_mirror
+	v = dpp_min_step<0x140, 0xf>(v);     // row_mirror: every lane of a 16-lane row holds the row minimum
+	v = dpp_min_step<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
+	v = dpp_min_step<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave minimum
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+	return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// inclusive prefix maximum over the wave (lane order), DPP only
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int32_t dpp_max_step(int32_t v)
+{
+	const int32_t o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+	return o > v ? o : v;
+}
+__device__ __forceinline__ int32_t wave_prefix_max_incl(int32_t v)
+{
+	v = dpp_max_step<0x111, 0xf>(v);     // row_shr:1
+	v = dpp_max_step<0x112, 0xf>(v);     // row_shr:2
+	v = dpp_max_step<0x114, 0xf>(v);     // row_shr:4
+	v = dpp_max_step<0x118, 0xf>(v);     // row_shr:8
+	v = dpp_max_step<0x142, 0xa>(v);     // row_bcast15
+	v = dpp_max_step<0x143, 0xc>(v);     // row_bcast31
+	return v;
+}
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int32_t dpp_min_step_i(int32_t v)
+{
+	const int32_t o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+	return o < v ? o : v;
+}
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+	v = dpp_min_step_i<0xB1, 0xf>(v); v = dpp_min_step_i<0x4E, 0xf>(v); v = dpp_min_step_i<0x141, 0xf>(v); v = dpp_min_step_i<0x140, 0xf>(v);
+	v = dpp_min_step_i<0x142, 0xa>(v); v = dpp_min_step_i<0x143, 0xc>(v);
+	return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) { return -wave_min_i32(-v); }   // y is a sequence coordinate: never INT32_MIN
+
+struct __attribute__((aligned(16))) CfEnt { double pri; int32_t y, x; };
+
+// One WAVE per segment.  Anchors are staged into LDS rings 64 at a time (one coalesced load per block, the next block
+// is in flight while the current one is swept) and f/p leave through the rings once per block, so the per-anchor
+// critical path touches LDS only.  Inside the sweep the wave is its own synchronisation domain (wavefront-scope
+// fences: LDS operations of one wave execute in order).
 __global__ __launch_bounds__(64)
 void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
                   uint64_t n_total, const uint64_t *__restrict__ q_aoff, int n_seq, ChainParams P,
-                  int32_t *__restrict__ f, int32_t *__restrict__ pp, uint32_t *__restrict__ seg_flag)
+                  int32_t *__restrict__ f, int32_t *__restrict__ pp, uint32_t *__restrict__ seg_flag, unsigned long long *__restrict__ prof)
 {
-	__shared__ double r_pri[CF_W];
-	__shared__ int32_t r_y[CF_W];
+	__shared__ CfEnt r_e[CF_W];
 	__shared__ int32_t r_f[CF_W];
-	__shared__ int32_t r_p[CF_WI];
-	__shared__ int32_t r_t[CF_WI];
+	__shared__ uint8_t s_sp[CF_W];
+	__shared__ int32_t r_p[CF_WI], r_t[CF_WI];
 	__shared__ int32_t s_sc[CF_MAXIN], s_j[CF_MAXIN];
 	__shared__ uint8_t s_fl[CF_MAXIN];
 	const int lane = threadIdx.x;
@@ -262,133 +338,218 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 	if (max_dist < P.bw) max_dist = P.bw;
 	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
 	for (int k = lane; k < CF_WI; k += 64) r_t[k] = -1;
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	int32_t st = 0, st_in = 0, i0 = 0;
 	bool bail = false;
-	for (int32_t i = 0; i < n && !bail; ++i) {
-		const u128 ai = A[i];
-		const int32_t yi = (int32_t)ai.y, q_span = (int32_t)(ai.y >> 32 & 0xff);
-		int32_t max_f = q_span, max_j = -1;
-		// 1. late insertion of the anchors that did not share x with their successors (lchain.c:281-293)
-		if (i0 < i && A[i0].x != ai.x) {
-			for (int32_t j = i0 + lane; j < i; j += 64) {
-				const u128 aj = A[j];
-				const int32_t fj = r_f[j & (CF_W - 1)];
-				r_pri[j & (CF_W - 1)] = -((double)fj + 0.5 * (double)P.pen_gap * (double)((int32_t)aj.x + (int32_t)aj.y));
-				r_y[j & (CF_W - 1)] = (int32_t)aj.y;
-			}
-			i0 = i;
-		}
-		// 2. eviction (lchain.c:295-309): x is ascending inside a segment, so the new start is a forward search
-		for (;;) {
-			const int32_t j = st + lane;
-			const bool keep = j >= i0 || !(ai.x > A[j < n ? j : n - 1].x + (uint64_t)max_dist);
-			const unsigned long long m = __ballot(keep);
-			if (m) { st += __ffsll((long long)m) - 1; break; }
-			st += 64;
-		}
-		if (st > i0) st = i0;
-		if (i0 - st > P.cap) st = i0 - P.cap;
-		if (max_dist_inner > 0) {
+	double sm_pri = 1e300; int32_t sm_arg = -1, sm_blk = -1, sm_ymin = 0, sm_ymax = 0;   // lane b: summary of ring block b
+	const unsigned long long c0 = wall_clock64();
+	unsigned long long n_scan = 0, n_inner = 0, n_incand = 0, n_slow = 0;
+	long long tk_scan = 0, tk_red = 0, tk_best = 0, tk_inner = 0, tk_store = 0;
+	u128 nxtv; nxtv.x = 0, nxtv.y = 0;
+	if (lane < n) nxtv = A[lane];
+	for (int32_t blk = 0; blk < n && !bail; blk += 64) {
+		// stage this block, start the load of the next one
+		if (blk + lane < n) { const int32_t s = (blk + lane) & CF_M; r_e[s].x = (int32_t)nxtv.x; r_e[s].y = (int32_t)nxtv.y; s_sp[s] = (uint8_t)(nxtv.y >> 32 & 0xff); }
+		if (blk + 64 + lane < n) nxtv = A[blk + 64 + lane];
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		// the ring must hold [st, blk+128)
+		if (blk + 128 - st > CF_W) { bail = true; break; }
+		const int32_t blk_end = blk + 64 < n ? blk + 64 : n;
+		for (int32_t i = blk; i < blk_end; ++i) {
+			const int32_t xi = r_e[i & CF_M].x, yi = r_e[i & CF_M].y, q_span = s_sp[i & CF_M];
+			int32_t max_f = q_span, max_j = -1;
+			// 1. late insertion (lchain.c:281-293): anchors that share x with i are not yet candidates; priorities were stored when f was known
+			if (i0 < i && r_e[i0 & CF_M].x != xi) i0 = i;
+			// 2+3. eviction (lchain.c:295-309) folded into the range-min scan: x ascends inside a segment, so "evicted" is the
+			// predicate x_i - x_j > max_dist; st trails the true window start and catches up while scanning
+			const long long k0 = clock64();
+			// 2. eviction (lchain.c:295-309): x ascends inside a segment, so the window start is a forward search
 			for (;;) {
-				const int32_t j = st_in + lane;
-				const bool keep = j >= i0 || !(ai.x > A[j < n ? j : n - 1].x + (uint64_t)max_dist_inner);
+				const int32_t j = st + lane;
+				const bool keep = j >= i0 || !(xi - r_e[j & CF_M].x > max_dist);
 				const unsigned long long m = __ballot(keep);
-				if (m) { st_in += __ffsll((long long)m) - 1; break; }
-				st_in += 64;
+				if (m) { st += __ffsll((long long)m) - 1; break; }
+				st += 64;
 			}
-			if (st_in > i0) st_in = i0;
-			if (i0 - st_in > P.cap) st_in = i0 - P.cap;
-		} else st_in = i0;
-		if (i0 - st > CF_W) { bail = true; break; }
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		// 3. range-min over the live window with keys in ((y_i-max_dist, +inf), (y_i, query anchor 0)]
-		double best = 1e300; int32_t best_j = -1; bool tie = false;
-		for (int32_t j = st + lane; j < i0; j += 64) {
-			const int32_t yj = r_y[j & (CF_W - 1)];
-			const bool in = yj > yi - max_dist && (yj < yi || (yj == yi && seg_is_query_start && j == 0));
-			if (in) {
-				const double pj = r_pri[j & (CF_W - 1)];
-				if (pj < best) best = pj, best_j = j, tie = false;
-				else if (pj == best) tie = true;
+			// 3. range-min over [st, i0) with keys in ((y_i-max_dist, +inf), (y_i, query anchor 0)]
+			double best = 1e300; int32_t best_j = -1; bool tie = false;
+			{
+				const int32_t y_lo = yi - max_dist;
+				auto scan64 = [&](int32_t j0, int32_t jend) {
+					++n_scan;
+					const int32_t j = j0 + lane;
+					if (j >= st && j < jend) {
+						const CfEnt ej = r_e[j & CF_M];
+						const bool in = ej.y > y_lo && (ej.y < yi || (ej.y == yi && seg_is_query_start && j == 0));
+						if (in) { if (ej.pri < best) best = ej.pri, best_j = j, tie = false; else if (ej.pri == best) tie = true; }
+					}
+				};
+				// (a) completed 64-anchor blocks below i0 are represented by their summaries (lane b holds ring block b): a block
+				//     wholly inside the window and the y range contributes its minimum, one wholly outside the y range nothing,
+				//     the others are scanned anchor by anchor
+				const int32_t S = blk < (i0 & ~63) ? blk : (i0 & ~63);
+				bool part = false;
+				if (lane < CF_W / 64 && sm_blk >= 0 && sm_blk + 64 > st && sm_blk + 64 <= S) {
+					const bool none = sm_ymax <= y_lo || sm_ymin > yi || (sm_ymin == yi && !(seg_is_query_start && sm_blk == 0));
+					if (sm_blk >= st && sm_ymin > y_lo && sm_ymax < yi) { best = sm_pri; best_j = sm_arg < 0 ? sm_blk : sm_arg; tie = sm_arg < 0; }
+					else if (!none) part = true;
+				}
+				unsigned long long pm = __ballot(part);
+				while (pm) {
+					const int bsel = __ffsll((long long)pm) - 1;
+					pm &= pm - 1;
+					const int32_t bb = __builtin_amdgcn_readlane(sm_blk, bsel);
+					scan64(bb, bb + 64);
+				}
+				// (b) anchors not covered by a summary: the block being swept and blocks reaching beyond i0
+				for (int32_t tj = S > st ? S : st; tj < i0; tj += 64) scan64(tj, i0);
 			}
-		}
-		{
-			double wb = best;
+			if (i0 - st > P.cap) { bail = true; break; }             // size cap of the tree (lchain.c:304): not handled here
+			const long long k1 = clock64();
+			{
+				const double wb = wave_min_f64(best);
+				const unsigned long long who = __ballot(best_j >= 0 && best == wb);
+				if (who == 0) best_j = -1;
+				else {
+					if (__popcll(who) > 1 || __ballot(tie && best == wb)) { bail = true; break; }
+					best_j = __builtin_amdgcn_readlane(best_j, __ffsll((long long)who) - 1);
+				}
+			}
+			const long long k2 = clock64();
+			long long k3 = k2;
+			if (best_j >= 0) {
+				int32_t exact, width; const int32_t j = best_j;
+				const CfEnt ej = r_e[j & CF_M];
+				int32_t sc = r_f[j & CF_M] + score_pair32(xi, yi, ej.x, ej.y, s_sp[j & CF_M], P.pen_gap, P.pen_skip, &exact, &width);
+				if (width <= P.bw && sc > max_f) max_f = sc, max_j = j;
+				k3 = clock64();
+				if (!exact && max_dist_inner > 0 && yi > 0) {
+					// inner window start (lchain.c:300-303), exact; it is only needed here, so it is brought up to date here
+					if (st_in < st) st_in = st;
+					for (;;) {
+						const int32_t jj = st_in + lane;
+						const bool keep = jj >= i0 || !(xi - r_e[jj & CF_M].x > max_dist_inner);
+						const unsigned long long m = __ballot(keep);
+						if (m) { st_in += __ffsll((long long)m) - 1; break; }
+						st_in += 64;
+					}
+					if (st_in > i0) st_in = i0;
+				}
+				if (!exact && max_dist_inner > 0 && st_in < i0 && yi > 0) {
+					// lchain.c:322-349: candidates of the inner window with y in [y_i - inner, y_i - 1], visited by descending (y, j)
+					const int32_t n_in = i0 - st_in;
+					if (n_in > CF_MAXIN) { bail = true; break; }
+					++n_inner; n_incand += n_in;
+					// lane l of group k looks at candidate jc = i0-1-(l+64k): if y does not decrease with the index anywhere in the
+					// window (the co-linear case), descending (y, j) IS descending index, i.e. ascending (k, l)
+					int32_t c_sc[CF_MAXIN / 64], c_j[CF_MAXIN / 64]; bool c_ok[CF_MAXIN / 64], c_val[CF_MAXIN / 64], c_mk[CF_MAXIN / 64];
+					bool unsorted = false;
 #pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) {
-				const double o = __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(wb) >> 32), d) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(wb) & 0xffffffffLL), d));
-				wb = o < wb ? o : wb;
-			}
-			const unsigned long long who = __ballot(best_j >= 0 && best == wb);
-			if (who == 0) best_j = -1;
-			else {
-				if (__popcll(who) > 1 || __ballot(tie && best == wb)) { bail = true; break; }
-				best_j = __shfl(best_j, __ffsll((long long)who) - 1);
-			}
-		}
-		if (best_j >= 0) {
-			int32_t exact, width, n_skip = 0, j = best_j;
-			int32_t sc = r_f[j & (CF_W - 1)] + score_pair(ai, A[j], P.pen_gap, P.pen_skip, &exact, &width);
-			if (width <= P.bw && sc > max_f) max_f = sc, max_j = j;
-			if (!exact && st_in < i0 && yi > 0) {
-				const int32_t n_in = i0 - st_in;
-				if (n_in > CF_MAXIN) { bail = true; break; }
-				// per candidate: score, bandwidth test, validity (y in [y_i - inner, y_i - 1]); marks for predecessors
-				int32_t c_sc[CF_MAXIN / 64], c_y[CF_MAXIN / 64]; bool c_ok[CF_MAXIN / 64], c_val[CF_MAXIN / 64];
-#pragma unroll
-				for (int k = 0; k < CF_MAXIN / 64; ++k) {
-					const int32_t jc = st_in + lane + 64 * k;
-					c_val[k] = false; c_ok[k] = false; c_sc[k] = 0; c_y[k] = 0;
-					if (jc < i0) {
-						const int32_t yj = r_y[jc & (CF_W - 1)];
-						c_y[k] = yj;
-						if (yj <= yi - 1 && yj >= yi - max_dist_inner) {
-							int32_t wdt;
-							c_val[k] = true;
-							c_sc[k] = r_f[jc & (CF_W - 1)] + score_pair(ai, A[jc], P.pen_gap, P.pen_skip, nullptr, &wdt);
-							c_ok[k] = wdt <= P.bw;
-							if (c_ok[k]) { const int32_t pj = r_p[jc & (CF_WI - 1)]; if (pj >= st_in) r_t[pj & (CF_WI - 1)] = i; }
+					for (int k = 0; k < CF_MAXIN / 64; ++k) {
+						const int32_t jc = i0 - 1 - (lane + 64 * k);
+						c_val[k] = false; c_ok[k] = false; c_mk[k] = false; c_sc[k] = 0; c_j[k] = jc;
+						if (jc >= st_in) {
+							const CfEnt ec = r_e[jc & CF_M];
+							if (jc + 1 < i0 && r_e[(jc + 1) & CF_M].y < ec.y) unsorted = true;
+							if (ec.y <= yi - 1 && ec.y >= yi - max_dist_inner) {
+								int32_t wdt;
+								c_val[k] = true;
+								c_sc[k] = r_f[jc & CF_M] + score_pair32(xi, yi, ec.x, ec.y, s_sp[jc & CF_M], P.pen_gap, P.pen_skip, nullptr, &wdt);
+								c_ok[k] = wdt <= P.bw;
+								if (c_ok[k]) { const int32_t pj = r_p[jc & (CF_WI - 1)]; if (pj >= st_in) r_t[pj & (CF_WI - 1)] = i; }
+							}
 						}
 					}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				// rank by descending (y, j) among valid candidates (all-pairs count), then scatter in scan order
-				int32_t n_valid = 0;
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
-				for (int k = 0; k < CF_MAXIN / 64; ++k) n_valid += __popcll(__ballot(c_val[k]));
+					for (int k = 0; k < CF_MAXIN / 64; ++k) c_mk[k] = c_val[k] && r_t[c_j[k] & (CF_WI - 1)] == i;
+					if (__ballot(unsorted)) {
+						// general case: rank by descending (y, j) among valid candidates (all-pairs count), scatter, reload in scan order
+						++n_slow;
+						int32_t n_valid = 0;
 #pragma unroll
-				for (int k = 0; k < CF_MAXIN / 64; ++k) {
-					const int32_t jc = st_in + lane + 64 * k;
-					if (c_val[k]) {
-						int32_t rank = 0;
-						for (int32_t jo = st_in; jo < i0; ++jo) {
-							const int32_t yo = r_y[jo & (CF_W - 1)];
-							const bool vo = yo <= yi - 1 && yo >= yi - max_dist_inner;
-							rank += (vo && (yo > c_y[k] || (yo == c_y[k] && jo > jc))) ? 1 : 0;
+						for (int k = 0; k < CF_MAXIN / 64; ++k) n_valid += __popcll(__ballot(c_val[k]));
+#pragma unroll
+						for (int k = 0; k < CF_MAXIN / 64; ++k) {
+							if (c_val[k]) {
+								const int32_t jc = c_j[k], yc = r_e[jc & CF_M].y;
+								int32_t rank = 0;
+#pragma unroll 8
+								for (int32_t jo = st_in; jo < i0; ++jo) {
+									const int32_t yo = r_e[jo & CF_M].y;
+									const bool vo = yo <= yi - 1 && yo >= yi - max_dist_inner;
+									rank += (vo && (yo > yc || (yo == yc && jo > jc))) ? 1 : 0;
+								}
+								s_sc[rank] = c_sc[k]; s_j[rank] = jc;
+								s_fl[rank] = (uint8_t)((c_ok[k] ? 1 : 0) | (c_mk[k] ? 2 : 0));
+							}
 						}
-						s_sc[rank] = c_sc[k]; s_j[rank] = jc;
-						s_fl[rank] = (uint8_t)((c_ok[k] ? 1 : 0) | (r_t[jc & (CF_WI - 1)] == i ? 2 : 0));
+						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+						for (int k = 0; k < CF_MAXIN / 64; ++k) {
+							const int32_t c = lane + 64 * k;
+							c_val[k] = c < n_valid; c_ok[k] = false; c_mk[k] = false;
+							if (c_val[k]) { const int32_t fl = s_fl[c]; c_ok[k] = fl & 1; c_mk[k] = (fl & 2) != 0; c_sc[k] = s_sc[c]; c_j[k] = s_j[c]; }
+						}
+						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 					}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				for (int32_t c = 0; c < n_valid; ++c) {                       // lchain.c:330-346, wave-uniform
-					const int32_t fl = s_fl[c];
-					if (fl & 1) {
-						const int32_t scc = s_sc[c];
-						if (scc > max_f) { max_f = scc, max_j = s_j[c]; if (n_skip > 0) --n_skip; }
-						else if (fl & 2) { if (++n_skip > P.max_skip) break; }
+					// the scan itself (lchain.c:330-346): "sc > max_f" marks strict prefix maxima, n_skip is replayed over the events
+					int32_t n_skip = 0; bool stop = false;
+#pragma unroll
+					for (int k = 0; k < CF_MAXIN / 64; ++k) {
+						if (stop || 64 * k >= n_in) break;
+						const int32_t v = c_ok[k] ? c_sc[k] : INT32_MIN;
+						const int32_t incl = wave_prefix_max_incl(v);
+						int32_t excl = __builtin_amdgcn_update_dpp(max_f, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps the running maximum
+						if (excl < max_f) excl = max_f;
+						const bool is_max = c_ok[k] && c_sc[k] > excl;
+						const unsigned long long mx = __ballot(is_max), inc = __ballot(c_ok[k] && !is_max && c_mk[k]);
+						// between two new maxima n_skip only grows (by the marked candidates in between); a new maximum takes one off
+						unsigned long long rest = mx; int last = -1, pos = 0;
+						for (;;) {
+							const int c = rest ? __ffsll((long long)rest) - 1 : 64;
+							const unsigned long long range = (c >= 64 ? ~0ULL : ((1ULL << c) - 1)) & ~((1ULL << pos) - 1);
+							n_skip += __popcll(inc & range);
+							if (n_skip > P.max_skip) { stop = true; break; }
+							if (c >= 64) break;
+							rest &= rest - 1;
+							last = c; if (n_skip > 0) --n_skip;
+							pos = c + 1;
+							if (pos >= 64) break;
+						}
+						if (last >= 0) { max_f = __builtin_amdgcn_readlane(c_sc[k], last); max_j = __builtin_amdgcn_readlane(c_j[k], last); }
 					}
 				}
 			}
+			const long long k4 = clock64();
+			if (lane == 0) {
+				r_f[i & CF_M] = max_f; r_p[i & (CF_WI - 1)] = max_j;
+				r_e[i & CF_M].pri = -((double)max_f + 0.5 * (double)P.pen_gap * (double)(xi + yi));
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			const long long k5 = clock64();
+			tk_scan += k1 - k0; tk_red += k2 - k1; tk_best += k3 - k2; tk_inner += k4 - k3; tk_store += k5 - k4;
 		}
-		if (lane == 0) {
-			F[i] = max_f, PP[i] = max_j;
-			r_f[i & (CF_W - 1)] = max_f; r_p[i & (CF_WI - 1)] = max_j;
+		if (bail) break;
+		if (blk + lane < n) { F[blk + lane] = r_f[(blk + lane) & CF_M]; PP[blk + lane] = r_p[(blk + lane) & (CF_WI - 1)]; }
+		if (blk + 64 <= n) {
+			// summary of the finished block: minimum priority (and whether it is unique), y range
+			const CfEnt eb = r_e[(blk + lane) & CF_M];
+			const double mp = wave_min_f64(eb.pri);
+			const unsigned long long who = __ballot(eb.pri == mp);
+			const int32_t ymin = wave_min_i32(eb.y), ymax = wave_max_i32(eb.y);
+			if (lane == ((blk >> 6) & (CF_W / 64 - 1))) {
+				sm_pri = mp; sm_arg = __popcll(who) == 1 ? blk + (int32_t)(__ffsll((long long)who) - 1) : -1;
+				sm_blk = blk; sm_ymin = ymin; sm_ymax = ymax;
+			}
 		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
 	if (lane == 0) seg_flag[sg] = bail ? 1u : 0u;
+	if (prof && lane == 0) {
+		const unsigned long long dt = wall_clock64() - c0;
+		atomicAdd(&prof[0], dt); atomicMax(&prof[1], dt); atomicMax(&prof[2], (unsigned long long)n);
+		atomicAdd(&prof[3], n_scan); atomicAdd(&prof[4], n_inner); atomicAdd(&prof[5], n_incand); atomicAdd(&prof[6], n_slow);
+		atomicAdd(&prof[7], (unsigned long long)tk_scan); atomicAdd(&prof[8], (unsigned long long)tk_red); atomicAdd(&prof[9], (unsigned long long)tk_best); atomicAdd(&prof[10], (unsigned long long)tk_inner); atomicAdd(&prof[11], (unsigned long long)tk_store);
+	}
 }
 
 // one lane per segment: the sweep of lchain.c:276-357 restricted to anchors [b,e) (tree empty at b)
@@ -540,7 +701,7 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
                  uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
                  ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out, unsigned long long *__restrict__ prof)
 {
-	__shared__ uint32_t head[256], tail[256];
+	__shared__ RsLds L;
 	const int q = blockIdx.x, lane = threadIdx.x;
 	if (q >= n_seq) return;
 	const uint64_t b = q_aoff[q];
@@ -564,7 +725,9 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	if (n_z == 0) return;
-	radix_sort_128x_wave(z, n_z, head, tail, lane);
+	if (lane == 0) L.prof[0] = L.prof[1] = L.prof[2] = L.prof[3] = 0;
+	const unsigned long long cs = wall_clock64();
+	radix_sort_128x_wave(z, n_z, L, lane);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	const unsigned long long c1 = wall_clock64();
 	// ---- walks (every lane executes the same control flow) ----
@@ -644,6 +807,7 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 	if (prof && lane == 0) {
 		const unsigned long long c3 = wall_clock64();
 		atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2);
+		atomicAdd(&prof[6], cs - c0); for (int k = 0; k < 4; ++k) atomicAdd(&prof[7 + k], L.prof[k]);
 		atomicMax(&prof[3], c1 - c0); atomicMax(&prof[4], c2 - c1); atomicMax(&prof[5], c3 - c2);
 	}
 }
@@ -703,14 +867,22 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		DBuf<uint32_t> seg_flag(n_seg);
 		EventTimer et(st);
 		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
-		if (use_fast) hipLaunchKernelGGL(k_chain_fast, dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p);
+		DBuf<unsigned long long> cprof(16); cprof.zero(st);
+		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
+		if (use_fast) hipLaunchKernelGGL(k_chain_fast, dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p,
+		                                 verbose ? cprof.p : (unsigned long long*)nullptr);
+		const double ms_fast = verbose ? et.stop() : 0.0;
 		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
 		                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
 		PGA_HIP(hipGetLastError());
 		const double ms = et.stop();
 		if (getenv("PGA_VERBOSE") && use_fast) {
 			std::vector<uint32_t> fl = seg_flag.download(st); size_t nf = 0; for (uint32_t v : fl) nf += v;
-			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel, %.3f ms\n", n_seg, nf, ms);
+			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel, %.3f ms (fast kernel %.3f ms)\n", n_seg, nf, ms, ms_fast);
+			std::vector<unsigned long long> pr = cprof.download(st);
+			fprintf(stderr, "[pga]   chain fast: longest segment %llu anchors, slowest %.2f ms, sum %.1f ms; scan iterations %.2f/anchor, inner scans %.3f/anchor with %.1f candidates, %llu unsorted\n",
+			        pr[2], pr[1] * 1e-5, pr[0] * 1e-5, (double)pr[3] / (double)n_a, (double)pr[4] / (double)n_a, pr[4] ? (double)pr[5] / (double)pr[4] : 0.0, pr[6]);
+			fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a);
 		}
 		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
 	}
@@ -721,7 +893,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
 	{
 		EventTimer et(st);
-		DBuf<unsigned long long> prof(8); prof.zero(st);
+		DBuf<unsigned long long> prof(12); prof.zero(st);
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
 		                   verbose ? prof.p : (unsigned long long*)nullptr);
@@ -730,6 +902,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 			std::vector<unsigned long long> pr = prof.download(st);   // wall_clock64 ticks at 100 MHz
 			fprintf(stderr, "[pga]   backtrack: %.3f ms; per-query max (ms): list+sort %.2f, walks %.2f, compact %.2f; sums %.1f %.1f %.1f\n", ms,
 			        pr[3] * 1e-5, pr[4] * 1e-5, pr[5] * 1e-5, pr[0] * 1e-5, pr[1] * 1e-5, pr[2] * 1e-5);
+			fprintf(stderr, "[pga]   backtrack sums (ms): list %.1f | sort: vary %.1f hist %.1f walk %.1f runs %.1f\n", pr[6] * 1e-5, pr[7] * 1e-5, pr[8] * 1e-5, pr[9] * 1e-5, pr[10] * 1e-5);
 		}
 		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
 	}

@@ -258,13 +258,13 @@ __global__ void k_tie_flags(const uint64_t *__restrict__ xs, const uint64_t *__r
 __global__ __launch_bounds__(64)
 void k_sort_exact(int n_seq, const uint32_t *__restrict__ q_tie, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a_unsorted, u128 *__restrict__ a_sorted)
 {
-	__shared__ uint32_t head[256], tail[256];
+	__shared__ RsLds L;
 	const int q = blockIdx.x, lane = threadIdx.x;
 	if (q >= n_seq || !q_tie[q]) return;
 	const uint64_t b = q_aoff[q], e = q_aoff[q + 1];
 	for (uint64_t i = b + lane; i < e; i += 64) a_sorted[i] = a_unsorted[i];
 	__threadfence_block();
-	radix_sort_128x_wave(a_sorted + b, (int64_t)(e - b), head, tail, lane);
+	radix_sort_128x_wave(a_sorted + b, (int64_t)(e - b), L, lane);
 }
 
 // ---- host orchestration ----
