@@ -20,6 +20,11 @@
 
 namespace pga {
 
+// ---- device memory: cached blocks (pga_mem.cpp) ----
+void *dev_alloc(size_t bytes);
+void dev_free(void *p);
+void dev_trim();        // release every idle block of the current device
+
 // ---- device buffer ----
 template <class T> struct DBuf {
 	T *p = nullptr; size_t n = 0, cap = 0;
@@ -29,9 +34,9 @@ template <class T> struct DBuf {
 	DBuf(DBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
 	DBuf &operator=(DBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
 	~DBuf() { release(); }
-	void release() { if (p) (void)hipFree(p); p = nullptr; n = cap = 0; }
+	void release() { if (p) dev_free(p); p = nullptr; n = cap = 0; }
 	void alloc(size_t n_) { // contents undefined
-		if (n_ > cap) { release(); size_t c = n_ + n_ / 8 + 64; PGA_HIP(hipMalloc((void**)&p, c * sizeof(T))); cap = c; }
+		if (n_ > cap) { release(); p = (T*)dev_alloc(n_ * sizeof(T)); cap = n_; }
 		n = n_;
 	}
 	void zero(hipStream_t s = 0) { if (n) PGA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }

@@ -329,23 +329,36 @@ size_t dp_slab_bytes(int qlen, int tlen, int w)
 void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
-void launch_extd2_wide(unsigned n_blocks, int t_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact);
+void launch_extd2_wide(unsigned n_blocks, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 // Problem classes (each is one persistent launch):
-//   0,1  register-resident kernel (pga_ksw_fast.hip), target <= 256 / <= 512 lanes, band never binding
-//   2,3  workgroup kernel with LDS rows (pga_ksw_wide.hip), target <= 2048 / <= 10240 columns
-//   4    single-wave kernel with rows in the HBM slab (targets wider than LDS can hold; not reached by pangraph's windows)
-#define DP_NCLASS 5
+//   0,1    register-resident kernel (pga_ksw_fast.hip), target <= 256 / <= 512 lanes, band never binding
+//   2,3,4  workgroup kernel (pga_ksw_wide.hip) by LDS footprint of the band ring + sequences: <= 48 KB (three workgroups
+//          per CU), <= 76 KB (two), <= 152 KB (one)
+//   5      single-wave kernel with rows in the HBM slab (targets wider than LDS can hold; not reached by pangraph's windows)
+#define DP_NCLASS 6
+#define WIDE_LDS_MAX (152 * 1024)
+static inline int wide_ring(const DpJob &j)
+{
+	const int T = (j.tlen + 15) / 16 * 16;
+	int w = j.w < 0 ? (j.tlen > j.qlen ? j.tlen : j.qlen) : j.w;
+	int R = ((w < j.tlen ? w : j.tlen) + 15) / 16 * 16 + 96;
+	return R > T ? T : R;
+}
+static inline int wide_seqcap(const DpJob &j) { return ((j.qlen > j.tlen ? j.qlen : j.tlen) + 15) / 16 * 16; }
 static int dp_class(const DpJob &j, size_t need)
 {
 	(void)need;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
-	if (j.tlen <= 2048) return 2;
-	if (j.tlen <= 10240) return 3;
-	return 4;
+	const size_t rows = (size_t)14 * wide_ring(j), l = rows + 2 * (size_t)wide_seqcap(j);
+	if (l <= 48 * 1024) return 2;
+	if (l <= 76 * 1024) return 3;
+	if (rows <= WIDE_LDS_MAX) return 4;
+	return 5;
 }
 
 void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st, Timers *tm)
@@ -354,7 +367,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	const size_t n = jobs.size();
 	if (n == 0) return;
 	std::vector<uint32_t> cls[DP_NCLASS];
-	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0};
+	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0, 0};
 	std::vector<size_t> need(n);
 	unsigned long long cig_total = 0;
 	for (size_t i = 0; i < n; ++i) {
@@ -379,18 +392,20 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		DBuf<DpJob> d_jobs; d_jobs.upload(jb, st);
 		DBuf<DpRes> d_r(ids.size());
 		DBuf<uint32_t> d_cnt(1); d_cnt.zero(st);
-		size_t n_waves = c == 4 ? 256 * 2 : c == 3 ? 256 : c == 2 ? 256 * 4 : 256 * 16;
+		size_t n_waves = c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
 		if (n_waves > ids.size()) n_waves = ids.size();
-		const size_t budget = (size_t)32 << 30;
+		size_t budget = (size_t)96 << 30;
+		{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 * 3 < budget) budget = fr / 4 * 3; }
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
 		DBuf<uint8_t> d_slab(n_waves * slab_max[c]);
 		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launching dp class %d: %zu problems on %zu waves, slab %zu B\n", c, ids.size(), n_waves, slab_max[c]); fflush(stderr); }
 		EventTimer et(st);
 		if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)n_waves, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
-		else if (c <= 3) {
-			int tmax = 0; bool exact = false;
-			for (uint32_t id : ids) { tmax = std::max(tmax, (jobs[id].tlen + 15) / 16 * 16); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
-			launch_extd2_wide((unsigned)n_waves, tmax, exact, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
+		else if (c <= 4) {
+			int r_cap = 0, seq_cap = 0; bool exact = false;
+			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
+			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
+			launch_extd2_wide((unsigned)n_waves, r_cap, seq_cap, exact, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
 		                        d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
@@ -403,6 +418,17 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		}
 		std::vector<DpRes> r = d_r.download(st);
 		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];
+		if (c >= 2 && c <= 4 && getenv("PGA_VERBOSE")) {
+			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
+			for (size_t i = 0; i < ids.size(); ++i) {
+				const DpJob &j = jobs[ids[i]];
+				sq += j.qlen, stl += j.tlen, sw += j.w, zd += r[i].zdropped != 0, mt += r[i].max_t + r[i].max_q, ext += (j.flag & 0x40) != 0, big += need[ids[i]] > (8u << 20);
+				dg += r[i].pad;
+			}
+			const double m = (double)ids.size();
+			fprintf(stderr, "[pga]       class %d: mean qlen %.0f tlen %.0f w %.0f; extension-only %.0f%%, z-dropped %.0f%%, mean max_q+max_t %.0f, ~diagonals %.0f, slab > 8 MB: %.0f\n", c, sq / m, stl / m, sw / m,
+			        100 * ext / m, 100 * zd / m, mt / m, dg / m, big);
+		}
 	}
 	unsigned long long used = d_cursor.download(st)[0];
 	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");

@@ -2,8 +2,12 @@
 // max_gap x max_gap with band 1.5*bw, second exact passes, long-join segments): everything pga_ksw_fast.hip
 // does not take.  Same per-lane int8 recurrence and the same 16-lane rounding / stale-profile behaviour as
 // ksw2_extd2_sse.c:131-386 (see pga_ksw.hip), laid out for a 256-thread workgroup:
-//   * all rows live in LDS (dynamic, 10 B/column + 4 B/column of H in exact mode, up to 10240 columns = 143 KB):
-//     one workgroup per CU for the widest problems, several for narrow ones;
+//   * all rows live in LDS as a RING over the band (dynamic, 10 B/column + 4 B/column of H in exact mode; a column's slot
+//     is t mod R with R >= band + 96, so a 10 kb x 10 kb extension with band 2873 needs 42 KB, not 143 KB, and several
+//     workgroups share a CU); a column that enters the band gets the initial values the reference's freshly
+//     allocated rows hold, which keeps its stale-lane behaviour;
+//   * both sequences are copied to LDS once per problem (orientation and complement resolved at copy time), so the
+//     diagonal loop issues no global loads at all -- its direction-matrix stores are fire-and-forget;
 //   * x, v and x2 -- the rows a cell reads at t-1 -- are double-buffered by diagonal parity, so the four waves
 //     sweep a diagonal's band in parallel without a read/write hazard.  Band ranges only move right, so a
 //     column that enters the band was never computed before and both buffers still hold its initial value:
@@ -13,6 +17,7 @@
 //   * wave 0 walks the direction matrix back through a 64x64 LDS window (fences only, as in the fast kernel).
 #include "pga_common.h"
 #include "pga_dp.h"
+#include "pga_wave.h"
 
 namespace pga {
 
@@ -24,6 +29,7 @@ namespace pga {
 #define EZ_REV_CIGAR  0x80
 #define WIDE_NT 256
 #define WBT 64
+#define WIDE_LDS_MAX (152 * 1024)   // dynamic LDS the kernel may ask for (160 KB per CU minus its static arrays); pga_ksw.hip sizes classes with it
 
 __device__ __forceinline__ int sx8w(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
 
@@ -39,7 +45,7 @@ __device__ __forceinline__ void diag_range_w(int r, int qlen, int tlen, int w, i
 
 __global__ __launch_bounds__(WIDE_NT)
 void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
-                  uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes, int t_cap,
+                  uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes, int r_cap, int seq_cap, int exact_rows,
                   DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
 	extern __shared__ __align__(16) uint8_t dyn[];
@@ -80,61 +86,95 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			int c = q_base[J.qlen_full - 1 - pj];
 			return c < 4 ? 3 - c : 4;
 		};
-		// LDS rows (T <= t_cap is guaranteed by the launcher)
-		int8_t *u = (int8_t*)dyn, *y = u + t_cap, *y2 = y + t_cap, *s = y2 + t_cap;
-		int8_t *xb[2] = { s + t_cap, s + 2 * t_cap }, *vb[2] = { s + 3 * t_cap, s + 4 * t_cap }, *x2b[2] = { s + 5 * t_cap, s + 6 * t_cap };
-		int32_t *H = (int32_t*)(s + 7 * t_cap);
+		// LDS rows: ring of R columns (R == T when the whole target fits the launch's ring capacity)
+		int R = ((w < tlen ? w : tlen) + 15) / 16 * 16 + 96;
+		if (R > T) R = T;
+		if (R > r_cap) R = r_cap;                          // the launcher sized r_cap for every problem of the class
+		int8_t *u = (int8_t*)dyn, *y = u + r_cap, *y2 = y + r_cap, *s = y2 + r_cap;
+		int8_t *xb[2] = { s + r_cap, s + 2 * r_cap }, *vb[2] = { s + 3 * r_cap, s + 4 * r_cap }, *x2b[2] = { s + 5 * r_cap, s + 6 * r_cap };
+		int32_t *H = (int32_t*)(s + 7 * r_cap);
+		uint8_t *tq = (uint8_t*)(s + 7 * r_cap) + (exact_rows ? (size_t)4 * r_cap : 0), *qq = tq + seq_cap;   // sequences, when seq_cap > 0
+		const bool seq_lds = seq_cap > 0;
 		uint8_t *pmat = slab;
 		uint32_t *cig_tmp = (uint32_t*)(pmat + (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15));
-		for (int t = tid; t < T; t += WIDE_NT) {
+		const int init_n = R;
+		for (int t = tid; t < init_n; t += WIDE_NT) {
 			u[t] = y[t] = (int8_t)(-q - e); y2[t] = (int8_t)(-q2 - e2); s[t] = 0;
 			xb[0][t] = xb[1][t] = vb[0][t] = vb[1][t] = (int8_t)(-q - e);
 			x2b[0][t] = x2b[1][t] = (int8_t)(-q2 - e2);
 			if (!approx_max) H[t] = KSW_NEG_INF;
 		}
+		if (seq_lds) {
+			for (int i = tid; i < tlen; i += WIDE_NT) tq[i] = (uint8_t)target_at(i);
+			for (int j = tid; j < qlen; j += WIDE_NT) qq[j] = (uint8_t)query_at(j);
+		}
+		int init_hi = R - 1;                               // highest column whose slot holds that column's state
 		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
 		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
 		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
 		const int n_diag = qlen + tlen - 1;
+		int r_done = 0;
 		__syncthreads();
 
+		int base = 0;                                       // multiple of R with base <= st-16: slot(t) = t-base (-R)
 		for (int r = 0; r < n_diag; ++r) {
+			r_done = r + 1;
 			int st0, en0;
 			diag_range_w(r, qlen, tlen, w, st0, en0);
 			if (st0 > en0) { ez_zdropped = 1; break; }
 			const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+			while (st - 16 >= base + R) base += R;
+			auto sl = [&](int t) { const int x = t - base; return x >= R ? x - R : x; };
+			const int span = ((en0 - st0) / 16 + 1) * 16;
+			// columns entering the band take over the slots of columns that left it long ago
+			{
+				int need_hi = en > st0 + span - 1 ? en : st0 + span - 1;
+				if (need_hi > T - 1) need_hi = T - 1;
+				if (need_hi > init_hi) {
+					for (int t = init_hi + 1 + tid; t <= need_hi; t += WIDE_NT) {
+						const int k = sl(t);
+						u[k] = y[k] = (int8_t)(-q - e); y2[k] = (int8_t)(-q2 - e2); s[k] = 0;
+						xb[0][k] = xb[1][k] = vb[0][k] = vb[1][k] = (int8_t)(-q - e);
+						x2b[0][k] = x2b[1][k] = (int8_t)(-q2 - e2);
+						if (!approx_max) H[k] = KSW_NEG_INF;
+					}
+					init_hi = need_hi;
+					__syncthreads();
+				}
+			}
 			const int8_t *xr = xb[r & 1], *vr = vb[r & 1], *x2r = x2b[r & 1];
 			int8_t *xw = xb[(r + 1) & 1], *vw = vb[(r + 1) & 1], *x2w = x2b[(r + 1) & 1];
 			int x1, x21, v1;
 			if (st > 0) {
-				if (st - 1 >= last_st && st - 1 <= last_en) x1 = xr[st - 1], x21 = x2r[st - 1], v1 = vr[st - 1];
+				if (st - 1 >= last_st && st - 1 <= last_en) { const int k = sl(st - 1); x1 = xr[k], x21 = x2r[k], v1 = vr[k]; }
 				else x1 = sx8w(-q - e), x21 = sx8w(-q2 - e2), v1 = sx8w(-q - e);
 			} else {
 				x1 = sx8w(-q - e), x21 = sx8w(-q2 - e2);
 				v1 = r == 0 ? sx8w(-q - e) : r < long_thres ? sx8w(-e) : r == long_thres ? sx8w(long_diff) : sx8w(-e2);
 			}
 			if (en >= r && tid == 0) {
-				y[r] = (int8_t)(-q - e), y2[r] = (int8_t)(-q2 - e2);
-				u[r] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+				const int k = sl(r);
+				y[k] = (int8_t)(-q - e), y2[k] = (int8_t)(-q2 - e2);
+				u[k] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
 			}
-			{
-				const int span = ((en0 - st0) / 16 + 1) * 16;
-				for (int o = tid; o < span; o += WIDE_NT) {
-					const int t = st0 + o;
-					if (t < T) {
-						const int a = target_at(t), b = query_at(r - t);
-						int sc = a == b ? sc_mch : sc_mis;
-						if (a == 4 || b == 4) sc = sc_N;
-						s[t] = (int8_t)sc;
-					}
+			for (int o = tid; o < span; o += WIDE_NT) {
+				const int t = st0 + o;
+				if (t < T) {
+					int a, b;
+					if (seq_lds) { a = t < tlen ? (int)tq[t] : 0; const int j = r - t; b = (j >= 0 && j < qlen) ? (int)qq[j] : 0; }
+					else a = target_at(t), b = query_at(r - t);
+					int sc = a == b ? sc_mch : sc_mis;
+					if (a == 4 || b == 4) sc = sc_N;
+					s[sl(t)] = (int8_t)sc;
 				}
 			}
 			__syncthreads();
 			uint8_t *prow = pmat + (size_t)r * n_col - st;
 			for (int t = st + tid; t <= en; t += WIDE_NT) {
-				const int xt1 = t == st ? x1 : (int)xr[t - 1], vt1 = t == st ? v1 : (int)vr[t - 1], x2t1 = t == st ? x21 : (int)x2r[t - 1];
-				const int ut = u[t], yo = y[t], y2o = y2[t];
-				int z = s[t];
+				const int k = sl(t), k1 = t == st ? k : sl(t - 1);
+				const int xt1 = t == st ? x1 : (int)xr[k1], vt1 = t == st ? v1 : (int)vr[k1], x2t1 = t == st ? x21 : (int)x2r[k1];
+				const int ut = u[k], yo = y[k], y2o = y2[k];
+				int z = s[k];
 				int a = sx8w(xt1 + vt1), b = sx8w(yo + ut), a2 = sx8w(x2t1 + vt1), b2 = sx8w(y2o + ut), d;
 				if (!right) {
 					d = 0;
@@ -149,19 +189,19 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					d = z > b2 ? d : 4; z = z > b2 ? z : b2;
 				}
 				if (sc_mch < z) z = sc_mch;
-				u[t] = (int8_t)(z - vt1), vw[t] = (int8_t)(z - ut);
+				u[k] = (int8_t)(z - vt1), vw[k] = (int8_t)(z - ut);
 				int tmp = sx8w(z - q); a = sx8w(a - tmp), b = sx8w(b - tmp);
 				tmp = sx8w(z - q2); a2 = sx8w(a2 - tmp), b2 = sx8w(b2 - tmp);
 				if (!right) {
-					xw[t]  = (int8_t)((a  > 0 ? a  : 0) - qe);  if (a  > 0) d |= 0x08;
-					y[t]   = (int8_t)((b  > 0 ? b  : 0) - qe);  if (b  > 0) d |= 0x10;
-					x2w[t] = (int8_t)((a2 > 0 ? a2 : 0) - qe2); if (a2 > 0) d |= 0x20;
-					y2[t]  = (int8_t)((b2 > 0 ? b2 : 0) - qe2); if (b2 > 0) d |= 0x40;
+					xw[k]  = (int8_t)((a  > 0 ? a  : 0) - qe);  if (a  > 0) d |= 0x08;
+					y[k]   = (int8_t)((b  > 0 ? b  : 0) - qe);  if (b  > 0) d |= 0x10;
+					x2w[k] = (int8_t)((a2 > 0 ? a2 : 0) - qe2); if (a2 > 0) d |= 0x20;
+					y2[k]  = (int8_t)((b2 > 0 ? b2 : 0) - qe2); if (b2 > 0) d |= 0x40;
 				} else {
-					xw[t]  = (int8_t)((0 > a  ? 0 : a)  - qe);  if (!(0 > a))  d |= 0x08;
-					y[t]   = (int8_t)((0 > b  ? 0 : b)  - qe);  if (!(0 > b))  d |= 0x10;
-					x2w[t] = (int8_t)((0 > a2 ? 0 : a2) - qe2); if (!(0 > a2)) d |= 0x20;
-					y2[t]  = (int8_t)((0 > b2 ? 0 : b2) - qe2); if (!(0 > b2)) d |= 0x40;
+					xw[k]  = (int8_t)((0 > a  ? 0 : a)  - qe);  if (!(0 > a))  d |= 0x08;
+					y[k]   = (int8_t)((0 > b  ? 0 : b)  - qe);  if (!(0 > b))  d |= 0x10;
+					x2w[k] = (int8_t)((0 > a2 ? 0 : a2) - qe2); if (!(0 > a2)) d |= 0x20;
+					y2[k]  = (int8_t)((0 > b2 ? 0 : b2) - qe2); if (!(0 > b2)) d |= 0x40;
 				}
 				prow[t] = (uint8_t)d;
 			}
@@ -170,24 +210,20 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			if (!approx_max) {
 				int max_H, max_t;
 				if (r > 0) {
-					const int Hen = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + vw[en0];
+					const int Hen = en0 > 0 ? H[sl(en0 - 1)] + u[sl(en0)] : H[sl(en0)] + vw[sl(en0)];
 					__syncthreads();
 					const int en1 = st0 + (en0 - st0) / 4 * 4;
 					long long best = ((long long)Hen << 32) | 0xffffffffu;
 					for (int t = st0 + tid; t < en0; t += WIDE_NT) {
-						const int h = H[t] + vw[t];
-						H[t] = h;
+						const int k = sl(t);
+						const int h = H[k] + vw[k];
+						H[k] = h;
 						const unsigned ord = t < en1 ? 1u + ((unsigned)((t - st0) & 3) << 28) + (unsigned)t : 1u + (4u << 28) + (unsigned)t;
 						const long long key = ((long long)h << 32) | (0xffffffffu - ord);
 						best = key > best ? key : best;
 					}
-					if (tid == 0) H[en0] = Hen;
-#pragma unroll
-					for (int dd = 32; dd >= 1; dd >>= 1) {
-						int lo = __shfl_xor((int)(best & 0xffffffffLL), dd), hi = __shfl_xor((int)(best >> 32), dd);
-						long long o = ((long long)hi << 32) | (unsigned int)lo;
-						best = o > best ? o : best;
-					}
+					if (tid == 0) H[sl(en0)] = Hen;
+					best = wave_max_i64(best);
 					if (lane == 0) s_part[wave] = best;
 					__syncthreads();
 #pragma unroll
@@ -196,26 +232,26 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					const unsigned ord = 0xffffffffu - (unsigned)(best & 0xffffffffLL);
 					max_t = ord == 0 ? en0 : (int)((ord - 1) & 0x0fffffffu);
 				} else {
-					if (tid == 0) H[0] = vw[0] - qe_h;
+					if (tid == 0) H[sl(0)] = vw[sl(0)] - qe_h;
 					__syncthreads();
-					max_H = H[0], max_t = 0;
+					max_H = H[sl(0)], max_t = 0;
 				}
-				if (en0 == tlen - 1) { const int h = H[en0]; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
-				if (r - st0 == qlen - 1) { const int h = H[st0]; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+				if (en0 == tlen - 1) { const int h = H[sl(en0)]; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
+				if (r - st0 == qlen - 1) { const int h = H[sl(st0)]; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
 				if (max_H > ez_max) ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
 				else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
 					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
 					if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
 				}
-				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = H[tlen - 1];
+				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = H[sl(tlen - 1)];
 			} else {
 				if (r > 0) {
 					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-						const int d0 = vw[last_H0_t], d1 = u[last_H0_t + 1];
+						const int d0 = vw[sl(last_H0_t)], d1 = u[sl(last_H0_t + 1)];
 						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
-					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += vw[last_H0_t];
-					else ++last_H0_t, H0 += u[last_H0_t];
-				} else H0 = vw[0] - qe_h, last_H0_t = 0;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += vw[sl(last_H0_t)];
+					else ++last_H0_t, H0 += u[sl(last_H0_t)];
+				} else H0 = vw[sl(0)] - qe_h, last_H0_t = 0;
 				if (flag & EZ_APPROX_DROP) {
 					if (H0 > ez_max) ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
 					else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
@@ -290,20 +326,22 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			if (lane == 0) {
 				DpRes R;
 				R.max = ez_max, R.max_q = ez_max_q, R.max_t = ez_max_t, R.mqe = ez_mqe, R.mqe_t = ez_mqe_t, R.mte = ez_mte, R.mte_q = ez_mte_q;
-				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = n_cigar, R.pad = 0, R.cigar_off = base;
+				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = n_cigar, R.pad = r_done, R.cigar_off = base;
 				res[jid] = R;
 			}
 		}
 	}
 }
 
-void launch_extd2_wide(unsigned n_blocks, int t_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact) { return (size_t)r_cap * 10 + (exact ? (size_t)r_cap * 4 : 0) + 2 * (size_t)seq_cap; }
+
+void launch_extd2_wide(unsigned n_blocks, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
-	const size_t lds = (size_t)t_cap * 10 + (exact ? (size_t)t_cap * 4 : 0);
+	const size_t lds = wide_lds_bytes(r_cap, seq_cap, exact);
 	static bool attr_set = false;
-	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
-	hipLaunchKernelGGL(k_extd2_wide, dim3(n_blocks), dim3(WIDE_NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, t_cap, res, pool, cursor, pool_cap);
+	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_MAX)); attr_set = true; }
+	hipLaunchKernelGGL(k_extd2_wide, dim3(n_blocks), dim3(WIDE_NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga
