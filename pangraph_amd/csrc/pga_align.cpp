@@ -20,8 +20,17 @@
 #include <list>
 #include <chrono>
 #include <cstdio>
+#include <mutex>
 
 namespace pga {
+
+// host-side phase accounting (PGA_VERBOSE): nanoseconds summed over threads
+static std::atomic<long long> g_ns[8];
+static bool g_prof = false;
+struct ScopeNs { int k; std::chrono::steady_clock::time_point t0; explicit ScopeNs(int k_) : k(k_) { if (g_prof) t0 = std::chrono::steady_clock::now(); }
+	~ScopeNs() { if (g_prof) g_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
+
+
 
 #define SEED_LONG_JOIN (1ULL<<40)
 #define SEED_IGNORE    (1ULL<<41)
@@ -290,10 +299,13 @@ static void track_zdrop(int32_t score, int i, int j, int32_t *max, int *max_i, i
 		if (z > *max_zdrop) { *max_zdrop = z; pos[0][0] = *max_i, pos[0][1] = i; pos[1][0] = *max_j, pos[1][1] = j; }
 	} else *max = score, *max_i = i, *max_j = j;
 }
-static int test_zdrop(const mm_mapopt_t &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat) // align.c:47-89
+// mm_test_zdrop (align.c:47-89), first half: the walk along the CIGAR.  Returns max_zdrop and, in pos, the window of the
+// worst drop.  The second half (the local alignment of the window against its reverse complement, align.c:78-86) is a
+// separate problem: on the GPU (pga_ll.hip) or, for windows the kernel does not take, ll_i16 here.
+static int zdrop_walk(const mm_mapopt_t &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat, int pos[2][2])
 {
 	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
-	int pos[2][2] = {{-1, -1}, {-1, -1}}, q_len, t_len;
+	pos[0][0] = pos[0][1] = pos[1][0] = pos[1][1] = -1;
 	for (uint32_t k = 0; k < n_cigar; ++k) {
 		uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
@@ -305,15 +317,41 @@ static int test_zdrop(const mm_mapopt_t &opt, const uint8_t *qseq, const uint8_t
 			track_zdrop(score, i, j, &max, &max_i, &max_j, opt.e, &max_zdrop, pos);
 		}
 	}
-	q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
-	if (!(opt.flag & (MM_F_SPLICE|MM_F_SR|MM_F_FOR_ONLY|MM_F_REV_ONLY)) && max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap) {
-		std::vector<uint8_t> qseq2((size_t)(q_len > 0 ? q_len : 0));
-		int q_off, t_off;
-		for (i = 0; i < q_len; ++i) { int c = qseq[pos[1][1] - i - 1]; qseq2[i] = (uint8_t)(c >= 4 ? 4 : 3 - c); }
-		score = ll_i16(q_len, qseq2.data(), mat, t_len, tseq + pos[0][0], opt.q, opt.e, &q_off, &t_off);
-		if (score >= opt.min_chain_score * opt.a && score >= opt.min_dp_max) return 2;
+	return max_zdrop;
+}
+static inline bool zdrop_wants_inversion_test(const mm_mapopt_t &opt, int max_zdrop, const int pos[2][2])
+{
+	const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
+	return !(opt.flag & (MM_F_SPLICE|MM_F_SR|MM_F_FOR_ONLY|MM_F_REV_ONLY)) && max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap;
+}
+static inline bool ll_on_device(const mm_mapopt_t &opt, int q_len, int t_len)
+{
+	const int q8 = (q_len + 7) / 8 * 8;
+	return q_len > 0 && t_len > 0 && q8 <= PGA_LL_MAX_LEN && t_len <= PGA_LL_MAX_LEN && (int64_t)(opt.a > 0 ? opt.a : -opt.a) * q8 < 32000;
+}
+
+// A sufficient condition for mm_test_zdrop (align.c:47-89) to return 0 that needs no sequence: every z it tracks is at
+// most max - score, i.e. at most the sum of all score decrements along the path.  The global pass's score fixes how
+// much the match columns fall short of all-matches (a*L - score - gap costs; the dual-affine gap costs are bounded
+// from below by their cheapest form), mm_test_zdrop itself charges q + e*len per gap.  If even that total cannot exceed
+// zdrop (nor zdrop_inv, which gates the inversion test), the answer is 0.
+static bool zdrop_impossible(const mm_mapopt_t &opt, const DpRes &ez, const uint32_t *cigar)
+{
+	if (ez.zdropped || ez.n_cigar <= 0 || ez.score <= -0x3fffffff) return false;
+	int64_t L = 0, g_dp = 0, g_test = 0;
+	for (int k = 0; k < ez.n_cigar; ++k) {
+		const int64_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (op == 0) L += len;
+		else if (op == 1 || op == 2 || op == 3) {
+			const int64_t c1 = opt.q + (int64_t)opt.e * len, c2 = opt.q2 + (int64_t)opt.e2 * len;
+			g_dp += c1 < c2 ? c1 : c2;
+			g_test += c1;
+		} else return false;
 	}
-	return max_zdrop > opt.zdrop ? 1 : 0;
+	const int64_t shortfall = (int64_t)opt.a * L - (int64_t)ez.score - g_dp;
+	if (shortfall < 0) return false;                 // not a plain match/mismatch matrix: leave it to the full test
+	const int64_t lim = opt.zdrop < opt.zdrop_inv ? opt.zdrop : opt.zdrop_inv;
+	return shortfall + g_test <= lim;
 }
 
 static void cigar_append(Reg &r, uint32_t n_cigar, const uint32_t *cigar) // align.c:291-314
@@ -513,7 +551,7 @@ static void fix_bad_ends(const Reg &r, const u128 *a, int bw, int min_match, int
 }
 
 // ---------------- the per-region state machine ----------------
-struct Seg { int32_t i, rs, qs, re, qe, bw1; int job1 = -1, job2 = -1, zcode = -1; };
+struct Seg { int32_t i, rs, qs, re, qe, bw1; int job1 = -1, job2 = -1, zcode = -1; int ll_job = -1; int32_t max_zdrop = 0; };
 
 struct RegTask {
 	Reg r;
@@ -528,6 +566,7 @@ struct RegTask {
 	bool dropped = false;
 	// inversion test state (mm_align1_inv)
 	int inv_state = 0;      // 0 = not evaluated, 1 = waiting for its DP problem, 2 = resolved
+	int inv_ll_job = -1;    // the local-alignment query that precedes it (state 3 = waiting for that)
 	int inv_job = -1; int32_t inv_q_off = 0, inv_t_off = 0, inv_ql = 0, inv_tl = 0;
 };
 
@@ -560,7 +599,7 @@ struct Driver {
 		DpRes r; memset(&r, 0, sizeof(r));
 		// problems the reference never hands to the kernel (align.c:326-328, ksw2_extd2_sse.c:82) are resolved here
 		r.max_q = r.max_t = r.mqe_t = r.mte_q = -1; r.score = r.mqe = r.mte = NEG_INF;
-		if (opt.max_sw_mat > 0 && (int64_t)tlen * qlen > opt.max_sw_mat) { r.zdropped = 1; r.pad = 1; }
+		if (!(flag & PGA_JOB_LL) && opt.max_sw_mat > 0 && (int64_t)tlen * qlen > opt.max_sw_mat) { r.zdropped = 1; r.pad = 1; }
 		else if (qlen <= 0 || tlen <= 0) r.pad = 1;
 		Q.res.push_back(r); Q.cig.push_back(nullptr);
 		if (!r.pad) Q.pending.push_back(id);
@@ -672,16 +711,43 @@ struct Driver {
 		}
 		if (T.seg_k == 0) T.re1 = T.rs, T.qe1 = T.qs;
 		std::vector<uint8_t> qw, tw;
+		ScopeNs sc_seg(0);
 		while (T.seg_k < T.segs.size() && !T.dropped) {
 			Seg &sg = T.segs[T.seg_k];
 			if (!have(Q, sg.job1)) return false;
 			T.re1 = sg.re, T.qe1 = sg.qe;
 			int final_job = sg.job1;
-			if (sg.zcode < 0) {
-				acc.query(Q.qid, T.rev, sg.qs, sg.qe, qw); acc.target(Q.base + T.rid, sg.rs, sg.re, tw);
+			if (sg.zcode < 0 && sg.ll_job < 0) {
 				const DpRes &e1 = Q.res[sg.job1];
-				sg.zcode = test_zdrop(opt, qw.data(), tw.data(), (uint32_t)e1.n_cigar, Q.cig[sg.job1], mat);
-				if (sg.zcode != 0) sg.job2 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, sg.zcode == 2 ? opt.zdrop_inv : opt.zdrop, 0);
+				if (zdrop_impossible(opt, e1, Q.cig[sg.job1])) { sg.zcode = 0; if (g_prof) g_ns[5] += 1; }
+				else {
+					if (g_prof) g_ns[6] += 1;
+					ScopeNs sc(7);
+					acc.query(Q.qid, T.rev, sg.qs, sg.qe, qw); acc.target(Q.base + T.rid, sg.rs, sg.re, tw);
+					int pos[2][2];
+					sg.max_zdrop = zdrop_walk(opt, qw.data(), tw.data(), (uint32_t)e1.n_cigar, Q.cig[sg.job1], mat, pos);
+					const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
+					if (!zdrop_wants_inversion_test(opt, sg.max_zdrop, pos)) sg.zcode = sg.max_zdrop > opt.zdrop ? 1 : 0;
+					else if (ll_on_device(opt, q_len, t_len)) {
+						// the window against its own reverse complement: query = the other strand, [L - (qs+pos11), +q_len)
+						sg.ll_job = request(Q, 1 - T.rev, T.rid, qlen - (sg.qs + pos[1][1]), q_len, sg.rs + pos[0][0], t_len, 0, 0, -1, 0, PGA_JOB_LL);
+						// whatever the answer, the second pass runs when both thresholds agree (they do in every asm preset)
+						if (opt.zdrop == opt.zdrop_inv) sg.job2 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, opt.zdrop, 0);
+					} else {
+						std::vector<uint8_t> qseq2((size_t)(q_len > 0 ? q_len : 0));
+						int q_off, t_off;
+						for (int i = 0; i < q_len; ++i) { int c = qw[pos[1][1] - i - 1]; qseq2[i] = (uint8_t)(c >= 4 ? 4 : 3 - c); }
+						const int score = ll_i16(q_len, qseq2.data(), mat, t_len, tw.data() + pos[0][0], opt.q, opt.e, &q_off, &t_off);
+						sg.zcode = (score >= opt.min_chain_score * opt.a && score >= opt.min_dp_max) ? 2 : (sg.max_zdrop > opt.zdrop ? 1 : 0);
+					}
+				}
+				if (sg.zcode > 0 && sg.job2 < 0) sg.job2 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, sg.zcode == 2 ? opt.zdrop_inv : opt.zdrop, 0);
+			}
+			if (sg.zcode < 0) {
+				if (!have(Q, sg.ll_job)) return false;
+				const int score = Q.res[sg.ll_job].score;
+				sg.zcode = (score >= opt.min_chain_score * opt.a && score >= opt.min_dp_max) ? 2 : (sg.max_zdrop > opt.zdrop ? 1 : 0);
+				if (sg.zcode > 0 && sg.job2 < 0) sg.job2 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, sg.zcode == 2 ? opt.zdrop_inv : opt.zdrop, 0);
 			}
 			if (sg.zcode != 0) { if (!have(Q, sg.job2)) return false; final_job = sg.job2; }
 			const DpRes &ez = Q.res[final_job];
@@ -712,7 +778,8 @@ struct Driver {
 		r.rs = T.rs1, r.re = T.re1;
 		if (!T.rev) r.qs = T.qs1, r.qe = T.qe1; else r.qs = qlen - T.qe1, r.qe = qlen - T.qs1;
 		if (r.has_p) {
-			acc.target(Q.base + T.rid, T.rs1, T.re1, tw); acc.query(Q.qid, (int)r.rev, T.qs1, T.qe1, qw);
+			{ ScopeNs sc(1); acc.target(Q.base + T.rid, T.rs1, T.re1, tw); acc.query(Q.qid, (int)r.rev, T.qs1, T.qe1, qw); }
+			ScopeNs sc(2);
 			update_extra(r, qw.data(), tw.data(), mat, opt.q, opt.e);
 		}
 		T.done = true;
@@ -733,17 +800,35 @@ struct Driver {
 			int ql = r1.rev ? r1.qs - r2.qe : r2.qs - r1.qe, tl = r2.rs - r1.re;
 			if (ql < opt.min_chain_score || ql > opt.max_gap) return 0;
 			if (tl < opt.min_chain_score || tl > opt.max_gap) return 0;
+			// qseq = r1.rev ? &qseq0[0][r2.qe] : &qseq0[1][qlen - r2.qs]; both windows are reversed before the local alignment
+			const int q_strand = r1.rev ? 0 : 1; const int32_t q_st = r1.rev ? r2.qe : qlen - r2.qs;
+			T.inv_ql = ql, T.inv_tl = tl;
+			int score, q_off, t_off;
+			if (ll_on_device(opt, ql, tl)) {
+				T.inv_ll_job = request(Q, q_strand, r1.rid, q_st, ql, r1.re, tl, 1, 0, -1, 0, PGA_JOB_LL);
+				T.inv_state = 3;
+				return 1;
+			}
 			std::vector<uint8_t> tw, qw;
 			acc.target(Q.base + r1.rid, r1.re, r2.rs, tw);
-			// qseq = r1.rev ? &qseq0[0][r2.qe] : &qseq0[1][qlen - r2.qs]
-			const int q_strand = r1.rev ? 0 : 1; const int32_t q_st = r1.rev ? r2.qe : qlen - r2.qs;
 			acc.query(Q.qid, q_strand, q_st, q_st + ql, qw);
 			std::reverse(qw.begin(), qw.end()); std::reverse(tw.begin(), tw.end());
-			int q_off, t_off;
-			int score = ll_i16(ql, qw.data(), mat, tl, tw.data(), opt.q, opt.e, &q_off, &t_off);
+			score = ll_i16(ql, qw.data(), mat, tl, tw.data(), opt.q, opt.e, &q_off, &t_off);
 			if (score < opt.min_dp_max) return 0;
 			q_off = ql - (q_off + 1), t_off = tl - (t_off + 1);
-			T.inv_q_off = q_off, T.inv_t_off = t_off, T.inv_ql = ql, T.inv_tl = tl;
+			T.inv_q_off = q_off, T.inv_t_off = t_off;
+			T.inv_job = request(Q, q_strand, r1.rid, q_st + q_off, ql - q_off, r1.re + t_off, tl - t_off, 0, (int)(opt.bw * 1.5), -1, opt.zdrop, EZ_EXTZ_ONLY);
+			T.inv_state = 1;
+		}
+		if (T.inv_state == 3) {
+			if (!have(Q, T.inv_ll_job)) return 1;
+			const DpRes &lr = Q.res[T.inv_ll_job];
+			T.inv_state = 2;
+			if (lr.score < opt.min_dp_max) return 0;
+			const int ql = T.inv_ql, tl = T.inv_tl;
+			const int q_off = ql - (lr.max_q + 1), t_off = tl - (lr.max_t + 1);
+			const int q_strand = r1.rev ? 0 : 1; const int32_t q_st = r1.rev ? r2.qe : qlen - r2.qs;
+			T.inv_q_off = q_off, T.inv_t_off = t_off;
 			T.inv_job = request(Q, q_strand, r1.rid, q_st + q_off, ql - q_off, r1.re + t_off, tl - t_off, 0, (int)(opt.bw * 1.5), -1, opt.zdrop, EZ_EXTZ_ONLY);
 			T.inv_state = 1;
 		}
@@ -843,6 +928,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	const int n_seq = S.n_seq;
 	const double t_align0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	out.assign((size_t)n_seq, {});
+	g_prof = getenv("PGA_VERBOSE") != nullptr;
 	Driver D(S, opt, k);
 	std::vector<QueryCtx> Q((size_t)n_seq);
 	// ---- regions (mm_gen_regs) and plans ----
@@ -910,7 +996,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 				for (size_t i = 0; i < q.list.size(); ++i) {
 					RegTask &T = *q.list[i];
 					if (T.is_inv) continue;
-					if (!T.planned) D.plan(q, T);
+					if (!T.planned) { ScopeNs sc(3); D.plan(q, T); }
 					if (!T.done) {
 						Reg r2;
 						if (!D.advance(q, T, r2)) { waiting = true; continue; }
@@ -929,6 +1015,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 					}
 				}
 				if (waiting) { ++unfinished; return; }
+				ScopeNs sc_fin(4);
 				// ---- all regions aligned: filters, ranking, mapq (align.c:1013-1021, map.c:340-341) ----
 				std::vector<Reg> regs; regs.reserve(q.list.size());
 				for (RegTask *t : q.list) regs.push_back(std::move(t->r));
@@ -939,6 +1026,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 				out[qi] = std::move(regs);
 				q.finished = true; q.pool.clear(); q.list.clear(); q.a.clear(); q.a.shrink_to_fit();
 			});
+			if (g_prof) { fprintf(stderr, "[pga]   host phases (thread-summed s): segments %.3f, fetch %.3f, update_extra %.3f, plan %.3f, finish %.3f; z-drop test skipped %lld, run %lld (%.3f s)\n", g_ns[0] * 1e-9, g_ns[1] * 1e-9, g_ns[2] * 1e-9, g_ns[3] * 1e-9, g_ns[4] * 1e-9, (long long)g_ns[5], (long long)g_ns[6], g_ns[7] * 1e-9); for (auto &x : g_ns) x = 0; }
 			if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   round %d: host advance %.3f s\n", round, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_adv0);
 			if (unfinished.load() == 0) break;
 			bool any_pending = false; for (auto &q : Q) any_pending |= !q.pending.empty();

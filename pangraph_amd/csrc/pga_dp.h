@@ -25,6 +25,11 @@ struct DpRes {           // ksw_extz_t (ksw2.h:31-40)
 	uint64_t cigar_off;  // into the CIGAR pool returned with the batch
 };
 
+// DpJob.flag bit (not a ksw2 flag): the job is a local-alignment score query (ksw_ll_i16), answered by pga_ll.hip;
+// the result comes back as score / max_q (qe) / max_t (te)
+#define PGA_JOB_LL 0x8000
+#define PGA_LL_MAX_LEN 10240     // longest query (padded to 8) / target the LL kernel holds in LDS
+
 struct DpParams { int32_t q, e, q2, e2, sc_mch, sc_mis, sc_ambi; }; // sc_* are matrix entries mat[0], mat[1], mat[24]
 
 size_t dp_slab_bytes(int qlen, int tlen, int w);

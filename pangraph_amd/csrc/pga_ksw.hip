@@ -338,7 +338,8 @@ void launch_extd2_wide(unsigned n_blocks, int r_cap, int seq_cap, bool exact, co
 //   2,3,4  workgroup kernel (pga_ksw_wide.hip) by LDS footprint of the band ring + sequences: <= 48 KB (three workgroups
 //          per CU), <= 76 KB (two), <= 152 KB (one)
 //   5      single-wave kernel with rows in the HBM slab (targets wider than LDS can hold; not reached by pangraph's windows)
-#define DP_NCLASS 6
+//   6      local-alignment score queries of the inversion test (pga_ll.hip)
+#define DP_NCLASS 7
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -348,9 +349,14 @@ static inline int wide_ring(const DpJob &j)
 	return R > T ? T : R;
 }
 static inline int wide_seqcap(const DpJob &j) { return ((j.qlen > j.tlen ? j.qlen : j.tlen) + 15) / 16 * 16; }
+size_t ll_lds_bytes(int t_cap);
+void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter,
+                   unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st);
+
 static int dp_class(const DpJob &j, size_t need)
 {
 	(void)need;
+	if (j.flag & PGA_JOB_LL) return 6;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
@@ -367,20 +373,34 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	const size_t n = jobs.size();
 	if (n == 0) return;
 	std::vector<uint32_t> cls[DP_NCLASS];
-	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0, 0};
+	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0, 0, 0};
 	std::vector<size_t> need(n);
 	unsigned long long cig_total = 0;
 	for (size_t i = 0; i < n; ++i) {
-		need[i] = dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
+		const bool is_ll = jobs[i].flag & PGA_JOB_LL;
+		need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
 		const int c = dp_class(jobs[i], need[i]);
 		cls[c].push_back((uint32_t)i);
 		if (need[i] > slab_max[c]) slab_max[c] = need[i];
-		cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
+		if (!is_ll) cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
 	}
 	res.resize(n);
-	DBuf<uint32_t> d_pool((size_t)cig_total);
+	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
 	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
-	for (int c = 0; c < DP_NCLASS; ++c) {
+	// The classes are independent persistent launches: each gets its own stream, so the handful of huge problems
+	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
+	// (three streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
+	// land on the same queue run back to back)
+	static hipStream_t lane_stream_dev[16][3] = {};
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 1, 1, 1, 2};   // tiles | few huge problems | extensions + inversion queries
+	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
+	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
+	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; DBuf<uint8_t> d_slab; size_t n_waves; hipEvent_t e0, e1; };
+	std::vector<Launch> L;
+	size_t budget = (size_t)96 << 30;
+	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 * 3 < budget) budget = fr / 4 * 3; }
+	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
+	for (int c = DP_NCLASS - 1; c >= 0; --c) {               // longest-running classes first
 		if (cls[c].empty()) continue;
 		std::vector<uint32_t> &ids = cls[c];
 		// biggest problems first, so that the persistent waves finish together (the many small tiles of the
@@ -389,36 +409,62 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
 		std::vector<DpJob> jb(ids.size());
 		for (size_t i = 0; i < ids.size(); ++i) jb[i] = jobs[ids[i]];
-		DBuf<DpJob> d_jobs; d_jobs.upload(jb, st);
-		DBuf<DpRes> d_r(ids.size());
-		DBuf<uint32_t> d_cnt(1); d_cnt.zero(st);
-		size_t n_waves = c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
+		L.emplace_back();
+		Launch &X = L.back();
+		X.c = c; X.ids = &ids;
+		X.d_jobs.upload(jb, st);
+		PGA_HIP(hipStreamSynchronize(st));                   // jb is about to go out of scope
+		X.d_r.alloc(ids.size());
+		X.d_cnt.alloc(1); X.d_cnt.zero(st);
+		size_t n_waves = c == 6 ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
 		if (n_waves > ids.size()) n_waves = ids.size();
-		size_t budget = (size_t)96 << 30;
-		{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 * 3 < budget) budget = fr / 4 * 3; }
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
-		DBuf<uint8_t> d_slab(n_waves * slab_max[c]);
-		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launching dp class %d: %zu problems on %zu waves, slab %zu B\n", c, ids.size(), n_waves, slab_max[c]); fflush(stderr); }
-		EventTimer et(st);
-		if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)n_waves, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
+		X.n_waves = n_waves;
+		X.d_slab.alloc(n_waves * slab_max[c]);
+		budget -= std::min(budget, n_waves * slab_max[c]);
+	}
+	hipEvent_t ready;
+	PGA_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+	PGA_HIP(hipEventRecord(ready, st));
+	for (Launch &X : L) {
+		const int c = X.c;
+		std::vector<uint32_t> &ids = *X.ids;
+		hipStream_t &ls = lane_stream[lane_of_class[c]];
+		if (!ls) PGA_HIP(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+		hipStream_t cs = ls;
+		PGA_HIP(hipStreamWaitEvent(cs, ready, 0));
+		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
+		PGA_HIP(hipEventRecord(X.e0, cs));
+		if (c == 6) {
+			int t_cap = 16;
+			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
+			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)X.d_slab.p, slab_max[c] / 8, X.d_r.p, cs);
+		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c <= 4) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
-			launch_extd2_wide((unsigned)n_waves, r_cap, seq_cap, exact, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c], d_r.p, d_pool.p, d_cursor.p, cig_total, st);
-		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)n_waves), dim3(64), 0, st, d_jobs.p, (uint32_t)ids.size(), d_nt4, P, d_cnt.p, d_slab.p, slab_max[c],
-		                        d_r.p, d_pool.p, d_cursor.p, cig_total);
+			launch_extd2_wide((unsigned)X.n_waves, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c],
+		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
-		if (getenv("PGA_VERBOSE")) { fprintf(stderr, "[pga]     launched\n"); fflush(stderr); }
-		const double ms = et.stop();
+		PGA_HIP(hipEventRecord(X.e1, cs));
+	}
+	for (Launch &X : L) {
+		const int c = X.c;
+		std::vector<uint32_t> &ids = *X.ids;
+		PGA_HIP(hipEventSynchronize(X.e1));
+		float msf = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1));
+		const double ms = msf;
+		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
 			tm->kern[K_EXTD2].ms += ms; tm->kern[K_EXTD2].launches += 1; tm->kern[K_EXTD2].alg_bytes += 0.5 * bases; tm->dp_bases += bases; // 2-bit packed q+t reads; CIGAR bytes added below
-			if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms, slab %.1f KB x %zu waves\n", c, ids.size(), ms, slab_max[c] / 1024.0, n_waves);
+			if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms, slab %.1f KB x %zu waves\n", c, ids.size(), ms, slab_max[c] / 1024.0, X.n_waves);
 		}
-		std::vector<DpRes> r = d_r.download(st);
+		std::vector<DpRes> r = X.d_r.download(lane_stream[lane_of_class[c]]);
 		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];
-		if (c >= 2 && c <= 4 && getenv("PGA_VERBOSE")) {
+		if (c >= 2 && c <= 4 && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
@@ -430,6 +476,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			        100 * ext / m, 100 * zd / m, mt / m, dg / m, big);
 		}
 	}
+	(void)hipEventDestroy(ready);
 	unsigned long long used = d_cursor.download(st)[0];
 	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");
 	if (tm) { tm->kern[K_EXTD2].alg_bytes += 4.0 * (double)used; tm->dp_cigar_ops += (double)used; }

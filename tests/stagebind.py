@@ -120,6 +120,21 @@ def ref_extd2(dll, q: np.ndarray, t: np.ndarray, mat, gapo, gape, gapo2, gape2, 
                 mte_q=ez.mte_q, score=ez.score, reach_end=ez.reach_end, cigar=cig)
 
 
+def ref_ll(dll, q: np.ndarray, t: np.ndarray, mat, gapo, gape):
+    """ksw_ll_i16 of the reference build (ksw2_ll_sse.c:69-151): (score, qe, te)"""
+    dll.ksw_ll_qinit.restype = C.c_void_p
+    dll.ksw_ll_qinit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    dll.ksw_ll_i16.restype = C.c_int
+    dll.ksw_ll_i16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    q = np.ascontiguousarray(q, dtype=np.uint8); t = np.ascontiguousarray(t, dtype=np.uint8)
+    m = (C.c_int8 * 25)(*mat)
+    qp = dll.ksw_ll_qinit(None, 2, len(q), q.ctypes.data, 5, C.cast(m, C.c_void_p))
+    qe, te = C.c_int(-1), C.c_int(-1)
+    sc = dll.ksw_ll_i16(qp, len(t), t.ctypes.data, gapo, gape, C.byref(qe), C.byref(te))
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]; libc.free(qp)
+    return sc, qe.value, te.value
+
+
 def oracle_extd2(dll, q, t, mat, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag):
     ez = pgo_extz_t()
     C.memset(C.byref(ez), 0, C.sizeof(ez))
