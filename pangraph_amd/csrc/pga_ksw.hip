@@ -17,6 +17,7 @@
 // Persistent launch: a fixed grid of waves pulls problems from an atomic queue (problem sizes are ragged).
 #include "pga_common.h"
 #include "pga_dp.h"
+#include <chrono>
 #include <cstdio>
 
 namespace pga {
@@ -330,7 +331,7 @@ void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jo
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact);
-void launch_extd2_wide(unsigned n_blocks, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 // Problem classes (each is one persistent launch):
@@ -372,6 +373,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
 	if (n == 0) return;
+	const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	std::vector<uint32_t> cls[DP_NCLASS];
 	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0, 0, 0};
 	std::vector<size_t> need(n);
@@ -389,18 +391,25 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
 	// The classes are independent persistent launches: each gets its own stream, so the handful of huge problems
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
-	// (three streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
+	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static hipStream_t lane_stream_dev[16][3] = {};
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 1, 1, 1, 2};   // tiles | few huge problems | extensions + inversion queries
+	static hipStream_t lane_stream_dev[16][4] = {};
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
 	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; DBuf<uint8_t> d_slab; size_t n_waves; hipEvent_t e0, e1; };
 	std::vector<Launch> L;
+	L.reserve(DP_NCLASS);
 	size_t budget = (size_t)96 << 30;
 	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 * 3 < budget) budget = fr / 4 * 3; }
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
-	for (int c = DP_NCLASS - 1; c >= 0; --c) {               // longest-running classes first
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t_begin = now();
+	hipEvent_t ready;
+	PGA_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+	// every class is prepared and launched in turn, the classes with few, long problems first: they are already running
+	// while the host still lays out the million-tile classes
+	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
 		std::vector<uint32_t> &ids = cls[c];
 		// biggest problems first, so that the persistent waves finish together (the many small tiles of the
@@ -413,7 +422,6 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		Launch &X = L.back();
 		X.c = c; X.ids = &ids;
 		X.d_jobs.upload(jb, st);
-		PGA_HIP(hipStreamSynchronize(st));                   // jb is about to go out of scope
 		X.d_r.alloc(ids.size());
 		X.d_cnt.alloc(1); X.d_cnt.zero(st);
 		size_t n_waves = c == 6 ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
@@ -422,17 +430,15 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		X.n_waves = n_waves;
 		X.d_slab.alloc(n_waves * slab_max[c]);
 		budget -= std::min(budget, n_waves * slab_max[c]);
-	}
-	hipEvent_t ready;
-	PGA_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-	PGA_HIP(hipEventRecord(ready, st));
-	for (Launch &X : L) {
-		const int c = X.c;
-		std::vector<uint32_t> &ids = *X.ids;
+		PGA_HIP(hipEventRecord(ready, st));
+		PGA_HIP(hipStreamSynchronize(st));                   // jb goes out of scope at the end of this iteration
 		hipStream_t &ls = lane_stream[lane_of_class[c]];
-		if (!ls) PGA_HIP(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+		if (!ls) {
+			int prio_lo = 0, prio_hi = 0;
+			PGA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // numerically lower = higher priority
+			PGA_HIP(hipStreamCreateWithPriority(&ls, hipStreamNonBlocking, lane_of_class[c] == 0 ? prio_lo : prio_hi));
+		}
 		hipStream_t cs = ls;
-		PGA_HIP(hipStreamWaitEvent(cs, ready, 0));
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
 		if (c == 6) {
@@ -444,12 +450,14 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
-			launch_extd2_wide((unsigned)X.n_waves, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			const int nt = c == 4 ? 1024 : c == 3 ? 512 : 256;
+			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipEventRecord(X.e1, cs));
 	}
+	const double t_launched = now();
 	for (Launch &X : L) {
 		const int c = X.c;
 		std::vector<uint32_t> &ids = *X.ids;
@@ -477,11 +485,13 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		}
 	}
 	(void)hipEventDestroy(ready);
+	const double t_waited = now();
 	unsigned long long used = d_cursor.download(st)[0];
 	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");
 	if (tm) { tm->kern[K_EXTD2].alg_bytes += 4.0 * (double)used; tm->dp_cigar_ops += (double)used; }
 	cigars.resize((size_t)used);
 	if (used) { PGA_HIP(hipMemcpyAsync(cigars.data(), d_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st)); }
+	if (verbose) fprintf(stderr, "[pga]     dp_run host: classify %.3f, prepare+launch %.3f, wait+collect %.3f, CIGAR download %.3f s\n", t_begin - t_enter, t_launched - t_begin, t_waited - t_launched, now() - t_waited);
 }
 
 } // namespace pga

@@ -27,7 +27,6 @@ namespace pga {
 #define EZ_APPROX_DROP 0x10
 #define EZ_EXTZ_ONLY  0x40
 #define EZ_REV_CIGAR  0x80
-#define WIDE_NT 256
 #define WBT 64
 #define WIDE_LDS_MAX (152 * 1024)   // dynamic LDS the kernel may ask for (160 KB per CU minus its static arrays); pga_ksw.hip sizes classes with it
 
@@ -43,6 +42,7 @@ __device__ __forceinline__ void diag_range_w(int r, int qlen, int tlen, int w, i
 	st0 = st, en0 = en;
 }
 
+template <int WIDE_NT>
 __global__ __launch_bounds__(WIDE_NT)
 void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes, int r_cap, int seq_cap, int exact_rows,
@@ -51,6 +51,7 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 	extern __shared__ __align__(16) uint8_t dyn[];
 	__shared__ uint32_t s_job;
 	__shared__ long long s_part[WIDE_NT / 64];
+	__builtin_amdgcn_s_setprio(3);      // few, latency-bound workgroups: win issue arbitration against the tile kernels sharing the CU
 	__shared__ uint8_t s_win[WBT * WBT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint8_t *slab = slab_all + (size_t)blockIdx.x * slab_bytes;
@@ -335,13 +336,23 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 
 size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact) { return (size_t)r_cap * 10 + (exact ? (size_t)r_cap * 4 : 0) + 2 * (size_t)seq_cap; }
 
-void launch_extd2_wide(unsigned n_blocks, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+template <int NT> static void launch_wide_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab,
+                                             size_t slab_bytes, int r_cap, int seq_cap, int exact, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
+{
+	static bool attr_set = false;
+	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_MAX)); attr_set = true; }
+	hipLaunchKernelGGL(k_extd2_wide<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact, res, pool, cursor, pool_cap);
+}
+
+// n_threads: 256 for many problems (several workgroups per CU), 512 / 1024 when a class holds few, large problems:
+// a workgroup that has a CU to itself needs the extra waves to hide its LDS latency
+void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
 	const size_t lds = wide_lds_bytes(r_cap, seq_cap, exact);
-	static bool attr_set = false;
-	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_MAX)); attr_set = true; }
-	hipLaunchKernelGGL(k_extd2_wide, dim3(n_blocks), dim3(WIDE_NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
+	if (n_threads >= 1024) launch_wide_nt<1024>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
+	else if (n_threads >= 512) launch_wide_nt<512>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
+	else launch_wide_nt<256>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

@@ -27,6 +27,7 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 	__shared__ uint32_t s_job;
 	__shared__ unsigned long long s_part[LL_NT / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	__builtin_amdgcn_s_setprio(3);
 	int16_t *Hb[3] = { (int16_t*)dyn, (int16_t*)dyn + t_cap, (int16_t*)dyn + 2 * t_cap };
 	int16_t *Eb[2] = { (int16_t*)dyn + 3 * t_cap, (int16_t*)dyn + 4 * t_cap };
 	int16_t *Fr = (int16_t*)dyn + 5 * t_cap;
