@@ -644,23 +644,16 @@ __global__ void k_fix_pred(const uint64_t *__restrict__ seg_start, uint32_t n_se
 __device__ __forceinline__ int32_t rl(int32_t v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 
 __global__ __launch_bounds__(64)
-void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
-                 const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, u128 *__restrict__ z_all,
-                 uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
-                 ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out, unsigned long long *__restrict__ prof)
+void k_bt_list(int n_seq, const uint64_t *__restrict__ q_aoff, const int32_t *__restrict__ f_all, int32_t *__restrict__ t_all, u128 *__restrict__ z_all, ChainParams P,
+               int64_t *__restrict__ n_z_out, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out)
 {
-	__shared__ RsLds L;
 	const int q = blockIdx.x, lane = threadIdx.x;
 	if (q >= n_seq) return;
 	const uint64_t b = q_aoff[q];
 	const int64_t n = (int64_t)(q_aoff[q + 1] - b);
-	if (lane == 0) n_u_out[q] = 0, n_v_out[q] = 0;
+	if (lane == 0) n_u_out[q] = 0, n_v_out[q] = 0, n_z_out[q] = 0;
 	if (n == 0) return;
-	const unsigned long long c0 = wall_clock64();
-	const u128 *A = a + b; const int32_t *f = f_all + b, *p = p_all + b;
-	int32_t *t = t_all + b, *v = v_all + b;
-	u128 *z = z_all + b, *w = w_all + b, *out = out_all + b;
-	uint64_t *u = u_all + b, *u2 = u2_all + b;
+	const int32_t *f = f_all + b; int32_t *t = t_all + b; u128 *z = z_all + b;
 	// candidate ends in index order (order-preserving compaction), marks cleared
 	int64_t n_z = 0;
 	for (int64_t i0 = 0; i0 < n; i0 += 64) {
@@ -671,13 +664,26 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 		if (keep) { const int64_t o = n_z + __popcll(m & ((1ULL << lane) - 1)); z[o].x = (uint64_t)f[i]; z[o].y = (uint64_t)i; }
 		n_z += __popcll(m);
 	}
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	if (n_z == 0) return;
-	if (lane == 0) L.prof[0] = L.prof[1] = L.prof[2] = L.prof[3] = 0;
-	const unsigned long long cs = wall_clock64();
-	radix_sort_128x_wave(z, n_z, L, lane);
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	const unsigned long long c1 = wall_clock64();
+	if (lane == 0) n_z_out[q] = n_z;
+}
+
+__global__ __launch_bounds__(64)
+void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
+               const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, const u128 *__restrict__ z_all, const int64_t *__restrict__ n_z_in,
+               uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
+               ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out, unsigned long long *__restrict__ prof)
+{
+	const int q = blockIdx.x, lane = threadIdx.x;
+	if (q >= n_seq) return;
+	const uint64_t b = q_aoff[q];
+	const int64_t n = (int64_t)(q_aoff[q + 1] - b);
+	const int64_t n_z = n_z_in[q];
+	if (n == 0 || n_z == 0) return;
+	const unsigned long long c0 = wall_clock64(), c1 = c0;
+	const u128 *A = a + b; const int32_t *f = f_all + b, *p = p_all + b;
+	int32_t *t = t_all + b, *v = v_all + b;
+	const u128 *z = z_all + b; u128 *w = w_all + b, *out = out_all + b;
+	uint64_t *u = u_all + b, *u2 = u2_all + b;
 	// ---- walks (every lane executes the same control flow) ----
 	const int32_t max_drop = P.bw;
 	int64_t n_v = 0; int32_t n_u = 0;
@@ -755,7 +761,6 @@ void k_backtrack(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__r
 	if (prof && lane == 0) {
 		const unsigned long long c3 = wall_clock64();
 		atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2);
-		atomicAdd(&prof[6], cs - c0); for (int k = 0; k < 4; ++k) atomicAdd(&prof[7 + k], L.prof[k]);
 		atomicMax(&prof[3], c1 - c0); atomicMax(&prof[4], c2 - c1); atomicMax(&prof[5], c3 - c2);
 	}
 }
@@ -842,15 +847,23 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	{
 		EventTimer et(st);
 		DBuf<unsigned long long> prof(12); prof.zero(st);
+		DBuf<int64_t> n_z((size_t)n_seq);
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
-		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
+		hipLaunchKernelGGL(k_bt_list, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, f.p, t.p, z.p, P, n_z.p, n_u.p, n_v.p);
+		double ms_list = 0, ms_sort = 0;
+		if (verbose) { ms_list = et.stop(); }
+		EventTimer et2(st);
+		replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st);
+		if (verbose) ms_sort = et2.stop();
+		EventTimer et3(st);
+		hipLaunchKernelGGL(k_bt_walk, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, n_z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
 		                   verbose ? prof.p : (unsigned long long*)nullptr);
-		const double ms = et.stop();
+		const double ms_walk = et3.stop();
+		const double ms = verbose ? ms_list + ms_sort + ms_walk : et.stop();
 		if (verbose) {
 			std::vector<unsigned long long> pr = prof.download(st);   // wall_clock64 ticks at 100 MHz
-			fprintf(stderr, "[pga]   backtrack: %.3f ms; per-query max (ms): list+sort %.2f, walks %.2f, compact %.2f; sums %.1f %.1f %.1f\n", ms,
-			        pr[3] * 1e-5, pr[4] * 1e-5, pr[5] * 1e-5, pr[0] * 1e-5, pr[1] * 1e-5, pr[2] * 1e-5);
-			fprintf(stderr, "[pga]   backtrack sums (ms): list %.1f | sort: vary %.1f hist %.1f walk %.1f runs %.1f\n", pr[6] * 1e-5, pr[7] * 1e-5, pr[8] * 1e-5, pr[9] * 1e-5, pr[10] * 1e-5);
+			fprintf(stderr, "[pga]   backtrack: %.3f ms = candidate lists %.3f + sort replay %.3f + walks %.3f (per-query max: walks %.2f, compact %.2f ms)\n", ms, ms_list, ms_sort, ms_walk,
+			        pr[4] * 1e-5, pr[5] * 1e-5);
 		}
 		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
 	}

@@ -35,4 +35,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vector<uint64_t> &q_aoff, ChainResult &C, const std::vector<int32_t> &rep_len,
                  std::vector<std::vector<Reg>> &out, int n_threads, Timers *tm, hipStream_t st);
 
+// exact replay of minimap2's unstable radix_sort_128x on the flagged arrays [off[s], off[s+1]) of a (pga_sort_replay.hip)
+void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st);
+
 } // namespace pga

@@ -255,16 +255,13 @@ __global__ void k_tie_flags(const uint64_t *__restrict__ xs, const uint64_t *__r
 		if (i + 1 < q_aoff[lo + 1]) q_tie[lo] = 1;
 	}
 }
-__global__ __launch_bounds__(64)
-void k_sort_exact(int n_seq, const uint32_t *__restrict__ q_tie, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a_unsorted, u128 *__restrict__ a_sorted)
+// queries whose anchors hold equal keys restart from the raw order
+__global__ void k_copy_tied(int n_seq, const uint32_t *__restrict__ q_tie, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a_unsorted, u128 *__restrict__ a_sorted)
 {
-	__shared__ RsLds L;
-	const int q = blockIdx.x, lane = threadIdx.x;
+	const int q = blockIdx.x;
 	if (q >= n_seq || !q_tie[q]) return;
 	const uint64_t b = q_aoff[q], e = q_aoff[q + 1];
-	for (uint64_t i = b + lane; i < e; i += 64) a_sorted[i] = a_unsorted[i];
-	__threadfence_block();
-	radix_sort_128x_wave(a_sorted + b, (int64_t)(e - b), L, lane);
+	for (uint64_t i = b + (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < e; i += (uint64_t)gridDim.y * blockDim.x) a_sorted[i] = a_unsorted[i];
 }
 
 // ---- host orchestration ----
@@ -385,7 +382,8 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	hipLaunchKernelGGL(k_join128, dim3(nba), dim3(256), 0, st, x1.p, y1.p, n_a, O.a.p);
 	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
 	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, a_raw.p, q_tie.p);
-	hipLaunchKernelGGL(k_sort_exact, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
+	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
+	replay_sort_segments(O.a.p, n_a, O.q_aoff.p, nullptr, n_seq, q_tie.p, st);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipStreamSynchronize(st));
 	if (getenv("PGA_VERBOSE")) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ void rs_flush(u128 *beg, RsLds &L, int d, int lane)
 }
 
 // one level (ksort.h:118-146) on [beg, beg+n)
-__device__ inline void rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane)
+__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane)
 {
 	const unsigned long long t0 = wall_clock64();
 	for (int d = lane; d < 256; d += 64) L.head[d] = 0, L.wbase[d] = RS_NONE;
@@ -61,7 +61,7 @@ __device__ inline void rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 	rs_fence_wg();
 	const unsigned long long t1 = wall_clock64();
 	if (lane == 0) L.prof[1] += t1 - t0;
-	if (!__ballot(diff)) return;                               // one bucket: the walk is the identity
+	if (!__ballot(diff)) return false;                         // one bucket: the walk is the identity
 	if (lane == 0) { uint32_t pos = 0; for (int d = 0; d < 256; ++d) { const uint32_t c = L.head[d]; L.head[d] = pos; pos += c; L.tail[d] = pos; } }
 	rs_fence_wg();
 	for (int d = 0; d < 256; ++d) {
@@ -115,6 +115,7 @@ __device__ inline void rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 	}
 	rs_fence_wg();
 	if (lane == 0) L.prof[2] += wall_clock64() - t1;
+	return true;
 }
 
 // insertion-sort up to 64 records [b, e) through LDS: lane 0 sorts
@@ -130,92 +131,98 @@ __device__ __forceinline__ void rs_small_wave(u128 *beg, int64_t b, int64_t e, R
 	rs_fence_wg();
 }
 
+// Runs of records that agree on x >> hi_shift, found 64 records at a time: runs of <= 64 records are insertion-sorted
+// here (in LDS, one lane per run; ksort.h:142), longer ones are handed to big(offset, length).
+template <class Big>
+__device__ inline void rs_runs_wave(u128 *beg, int64_t n, int hi_shift, RsLds &L, int lane, Big big)
+{
+	int64_t rb = 0;
+	while (rb < n) {
+		// a window of 64 records starting at rb: which of them start a new run?
+		const int64_t pos = rb + lane;
+		const bool in = pos < n;
+		u128 rec; rec.x = ~0ULL, rec.y = 0;
+		if (in) rec = ld128(&beg[pos]);
+		const uint64_t hk = in ? (hi_shift >= 64 ? 0ULL : rec.x >> hi_shift) : ~0ULL;
+		const uint64_t hi0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hk >> 32), 0) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)hk, 0);
+		const uint32_t hp_lo = (uint32_t)__shfl((int)(uint32_t)(hk & 0xffffffffULL), lane > 0 ? lane - 1 : 0), hp_hi = (uint32_t)__shfl((int)(uint32_t)(hk >> 32), lane > 0 ? lane - 1 : 0);
+		const uint64_t hp = lane == 0 ? hi0 : ((uint64_t)hp_hi << 32 | (uint64_t)hp_lo);
+		const bool start = in && lane > 0 && hk != hp;
+		const unsigned long long sm = __ballot(start);
+		const int n_in = (int)(n - rb < 64 ? n - rb : 64);
+		const bool last_complete = (rb + n_in >= n);
+		const unsigned long long starts = sm | 1ULL;                               // bit 0: the run at rb
+		const int n_runs = __popcll(starts);
+		const int n_sort = last_complete ? n_runs : n_runs - 1;
+		if (n_sort == 0) {
+			// a single run that continues beyond the window: find its end
+			int64_t re = rb + n_in;
+			for (;;) {
+				const int64_t p2 = re + lane;
+				const bool brk = p2 >= n || (hi_shift >= 64 ? 0ULL : beg[p2 < n ? p2 : n - 1].x >> hi_shift) != hi0;
+				const unsigned long long bm = __ballot(brk);
+				if (bm) { re += __ffsll((long long)bm) - 1; break; }
+				re += 64;
+			}
+			if (re - rb > 64) big(rb, re - rb);
+			else rs_small_wave(beg, rb, re, L, lane);
+			rb = re;
+			continue;
+		}
+		// complete runs inside the window: run r spans [s_r, s_{r+1}); the last run of the window is complete only
+		// if the window reaches the end of the array, otherwise it restarts the next window.  Lane r sorts run r.
+		int my_b = -1, my_e = -1; int64_t next_rb = rb + n_in;
+		{
+			unsigned long long mrest = starts; int r = 0, prev = -1;
+			while (mrest) {
+				const int bpos = __ffsll((long long)mrest) - 1;
+				mrest &= mrest - 1;
+				if (prev >= 0 && r - 1 == lane) my_b = prev, my_e = bpos;
+				prev = bpos; ++r;
+			}
+			if (last_complete) { if (n_runs - 1 == lane) my_b = prev, my_e = n_in; }
+			else next_rb = rb + prev;
+		}
+		// only windows holding an out-of-order run are rewritten
+		const uint32_t xlo = (uint32_t)__shfl((int)(uint32_t)rec.x, lane > 0 ? lane - 1 : 0), xhi = (uint32_t)__shfl((int)(uint32_t)(rec.x >> 32), lane > 0 ? lane - 1 : 0);
+		const uint64_t xprev = (uint64_t)xhi << 32 | xlo;
+		const bool desc = in && lane > 0 && !start && rec.x < xprev && pos < next_rb;   // inside a complete run, smaller than its left neighbour
+		if (__ballot(desc)) {
+			L.ins[lane] = rec;
+			rs_fence_wave();
+			if (my_b >= 0 && my_e - my_b > 1) rs_insertion(L.ins + my_b, L.ins + my_e);
+			rs_fence_wave();
+			if (pos < next_rb) beg[pos] = L.ins[lane];
+			rs_fence_wg();
+		}
+		rb = next_rb;
+	}
+}
+
+// bits that differ somewhere in [beg, beg+n)
+__device__ inline uint64_t rs_varying_bits(const u128 *beg, int64_t n, int lane)
+{
+	uint64_t o = 0, a = ~0ULL;
+	for (int64_t i = lane; i < n; i += 64) { const uint64_t x = beg[i].x; o |= x; a &= x; }
+	uint32_t olo = (uint32_t)o, ohi = (uint32_t)(o >> 32), alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		olo |= (uint32_t)__shfl_xor((int)olo, d); ohi |= (uint32_t)__shfl_xor((int)ohi, d);
+		alo &= (uint32_t)__shfl_xor((int)alo, d); ahi &= (uint32_t)__shfl_xor((int)ahi, d);
+	}
+	return ((uint64_t)ohi << 32 | olo) ^ ((uint64_t)ahi << 32 | alo);
+}
+
+// the whole sort by one wave (small arrays, e.g. the chains of one query)
 __device__ inline void radix_sort_128x_wave(u128 *beg, int64_t n, RsLds &L, int lane)
 {
 	if (n <= 64) { rs_small_wave(beg, 0, n, L, lane); return; }
-	// bits that differ somewhere in the array
-	const unsigned long long t0 = wall_clock64();
-	uint64_t vary;
-	{
-		uint64_t o = 0, a = ~0ULL;
-		for (int64_t i = lane; i < n; i += 64) { const uint64_t x = beg[i].x; o |= x; a &= x; }
-		uint32_t olo = (uint32_t)o, ohi = (uint32_t)(o >> 32), alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
-#pragma unroll
-		for (int d = 32; d >= 1; d >>= 1) {
-			olo |= (uint32_t)__shfl_xor((int)olo, d); ohi |= (uint32_t)__shfl_xor((int)ohi, d);
-			alo &= (uint32_t)__shfl_xor((int)alo, d); ahi &= (uint32_t)__shfl_xor((int)ahi, d);
-		}
-		vary = ((uint64_t)ohi << 32 | olo) ^ ((uint64_t)ahi << 32 | alo);
-	}
-	if (lane == 0) L.prof[0] += wall_clock64() - t0;
+	const uint64_t vary = rs_varying_bits(beg, n, lane);
 	bool single_run = true;                                   // no level above has split the array yet
 	for (int shift = 56; shift >= 0; shift -= 8) {
 		if (((vary >> shift) & 255) == 0) continue;            // identity at this level for every run
 		if (single_run) { rs_level_wave(beg, n, shift, L, lane); single_run = false; continue; }
-		// runs of equal higher-order bytes, found 64 records at a time from a known run start
-		int64_t rb = 0;
-		const unsigned long long tr = wall_clock64(), w0 = L.prof[1] + L.prof[2];
-		while (rb < n) {
-			// a window of 64 records starting at rb, staged in LDS: which of them start a new run?
-			const int64_t pos = rb + lane;
-			const bool in = pos < n;
-			u128 rec; rec.x = ~0ULL, rec.y = 0;
-			if (in) rec = ld128(&beg[pos]);
-			const uint64_t hk = in ? rec.x >> (shift + 8) : ~0ULL;
-			const uint64_t hi0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hk >> 32), 0) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)hk, 0);
-			const uint32_t hp_lo = (uint32_t)__shfl((int)(uint32_t)(hk & 0xffffffffULL), lane > 0 ? lane - 1 : 0), hp_hi = (uint32_t)__shfl((int)(uint32_t)(hk >> 32), lane > 0 ? lane - 1 : 0);
-			const uint64_t hp = lane == 0 ? hi0 : ((uint64_t)hp_hi << 32 | (uint64_t)hp_lo);
-			const bool start = in && lane > 0 && hk != hp;
-			const unsigned long long sm = __ballot(start);
-			const int n_in = (int)(n - rb < 64 ? n - rb : 64);
-			const bool last_complete = (rb + n_in >= n);
-			const unsigned long long starts = sm | 1ULL;                               // bit 0: the run at rb
-			const int n_runs = __popcll(starts);
-			const int n_sort = last_complete ? n_runs : n_runs - 1;
-			if (n_sort == 0) {
-				// a single run that continues beyond the window: find its end
-				int64_t re = rb + n_in;
-				for (;;) {
-					const int64_t p2 = re + lane;
-					const bool brk = p2 >= n || (beg[p2].x >> (shift + 8)) != hi0;
-					const unsigned long long bm = __ballot(brk);
-					if (bm) { re += __ffsll((long long)bm) - 1; break; }
-					re += 64;
-				}
-				if (re - rb > 64) rs_level_wave(beg + rb, re - rb, shift, L, lane);
-				else rs_small_wave(beg, rb, re, L, lane);
-				rb = re;
-				continue;
-			}
-			// complete runs inside the window: run r spans [s_r, s_{r+1}); the last run of the window is complete only
-			// if the window reaches the end of the array, otherwise it restarts the next window.  Lane r sorts run r.
-			int my_b = -1, my_e = -1; int64_t next_rb = rb + n_in;
-			{
-				unsigned long long mrest = starts; int r = 0, prev = -1;
-				while (mrest) {
-					const int bpos = __ffsll((long long)mrest) - 1;
-					mrest &= mrest - 1;
-					if (prev >= 0 && r - 1 == lane) my_b = prev, my_e = bpos;
-					prev = bpos; ++r;
-				}
-				if (last_complete) { if (n_runs - 1 == lane) my_b = prev, my_e = n_in; }
-				else next_rb = rb + prev;
-			}
-			// only windows holding an out-of-order run are rewritten
-			const uint32_t xlo = (uint32_t)__shfl((int)(uint32_t)rec.x, lane > 0 ? lane - 1 : 0), xhi = (uint32_t)__shfl((int)(uint32_t)(rec.x >> 32), lane > 0 ? lane - 1 : 0);
-			const uint64_t xprev = (uint64_t)xhi << 32 | xlo;
-			const bool desc = in && lane > 0 && !start && rec.x < xprev && pos < next_rb;   // inside a complete run, smaller than its left neighbour
-			if (__ballot(desc)) {
-				L.ins[lane] = rec;
-				rs_fence_wave();
-				if (my_b >= 0 && my_e - my_b > 1) rs_insertion(L.ins + my_b, L.ins + my_e);
-				rs_fence_wave();
-				if (pos < next_rb) beg[pos] = L.ins[lane];
-				rs_fence_wg();
-			}
-			rb = next_rb;
-		}
-		if (lane == 0) L.prof[3] += (wall_clock64() - tr) - (L.prof[1] + L.prof[2] - w0);
+		rs_runs_wave(beg, n, shift + 8, L, lane, [&](int64_t rb, int64_t len) { rs_level_wave(beg + rb, len, shift, L, lane); });
 	}
 }
 
