@@ -641,7 +641,6 @@ __global__ void k_fix_pred(const uint64_t *__restrict__ seg_start, uint32_t n_se
 //     consecutive anchors in registers (one coalesced load) and follows the links with readlane -- memory latency
 //     is paid once per window instead of once per step.  t[]==2 of the reference is never observable (p[i] < i, a
 //     walk cannot meet itself), so one walk records the path, finds the cut (max_i) and marks only the kept part.
-__device__ __forceinline__ int32_t rl(int32_t v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 
 __global__ __launch_bounds__(64)
 void k_bt_list(int n_seq, const uint64_t *__restrict__ q_aoff, const int32_t *__restrict__ f_all, int32_t *__restrict__ t_all, u128 *__restrict__ z_all, ChainParams P,

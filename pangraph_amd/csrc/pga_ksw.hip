@@ -406,7 +406,8 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_begin = now();
 	hipEvent_t ready;
-	PGA_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+	PGA_HIP(hipEventCreate(&ready));
+	PGA_HIP(hipEventRecord(ready, st));                     // time base of the per-class start offsets printed under PGA_VERBOSE
 	// every class is prepared and launched in turn, the classes with few, long problems first: they are already running
 	// while the host still lays out the million-tile classes
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
@@ -430,7 +431,6 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		X.n_waves = n_waves;
 		X.d_slab.alloc(n_waves * slab_max[c]);
 		budget -= std::min(budget, n_waves * slab_max[c]);
-		PGA_HIP(hipEventRecord(ready, st));
 		PGA_HIP(hipStreamSynchronize(st));                   // jb goes out of scope at the end of this iteration
 		hipStream_t &ls = lane_stream[lane_of_class[c]];
 		if (!ls) {
@@ -456,19 +456,20 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipEventRecord(X.e1, cs));
+		(void)hipStreamQuery(cs);                             // push the packets out now: the class should start while the next one is prepared
 	}
 	const double t_launched = now();
 	for (Launch &X : L) {
 		const int c = X.c;
 		std::vector<uint32_t> &ids = *X.ids;
 		PGA_HIP(hipEventSynchronize(X.e1));
-		float msf = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1));
+		float msf = 0, ms_off = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1)); (void)hipEventElapsedTime(&ms_off, ready, X.e0);
 		const double ms = msf;
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
 			tm->kern[K_EXTD2].ms += ms; tm->kern[K_EXTD2].launches += 1; tm->kern[K_EXTD2].alg_bytes += 0.5 * bases; tm->dp_bases += bases; // 2-bit packed q+t reads; CIGAR bytes added below
-			if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms, slab %.1f KB x %zu waves\n", c, ids.size(), ms, slab_max[c] / 1024.0, X.n_waves);
+			if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		}
 		std::vector<DpRes> r = X.d_r.download(lane_stream[lane_of_class[c]]);
 		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];

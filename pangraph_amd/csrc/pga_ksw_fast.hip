@@ -17,6 +17,7 @@
 //     pulls a 64-row x 128-column window around the path into LDS with coalesced loads and walks it there.
 #include "pga_common.h"
 #include "pga_dp.h"
+#include "pga_wave.h"
 
 namespace pga {
 
@@ -89,6 +90,37 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			u[c] = v[c] = x[c] = y[c] = -q - e; x2[c] = y2[c] = -q2 - e2;
 			tb[c] = target_at(lane + 64 * c); qb[c] = 0; H[c] = KSW_NEG_INF;
 		}
+		// Gap fills between near-identical stretches, decided without the matrix: for two equally long sequences that differ
+		// in m positions (no ambiguous bases), every alignment other than the main diagonal has at least one insertion and one
+		// deletion, so it scores at most a*(n-1) - 2*min(q+e, q2+e2), while the diagonal scores a*n - (a+b)*m.  If the
+		// diagonal wins STRICTLY it is the unique optimum; the recurrence is exact inside an unbinding band and its
+		// left-aligned tie rule never fires, so the first approximate pass (KSW_EZ_APPROX_MAX only: no z-drop test, score
+		// = H at the end cell) returns exactly "nM" with that score.
+		if (flag == EZ_APPROX_MAX && qlen == tlen) {
+			int n_mis = 0; bool ambi = false;
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int t = lane + 64 * c;
+				if (t < tlen) { const int qc = query_at(t); ambi |= qc > 3 || tb[c] > 3; n_mis += qc != tb[c]; }
+			}
+			const unsigned long long any_ambi = __ballot(ambi);
+			int m_tot = 0;                                                // sum over lanes (a lane holds at most C columns)
+#pragma unroll
+			for (int k = 1; k <= C; ++k) m_tot += __popcll(__ballot(n_mis >= k));
+			const int g1 = qe < qe2 ? qe : qe2;
+			if (!any_ambi && (sc_mch - sc_mis) * m_tot < sc_mch + 2 * g1) {
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(pool_cursor, 1ULL);
+				if (lane == 0) {
+					if (base + 1 <= pool_cap) cigar_pool[base] = (uint32_t)tlen << 4;
+					DpRes R;
+					R.max = 0, R.max_q = -1, R.max_t = -1, R.mqe = KSW_NEG_INF, R.mqe_t = -1, R.mte = KSW_NEG_INF, R.mte_q = -1;
+					R.score = sc_mch * (tlen - m_tot) + sc_mis * m_tot, R.zdropped = 0, R.reach_end = 0, R.n_cigar = 1, R.pad = 0, R.cigar_off = base;
+					res[jid] = R;
+				}
+				continue;
+			}
+		}
 		int qblock = query_at(lane);                 // query[0..63]
 		qb[0] = lane == 0 ? __shfl(qblock, 0) : 0;   // diagonal 0: lane 0 needs query[0]
 
@@ -106,14 +138,12 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			for (int c = C - 1; c >= 0; --c) {
 				if (64 * c > en0 || 64 * c + 63 < st0) continue;                 // wave-uniform
 				const int t = lane + 64 * c;
-				int xt1 = __shfl_up(x[c], 1), vt1 = __shfl_up(v[c], 1), x2t1 = __shfl_up(x2[c], 1);
-				{   // cross-chunk carry: lane 63 of the chunk below, not yet updated on this diagonal (shuffles are wave-wide)
-					const int cx = __shfl(x[c > 0 ? c - 1 : 0], 63), cv = __shfl(v[c > 0 ? c - 1 : 0], 63), cx2 = __shfl(x2[c > 0 ? c - 1 : 0], 63);
-					if (lane == 0) {
-						if (c > 0) xt1 = cx, vt1 = cv, x2t1 = cx2;
-						else xt1 = -q - e, x2t1 = -q2 - e2, vt1 = bnd;               // ksw2_extd2_sse.c:155-158
-					}
-				}
+				// t-1 neighbour: one DPP wave shift; lane 0 takes lane 63 of the chunk below (not yet updated on this diagonal,
+				// chunks are swept high-to-low) or the boundary values of ksw2_extd2_sse.c:155-158
+				const int cx = c > 0 ? __builtin_amdgcn_readlane(x[c > 0 ? c - 1 : 0], 63) : -q - e;
+				const int cv = c > 0 ? __builtin_amdgcn_readlane(v[c > 0 ? c - 1 : 0], 63) : bnd;
+				const int cx2 = c > 0 ? __builtin_amdgcn_readlane(x2[c > 0 ? c - 1 : 0], 63) : -q2 - e2;
+				const int xt1 = wave_shr1(x[c], cx), vt1 = wave_shr1(v[c], cv), x2t1 = wave_shr1(x2[c], cx2);
 				int ut = u[c], yt = y[c], y2t = y2[c];
 				if (t == r) ut = bnd, yt = -q - e, y2t = -q2 - e2;               // ksw2_extd2_sse.c:160-163
 				const bool act = t >= st0 && t <= en0;
@@ -215,13 +245,13 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					{
 						const int c0 = last_H0_t >> 6, l0 = last_H0_t & 63, c1 = (last_H0_t + 1) >> 6, l1 = (last_H0_t + 1) & 63;
 #pragma unroll
-						for (int c = 0; c < C; ++c) { if (c == c0) d0 = __shfl(v[c], l0); if (c == c1) d1 = __shfl(u[c], l1); }
+						for (int c = 0; c < C; ++c) { if (c == c0) d0 = rl(v[c], l0); if (c == c1) d1 = rl(u[c], l1); }
 					}
 					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
 						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
 					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += d0;
 					else ++last_H0_t, H0 += d1;
-				} else H0 = __shfl(v[0], 0) - qe_h, last_H0_t = 0;
+				} else H0 = __builtin_amdgcn_readlane(v[0], 0) - qe_h, last_H0_t = 0;
 				if (r == n_diag - 1 && en0 == tlen - 1) ez_score = H0;
 			}
 			if (stop) break;
@@ -229,13 +259,11 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			{
 				const int nr = r + 1;
 				if ((nr & 63) == 0) qblock = query_at(nr + lane);
-				const int qnew = __shfl(qblock, nr & 63);
+				const int qnew = rl(qblock, nr & 63);
 #pragma unroll
 				for (int c = C - 1; c >= 0; --c) {
-					int sh = __shfl_up(qb[c], 1);
-					const int carry = __shfl(qb[c > 0 ? c - 1 : 0], 63);
-					if (lane == 0) sh = c > 0 ? carry : qnew;
-					qb[c] = sh;
+					const int carry = c > 0 ? __builtin_amdgcn_readlane(qb[c > 0 ? c - 1 : 0], 63) : qnew;
+					qb[c] = wave_shr1(qb[c], carry);
 				}
 			}
 		}

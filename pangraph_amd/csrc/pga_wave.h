@@ -6,6 +6,11 @@
 
 namespace pga {
 
+// value of lane `l` (uniform), as a scalar broadcast
+__device__ __forceinline__ int32_t rl(int32_t v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+// lane i receives lane i-1's value, lane 0 receives `first` (one DPP move: wave_shr:1)
+__device__ __forceinline__ int32_t wave_shr1(int32_t v, int32_t first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }
+
 // minimum of a double over the wave with DPP moves only (no LDS traffic); the result is uniform
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_min_step(double v)
 {
