@@ -84,7 +84,9 @@ struct PgaIdx {
 	bool have_results = false, indexed = false; mm_mapopt_t res_opt;
 	std::vector<std::vector<Reg>> results;
 	Timers tm;
-	hipStream_t st = 0;
+	hipStream_t st = 0;              // the part's own (non-blocking) stream
+	int arena = 0;                   // device-memory arena of the part (pga_mem.cpp)
+	~PgaIdx() { if (st) (void)hipStreamDestroy(st); }
 };
 
 static void require_device()
@@ -124,6 +126,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	require_device();
 	std::unique_ptr<PgaIdx> ix(new PgaIdx());
 	memset(&ix->hdr, 0, sizeof(ix->hdr));
+	PGA_HIP(hipStreamCreateWithFlags(&ix->st, hipStreamNonBlocking));
 	if (w < 1) w = 1;
 	double t0 = now_s();
 	const int64_t one_grp[2] = {0, n};
@@ -374,7 +377,15 @@ extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, cons
 	*out = nullptr;
 	try {
 		std::unique_ptr<pga_batch_s> B(new pga_batch_s());
-		const uint64_t max_bases = getenv("PGA_MAX_BATCH_BASES") ? strtoull(getenv("PGA_MAX_BATCH_BASES"), 0, 10) : 3000000000ULL;
+		// Sub-batches: at most PGA_MAX_BATCH_BASES each (32-bit anchor indices), and -- when the batch is large enough -- at
+		// least PGA_PARTS of them (default 1; 2 pays on very large batches): the parts are aligned CONCURRENTLY, each on its own stream, so the
+		// dependency-bound phases of one part (sort replay, chain sweep, the last few DP problems) overlap the others' work
+		uint64_t max_bases = getenv("PGA_MAX_BATCH_BASES") ? strtoull(getenv("PGA_MAX_BATCH_BASES"), 0, 10) : 3000000000ULL;
+		{
+			uint64_t total = 0; for (int64_t i = 0; i < group_off[n_groups]; ++i) total += seq_lens[i];
+			const int want = getenv("PGA_PARTS") ? atoi(getenv("PGA_PARTS")) : 1;
+			if (want > 1 && n_groups >= want && total >= 200000000ULL) max_bases = std::min<uint64_t>(max_bases, (total + want - 1) / want + 1);
+		}
 		int g0 = 0;
 		while (g0 < n_groups) {
 			int g1 = g0; uint64_t bases = 0;
@@ -407,17 +418,37 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 		std::unique_ptr<pga_result_s> R(new pga_result_s());
 		memset(&R->st, 0, sizeof(R->st));
 		double t_all = now_s();
-		for (size_t p = 0; p < B->parts.size(); ++p) {
+		const int n_parts = (int)B->parts.size();
+		int threads_each = params->n_threads > 0 ? params->n_threads : usable_cpus();
+		threads_each = std::max(1, threads_each / std::max(1, n_parts));
+		std::vector<std::string> errs((size_t)n_parts);
+		int dev = 0; PGA_HIP(hipGetDevice(&dev));
+		auto work = [&](int p) {
+			try {
+				PGA_HIP(hipSetDevice(dev));
+				dev_set_arena(p + 1);
+				PgaIdx &ix = *B->parts[p];
+				if (!ix.indexed || ix.hdr.w != io.w || ix.hdr.k != io.k) {
+					ix.hdr.w = io.w, ix.hdr.k = io.k, ix.hdr.b = 14 < 2 * io.k ? 14 : 2 * io.k;
+					ix.mid_occ_frac = -1.0f; ix.have_results = false;
+				}
+				const double up = ix.tm.upload; ix.tm = Timers(); ix.tm.upload = up;
+				idx_sketch_index(ix);          // the index is part of the hot path: rebuilt on every call, like every find_matches does
+				mm_mapopt_t mo = mo0;
+				if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
+				run_batch(ix, mo, threads_each);
+			} catch (std::exception &e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "unknown error"; }
+			dev_set_arena(0);
+		};
+		if (n_parts == 1) work(0);
+		else {
+			std::vector<std::thread> th;
+			for (int p = 0; p < n_parts; ++p) th.emplace_back(work, p);
+			for (auto &t : th) t.join();
+		}
+		for (int p = 0; p < n_parts; ++p) if (!errs[p].empty()) throw std::runtime_error(errs[p]);
+		for (int p = 0; p < n_parts; ++p) {
 			PgaIdx &ix = *B->parts[p];
-			if (!ix.indexed || ix.hdr.w != io.w || ix.hdr.k != io.k) {
-				ix.hdr.w = io.w, ix.hdr.k = io.k, ix.hdr.b = 14 < 2 * io.k ? 14 : 2 * io.k;
-				ix.mid_occ_frac = -1.0f; ix.have_results = false;
-			}
-			const double up = ix.tm.upload; ix.tm = Timers(); ix.tm.upload = up;
-			idx_sketch_index(ix);          // the index is part of the hot path: rebuilt on every call, like every find_matches does
-			mm_mapopt_t mo = mo0;
-			if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
-			run_batch(ix, mo, params->n_threads);
 			collect_results(ix, B->g0[p], B->goff[p], *R);
 			ix.results.clear(); ix.have_results = false;
 		}

@@ -23,7 +23,8 @@ namespace pga {
 // ---- device memory: cached blocks (pga_mem.cpp) ----
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
-void dev_trim();        // release every idle block of the current device
+void dev_trim();        // release every idle block
+void dev_set_arena(int arena);   // calling thread: recycle device blocks only within this arena (one per concurrent sub-batch)
 
 // ---- device buffer ----
 template <class T> struct DBuf {

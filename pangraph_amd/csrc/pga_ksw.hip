@@ -18,6 +18,7 @@
 #include "pga_common.h"
 #include "pga_dp.h"
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 
 namespace pga {
@@ -433,6 +434,8 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		budget -= std::min(budget, n_waves * slab_max[c]);
 		PGA_HIP(hipStreamSynchronize(st));                   // jb goes out of scope at the end of this iteration
 		hipStream_t &ls = lane_stream[lane_of_class[c]];
+		static std::mutex lane_mu;
+		std::lock_guard<std::mutex> lane_lk(lane_mu);
 		if (!ls) {
 			int prio_lo = 0, prio_hi = 0;
 			PGA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // numerically lower = higher priority

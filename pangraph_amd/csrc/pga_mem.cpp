@@ -13,11 +13,14 @@ namespace pga {
 namespace {
 struct Pool {
 	std::multimap<size_t, void*> idle;              // rounded size -> block
-	std::map<void*, size_t> live;                   // block -> rounded size
 	size_t idle_bytes = 0;
 };
+struct Live { size_t size; int dev, arena; };
 std::mutex g_mu;
-std::map<int, Pool> g_pools;
+std::map<std::pair<int, int>, Pool> g_pools;       // (device, arena)
+std::map<void*, Live> g_live;                      // block -> size and home pool
+size_t g_idle_total = 0;
+thread_local int t_arena = 0;
 
 size_t round_size(size_t b)
 {
@@ -35,18 +38,24 @@ size_t cache_limit()
 }
 }
 
+// Blocks are recycled inside an ARENA only.  A freed block may still be read by kernels queued on the stream of the code
+// that freed it; handing it to the same arena keeps every later use behind those kernels in stream order.  Concurrent
+// sub-batches (pga_api.cpp) run with one arena and one stream each.
+void dev_set_arena(int arena) { t_arena = arena; }
+
 void *dev_alloc(size_t bytes)
 {
 	int dev = 0;
 	PGA_HIP(hipGetDevice(&dev));
 	const size_t r = round_size(bytes);
+	const int arena = t_arena;
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
-		Pool &P = g_pools[dev];
+		Pool &P = g_pools[{dev, arena}];
 		auto it = P.idle.lower_bound(r);
 		if (it != P.idle.end() && it->first <= r + r / 4) {
 			void *p = it->second; const size_t sz = it->first;
-			P.idle.erase(it); P.idle_bytes -= sz; P.live[p] = sz;
+			P.idle.erase(it); P.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena};
 			return p;
 		}
 	}
@@ -59,28 +68,27 @@ void *dev_alloc(size_t bytes)
 		if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " allocating " + std::to_string(r) + " bytes of device memory");
 	}
 	std::lock_guard<std::mutex> lk(g_mu);
-	g_pools[dev].live[p] = r;
+	g_live[p] = Live{r, dev, arena};
 	return p;
 }
 
 void dev_free(void *p)
 {
 	if (!p) return;
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess) return;
 	std::vector<void*> drop;
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
-		Pool &P = g_pools[dev];
-		auto it = P.live.find(p);
-		if (it == P.live.end()) { drop.push_back(p); }
+		auto it = g_live.find(p);
+		if (it == g_live.end()) { drop.push_back(p); }
 		else {
-			const size_t sz = it->second;
-			P.live.erase(it);
-			P.idle.emplace(sz, p); P.idle_bytes += sz;
-			while (P.idle_bytes > cache_limit() && !P.idle.empty()) {
+			const Live lv = it->second;
+			g_live.erase(it);
+			Pool &P = g_pools[{lv.dev, lv.arena}];
+			P.idle.emplace(lv.size, p); P.idle_bytes += lv.size; g_idle_total += lv.size;
+			// over the limit: release the largest idle blocks of this pool (they are the DP slabs)
+			while (g_idle_total > cache_limit() && !P.idle.empty()) {
 				auto big = std::prev(P.idle.end());
-				drop.push_back(big->second); P.idle_bytes -= big->first; P.idle.erase(big);
+				drop.push_back(big->second); P.idle_bytes -= big->first; g_idle_total -= big->first; P.idle.erase(big);
 			}
 		}
 	}
@@ -89,14 +97,11 @@ void dev_free(void *p)
 
 void dev_trim()
 {
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess) return;
 	std::vector<void*> drop;
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
-		Pool &P = g_pools[dev];
-		for (auto &kv : P.idle) drop.push_back(kv.second);
-		P.idle.clear(); P.idle_bytes = 0;
+		for (auto &kv : g_pools) { for (auto &b : kv.second.idle) drop.push_back(b.second); kv.second.idle.clear(); kv.second.idle_bytes = 0; }
+		g_idle_total = 0;
 	}
 	for (void *q : drop) (void)hipFree(q);
 }
