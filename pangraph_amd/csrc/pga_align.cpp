@@ -954,7 +954,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	if (opt.flag & MM_F_CIGAR) {
 		DpParams P{opt.q, opt.e, opt.q2, opt.e2, D.mat[0], D.mat[1], D.mat[24]};
 		size_t n_requested = 0;
-		std::list<std::vector<uint32_t>> pools;
+		std::list<PinVec<uint32_t>> pools;
 		for (int round = 0; round < 100000; ++round) {
 			// run what was requested
 			{
@@ -967,7 +967,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 				if (!jb.empty()) {
 					std::vector<DpRes> rs;
 					pools.emplace_back();
-					std::vector<uint32_t> &cg = pools.back();          // stays alive until the batch is done: results point into it
+					PinVec<uint32_t> &cg = pools.back();          // stays alive until the batch is done: results point into it
 					double t_dp = getenv("PGA_VERBOSE") ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
 					dp_run(S.d_nt4.p, jb, P, rs, cg, st, tm);
 					if (t_dp > 0) fprintf(stderr, "[pga]   round %d: %zu DP problems in %.3f s\n", round, jb.size(), std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dp);

@@ -506,7 +506,7 @@ extern "C" int pga_stage_chain(const pga_params_t *params, int32_t n, const char
 		*anchors_xy = dup_out(flat); *anchor_off = dup_out(SR.h_q_aoff); *rep_len = dup_out(SR.h_rep_len);
 		ChainResult CR; chain_all(ix->S, SR.a, SR.q_aoff, SR.n_a, mo, io.k, CR, 0);
 		*n_u = dup_out(CR.n_u); *n_v = dup_out(CR.n_v);
-		std::vector<uint64_t> uu(CR.u); uu.resize(SR.n_a);
+		std::vector<uint64_t> uu(CR.u.begin(), CR.u.end()); uu.resize(SR.n_a);
 		*u = dup_out(uu);
 		std::vector<uint64_t> cf(SR.n_a * 2);
 		for (size_t i = 0; i < SR.n_a && i < CR.a.size(); ++i) cf[2 * i] = CR.a[i].x, cf[2 * i + 1] = CR.a[i].y;
@@ -535,7 +535,7 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 		DpParams P{gapo, gape, gapo2, gape2, a, b, sc_ambi};
 		std::vector<DpJob> run; std::vector<int> idx;
 		for (int i = 0; i < n_jobs; ++i) if (qlen[i] > 0 && tlen[i] > 0) run.push_back(jobs[i]), idx.push_back(i);
-		std::vector<DpRes> res; std::vector<uint32_t> cg;
+		std::vector<DpRes> res; PinVec<uint32_t> cg;
 		dp_run(d.p, run, P, res, cg, 0);
 		std::vector<uint32_t> all;
 		for (int i = 0; i < n_jobs; ++i) { int32_t *e = ez + 12 * i; e[0] = 0; e[1] = e[2] = -1; e[3] = -0x40000000; e[4] = -1; e[5] = -0x40000000; e[6] = -1; e[7] = -0x40000000; e[8] = e[9] = e[10] = e[11] = 0; cigar_off[i] = 0; }

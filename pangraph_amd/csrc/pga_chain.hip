@@ -868,9 +868,8 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	}
 	PGA_HIP(hipGetLastError());
 	O.n_u = n_u.download(st); O.n_v = n_v.download(st);
-	O.u = u.download(st);
-	std::vector<u128> oa = out.download(st);
-	O.a.swap(oa);
+	download_to(O.u, u.p, u.n, st);
+	download_to(O.a, out.p, out.n, st);
 }
 
 } // namespace pga

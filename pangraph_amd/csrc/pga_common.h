@@ -52,6 +52,32 @@ template <class T> struct DBuf {
 
 struct u128 { uint64_t x, y; };
 
+// ---- pinned host memory: cached blocks (pga_mem.cpp); device-to-host copies into it run at full DMA speed ----
+void *pin_alloc(size_t bytes);
+void pin_free(void *p);
+template <class T> struct PinVec {          // the small subset of std::vector the pipeline needs
+	T *p = nullptr; size_t n = 0, cap = 0;
+	PinVec() {}
+	PinVec(const PinVec&) = delete; PinVec &operator=(const PinVec&) = delete;
+	PinVec(PinVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+	PinVec &operator=(PinVec &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+	~PinVec() { release(); }
+	void release() { if (p) pin_free(p); p = nullptr; n = cap = 0; }
+	void resize(size_t n_) { if (n_ > cap) { T *q = (T*)pin_alloc((n_ ? n_ : 1) * sizeof(T)); if (n) memcpy(q, p, n * sizeof(T)); if (p) pin_free(p); p = q; cap = n_; } n = n_; }
+	void clear() { n = 0; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	T *data() { return p; } const T *data() const { return p; }
+	T *begin() { return p; } const T *begin() const { return p; }
+	T *end() { return p + n; } const T *end() const { return p + n; }
+	T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+};
+template <class T> static inline void download_to(PinVec<T> &h, const T *d, size_t n, hipStream_t s)
+{
+	h.resize(n);
+	if (n) { PGA_HIP(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(hipStreamSynchronize(s)); }
+}
+
 // ---- the sequence set of one batch, resident in HBM ----
 struct SeqSet {
 	int n_seq = 0;

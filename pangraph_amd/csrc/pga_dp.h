@@ -33,6 +33,6 @@ struct DpRes {           // ksw_extz_t (ksw2.h:31-40)
 struct DpParams { int32_t q, e, q2, e2, sc_mch, sc_mis, sc_ambi; }; // sc_* are matrix entries mat[0], mat[1], mat[24]
 
 size_t dp_slab_bytes(int qlen, int tlen, int w);
-void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st, Timers *tm = nullptr);
+void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm = nullptr);
 
 } // namespace pga

@@ -19,6 +19,7 @@
 #include "pga_dp.h"
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <cstdio>
 
 namespace pga {
@@ -369,7 +370,18 @@ static int dp_class(const DpJob &j, size_t need)
 	return 5;
 }
 
-void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, std::vector<uint32_t> &cigars, hipStream_t st, Timers *tm)
+// a few host threads for the per-problem loops (classification, gather, scatter): millions of problems per round
+template <class F> static void host_parallel(size_t n, F f)
+{
+	const int nt = (int)std::min<size_t>((size_t)usable_cpus(), n / 65536 + 1);
+	if (nt <= 1) { f(0, n); return; }
+	std::vector<std::thread> th;
+	const size_t per = (n + nt - 1) / nt;
+	for (int t = 0; t < nt; ++t) { const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per); if (lo < hi) th.emplace_back([=, &f] { f(lo, hi); }); }
+	for (auto &t : th) t.join();
+}
+
+void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
@@ -378,14 +390,25 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	std::vector<uint32_t> cls[DP_NCLASS];
 	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0, 0, 0};
 	std::vector<size_t> need(n);
+	std::vector<uint8_t> cls_of(n);
 	unsigned long long cig_total = 0;
+	host_parallel(n, [&](size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			const bool is_ll = jobs[i].flag & PGA_JOB_LL;
+			need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
+			cls_of[i] = (uint8_t)dp_class(jobs[i], need[i]);
+		}
+	});
+	{
+		size_t cnt[DP_NCLASS] = {0};
+		for (size_t i = 0; i < n; ++i) ++cnt[cls_of[i]];
+		for (int c = 0; c < DP_NCLASS; ++c) cls[c].reserve(cnt[c]);
+	}
 	for (size_t i = 0; i < n; ++i) {
-		const bool is_ll = jobs[i].flag & PGA_JOB_LL;
-		need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
-		const int c = dp_class(jobs[i], need[i]);
+		const int c = cls_of[i];
 		cls[c].push_back((uint32_t)i);
 		if (need[i] > slab_max[c]) slab_max[c] = need[i];
-		if (!is_ll) cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
+		if (!(jobs[i].flag & PGA_JOB_LL)) cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
 	}
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
@@ -398,17 +421,30 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
-	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; DBuf<uint8_t> d_slab; size_t n_waves; hipEvent_t e0, e1; };
+	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
-	size_t budget = (size_t)96 << 30;
-	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 * 3 < budget) budget = fr / 4 * 3; }
+	size_t budget = (size_t)64 << 30;                       // per class; the four lane slabs together stay well inside HBM
+	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 5 < budget) budget = tot / 5; }
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_begin = now();
 	hipEvent_t ready;
 	PGA_HIP(hipEventCreate(&ready));
 	PGA_HIP(hipEventRecord(ready, st));                     // time base of the per-class start offsets printed under PGA_VERBOSE
+	// scratch slabs: one grow-only buffer per launch lane (classes of a lane run one after the other and share it); sized
+	// before anything is launched so that no buffer moves under a running kernel
+	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
+	for (int c = DP_NCLASS - 1; c >= 0; --c) {
+		if (cls[c].empty()) continue;
+		size_t n_waves = c == 6 ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
+		if (n_waves > cls[c].size()) n_waves = cls[c].size();
+		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
+		waves_of[c] = n_waves;
+		lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], n_waves * slab_max[c]);
+	}
+	static thread_local DBuf<uint8_t> lane_slab[4];
+	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) { PGA_HIP(hipDeviceSynchronize()); lane_slab[l].alloc(lane_need[l]); }
 	// every class is prepared and launched in turn, the classes with few, long problems first: they are already running
 	// while the host still lays out the million-tile classes
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
@@ -418,20 +454,16 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		// register-resident classes are uniform enough to skip the sort)
 		if (c >= 2 || ids.size() < 100000)
 			std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
-		std::vector<DpJob> jb(ids.size());
-		for (size_t i = 0; i < ids.size(); ++i) jb[i] = jobs[ids[i]];
+		PinVec<DpJob> jb; jb.resize(ids.size());
+		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
 		L.emplace_back();
 		Launch &X = L.back();
 		X.c = c; X.ids = &ids;
-		X.d_jobs.upload(jb, st);
+		X.d_jobs.upload(jb.data(), jb.size(), st);
 		X.d_r.alloc(ids.size());
 		X.d_cnt.alloc(1); X.d_cnt.zero(st);
-		size_t n_waves = c == 6 ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
-		if (n_waves > ids.size()) n_waves = ids.size();
-		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
-		X.n_waves = n_waves;
-		X.d_slab.alloc(n_waves * slab_max[c]);
-		budget -= std::min(budget, n_waves * slab_max[c]);
+		X.n_waves = waves_of[c];
+		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		PGA_HIP(hipStreamSynchronize(st));                   // jb goes out of scope at the end of this iteration
 		hipStream_t &ls = lane_stream[lane_of_class[c]];
 		static std::mutex lane_mu;
@@ -447,15 +479,15 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		if (c == 6) {
 			int t_cap = 16;
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
-			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)X.d_slab.p, slab_max[c] / 8, X.d_r.p, cs);
-		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
+		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c <= 4) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
 			const int nt = c == 4 ? 1024 : c == 3 ? 512 : 256;
-			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, X.d_slab.p, slab_max[c],
+			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipEventRecord(X.e1, cs));
@@ -474,8 +506,9 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			tm->kern[K_EXTD2].ms += ms; tm->kern[K_EXTD2].launches += 1; tm->kern[K_EXTD2].alg_bytes += 0.5 * bases; tm->dp_bases += bases; // 2-bit packed q+t reads; CIGAR bytes added below
 			if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		}
-		std::vector<DpRes> r = X.d_r.download(lane_stream[lane_of_class[c]]);
-		for (size_t i = 0; i < ids.size(); ++i) res[ids[i]] = r[i];
+		PinVec<DpRes> r;
+		download_to(r, X.d_r.p, ids.size(), lane_stream[lane_of_class[c]]);
+		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
 		if (c >= 2 && c <= 4 && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
@@ -493,8 +526,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	unsigned long long used = d_cursor.download(st)[0];
 	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");
 	if (tm) { tm->kern[K_EXTD2].alg_bytes += 4.0 * (double)used; tm->dp_cigar_ops += (double)used; }
-	cigars.resize((size_t)used);
-	if (used) { PGA_HIP(hipMemcpyAsync(cigars.data(), d_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st)); }
+	download_to(cigars, d_pool.p, (size_t)used, st);
 	if (verbose) fprintf(stderr, "[pga]     dp_run host: classify %.3f, prepare+launch %.3f, wait+collect %.3f, CIGAR download %.3f s\n", t_begin - t_enter, t_launched - t_begin, t_waited - t_launched, now() - t_waited);
 }
 

@@ -106,4 +106,53 @@ void dev_trim()
 	for (void *q : drop) (void)hipFree(q);
 }
 
+// ---- pinned host blocks, cached the same way (hipHostMalloc costs milliseconds per hundred MB) ----
+namespace {
+std::mutex g_pin_mu;
+std::multimap<size_t, void*> g_pin_idle;
+std::map<void*, size_t> g_pin_live;
+size_t g_pin_idle_bytes = 0;
+}
+
+void *pin_alloc(size_t bytes)
+{
+	const size_t r = round_size(bytes);
+	{
+		std::lock_guard<std::mutex> lk(g_pin_mu);
+		auto it = g_pin_idle.lower_bound(r);
+		if (it != g_pin_idle.end() && it->first <= r + r / 4) {
+			void *p = it->second; const size_t sz = it->first;
+			g_pin_idle.erase(it); g_pin_idle_bytes -= sz; g_pin_live[p] = sz;
+			return p;
+		}
+	}
+	void *p = nullptr;
+	PGA_HIP(hipHostMalloc(&p, r, hipHostMallocDefault));
+	std::lock_guard<std::mutex> lk(g_pin_mu);
+	g_pin_live[p] = r;
+	return p;
+}
+
+void pin_free(void *p)
+{
+	if (!p) return;
+	std::vector<void*> drop;
+	{
+		std::lock_guard<std::mutex> lk(g_pin_mu);
+		auto it = g_pin_live.find(p);
+		if (it == g_pin_live.end()) drop.push_back(p);
+		else {
+			const size_t sz = it->second;
+			g_pin_live.erase(it);
+			g_pin_idle.emplace(sz, p); g_pin_idle_bytes += sz;
+			const size_t lim = (size_t)16 << 30;
+			while (g_pin_idle_bytes > lim && !g_pin_idle.empty()) {
+				auto big = std::prev(g_pin_idle.end());
+				drop.push_back(big->second); g_pin_idle_bytes -= big->first; g_pin_idle.erase(big);
+			}
+		}
+	}
+	for (void *q : drop) (void)hipHostFree(q);
+}
+
 } // namespace pga

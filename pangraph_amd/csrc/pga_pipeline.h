@@ -18,8 +18,8 @@ struct Reg {
 
 struct ChainResult {
 	std::vector<int32_t> n_u, n_v;   // per query
-	std::vector<uint64_t> u;         // chain i of query q at q_aoff[q]+i: score<<32|cnt
-	std::vector<u128> a;             // compacted anchors of query q at q_aoff[q] .. +n_v[q]
+	PinVec<uint64_t> u;              // chain i of query q at q_aoff[q]+i: score<<32|cnt
+	PinVec<u128> a;                  // compacted anchors of query q at q_aoff[q] .. +n_v[q]
 };
 
 struct SeedResult {
