@@ -20,6 +20,7 @@
 #include <chrono>
 #include <mutex>
 #include <thread>
+#include <array>
 #include <cstdio>
 
 namespace pga {
@@ -400,15 +401,36 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		}
 	});
 	{
-		size_t cnt[DP_NCLASS] = {0};
-		for (size_t i = 0; i < n; ++i) ++cnt[cls_of[i]];
-		for (int c = 0; c < DP_NCLASS; ++c) cls[c].reserve(cnt[c]);
-	}
-	for (size_t i = 0; i < n; ++i) {
-		const int c = cls_of[i];
-		cls[c].push_back((uint32_t)i);
-		if (need[i] > slab_max[c]) slab_max[c] = need[i];
-		if (!(jobs[i].flag & PGA_JOB_LL)) cig_total += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
+		// bucket the problem ids by class, in index order, with per-thread partial counts
+		const int nt = (int)std::min<size_t>((size_t)usable_cpus(), n / 65536 + 1);
+		const size_t per = (n + nt - 1) / nt;
+		std::vector<std::array<size_t, DP_NCLASS>> cnt((size_t)nt);
+		std::vector<std::array<size_t, DP_NCLASS>> mx((size_t)nt);
+		std::vector<unsigned long long> cg((size_t)nt, 0);
+		auto count = [&](int t) {
+			cnt[t].fill(0); mx[t].fill(0);
+			const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+			for (size_t i = lo; i < hi; ++i) {
+				const int c = cls_of[i];
+				++cnt[t][c];
+				if (need[i] > mx[t][c]) mx[t][c] = need[i];
+				if (!(jobs[i].flag & PGA_JOB_LL)) cg[t] += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
+			}
+		};
+		{ std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(count, t); count(0); for (auto &x : th) x.join(); }
+		std::vector<std::array<size_t, DP_NCLASS>> base((size_t)nt);
+		for (int c = 0; c < DP_NCLASS; ++c) {
+			size_t tot = 0;
+			for (int t = 0; t < nt; ++t) { base[t][c] = tot; tot += cnt[t][c]; if (mx[t][c] > slab_max[c]) slab_max[c] = mx[t][c]; }
+			cls[c].resize(tot);
+		}
+		for (int t = 0; t < nt; ++t) cig_total += cg[t];
+		auto fill = [&](int t) {
+			std::array<size_t, DP_NCLASS> pos = base[t];
+			const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+			for (size_t i = lo; i < hi; ++i) cls[cls_of[i]][pos[cls_of[i]]++] = (uint32_t)i;
+		};
+		{ std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(fill, t); fill(0); for (auto &x : th) x.join(); }
 	}
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
@@ -485,7 +507,8 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
-			const int nt = c == 4 ? 1024 : c == 3 ? 512 : 256;
+			// few problems: each workgroup effectively owns a CU, so give it the waves to hide its LDS latency
+			const int nt = (c == 4 || ids.size() <= 256) ? 1024 : (c == 3 || ids.size() <= 512) ? 512 : 256;
 			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);

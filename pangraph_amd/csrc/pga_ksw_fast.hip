@@ -38,6 +38,16 @@ __device__ __forceinline__ long long wave_max64f(long long v)
 	return v;
 }
 
+typedef short s2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int as_i(s2_t v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ s2_t as_s2(int v) { return __builtin_bit_cast(s2_t, v); }
+__device__ __forceinline__ s2_t splat2(int x) { s2_t r; r.x = (short)x; r.y = (short)x; return r; }
+__device__ __forceinline__ s2_t pmax(s2_t a, s2_t b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2_t pmin(s2_t a, s2_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s2_t pminu(s2_t a, s2_t b) { return __builtin_bit_cast(s2_t, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b))); }
+__device__ __forceinline__ int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }   // mask ? a : b, bitwise
+
 #define BT_ROWS 64
 #define BT_COLS 64
 
@@ -121,11 +131,108 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 				continue;
 			}
 		}
+		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
+		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
+		if (flag == EZ_APPROX_MAX) {
+			// ---- the bulk: first-pass gap fills (approximate mode, left-aligned gaps, no z-drop test), two chunks per VGPR ----
+			// Lane l holds columns l+128p (low half) and l+128p+64 (high half) of pair p; all arithmetic is packed 16-bit
+			// (values stay inside the reference's int8 range for every cell that matters).  Cells outside [st0,en0] are
+			// computed too and hold garbage: with an unbinding band no cell inside the range ever reads them (see the file
+			// header), and they never store a direction byte.
+			constexpr int NP = C / 2;
+			s2_t U[NP], V[NP], X[NP], Y[NP], X2[NP], Y2[NP], TB[NP], QB[NP];
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				U[p] = V[p] = X[p] = Y[p] = splat2(-q - e); X2[p] = Y2[p] = splat2(-q2 - e2);
+				TB[p].x = (short)tb[2 * p]; TB[p].y = (short)tb[2 * p + 1]; QB[p] = splat2(0);
+			}
+			int qblock = query_at(lane);
+			{ const int q0 = __builtin_amdgcn_readlane(qblock, 0); if (lane == 0) QB[0].x = (short)q0; }
+			const s2_t ZERO = splat2(0), ONE = splat2(1), MCH = splat2(sc_mch), DMIS = splat2(sc_mis - sc_mch), SCN = splat2(sc_N), Q1 = splat2(q), Q2 = splat2(q2), QE = splat2(qe), QE2 = splat2(qe2);
+			const s2_t INIT1 = splat2(-q - e), INIT2 = splat2(-q2 - e2), EIGHT = splat2(8), C16 = splat2(16), C32 = splat2(32), C64 = splat2(64);
+			int H0 = 0, last_H0_t = 0;
+			const int n_diag = qlen + tlen - 1;
+			for (int r = 0; r < n_diag; ++r) {
+				const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
+				const int st = st0 & ~15;
+				const int bnd = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+				const s2_t BND = splat2(bnd);
+				uint8_t *prow = pmat + (size_t)r * n_col - st;
+#pragma unroll
+				for (int p = NP - 1; p >= 0; --p) {
+					if (128 * p > en0 || 128 * p + 127 < st0) continue;          // wave-uniform
+					const int t_lo = lane + 128 * p, t_hi = t_lo + 64;
+					// t-1 neighbours (pre-update): low half <- lane 63 of the pair below (its high half) or the boundary; high half <- own low half
+					const unsigned ox = (unsigned)__builtin_amdgcn_readlane(as_i(X[p]), 63), ov = (unsigned)__builtin_amdgcn_readlane(as_i(V[p]), 63), ox2 = (unsigned)__builtin_amdgcn_readlane(as_i(X2[p]), 63);
+					unsigned px = (unsigned)(-q - e) & 0xffffu, pv = (unsigned)bnd & 0xffffu, px2 = (unsigned)(-q2 - e2) & 0xffffu;
+					if (p > 0) {
+						px = (unsigned)__builtin_amdgcn_readlane(as_i(X[p > 0 ? p - 1 : 0]), 63) >> 16;
+						pv = (unsigned)__builtin_amdgcn_readlane(as_i(V[p > 0 ? p - 1 : 0]), 63) >> 16;
+						px2 = (unsigned)__builtin_amdgcn_readlane(as_i(X2[p > 0 ? p - 1 : 0]), 63) >> 16;
+					}
+					const s2_t xt1 = as_s2(wave_shr1(as_i(X[p]), (int)(px | ox << 16)));
+					const s2_t vt1 = as_s2(wave_shr1(as_i(V[p]), (int)(pv | ov << 16)));
+					const s2_t x2t1 = as_s2(wave_shr1(as_i(X2[p]), (int)(px2 | ox2 << 16)));
+					// first row / first column values for the column that joins on this diagonal (ksw2_extd2_sse.c:160-163)
+					const int jm = (t_lo == r ? 0xffff : 0) | (t_hi == r ? (int)0xffff0000 : 0);
+					const s2_t ut = as_s2(bfi(jm, as_i(BND), as_i(U[p]))), yt = as_s2(bfi(jm, as_i(INIT1), as_i(Y[p]))), y2t = as_s2(bfi(jm, as_i(INIT2), as_i(Y2[p])));
+					// score profile
+					const s2_t dif = as_s2(as_i(TB[p]) ^ as_i(QB[p]));
+					s2_t z = MCH + pminu(dif, ONE) * DMIS;
+					{ const s2_t nf = pminu(as_s2((as_i(TB[p]) | as_i(QB[p])) >> 2 & 0x00010001), ONE); z = z + nf * (SCN - z); }
+					s2_t a = xt1 + vt1, b = yt + ut, a2 = x2t1 + vt1, b2 = y2t + ut;
+					const s2_t zm = pmax(pmax(pmax(z, a), pmax(b, a2)), b2);
+					// direction: the first of (z, a, b, a2, b2) that reaches the maximum (strict > in the reference)
+					s2_t d;
+					{
+						const s2_t n0 = pminu(zm - z, ONE), n1 = pminu(zm - a, ONE), n2 = pminu(zm - b, ONE), n3 = pminu(zm - a2, ONE);
+						d = n0 * (ONE + n1 * (ONE + n2 * (ONE + n3)));
+					}
+					z = pmin(zm, MCH);
+					U[p] = z - vt1; V[p] = z - ut;
+					s2_t tmp = z - Q1; a = a - tmp; b = b - tmp;
+					tmp = z - Q2; a2 = a2 - tmp; b2 = b2 - tmp;
+					{ const s2_t m = pmax(a, ZERO);  X[p]  = m - QE;  d = d + pmin(m, ONE) * EIGHT; }
+					{ const s2_t m = pmax(b, ZERO);  Y[p]  = m - QE;  d = d + pmin(m, ONE) * C16; }
+					{ const s2_t m = pmax(a2, ZERO); X2[p] = m - QE2; d = d + pmin(m, ONE) * C32; }
+					{ const s2_t m = pmax(b2, ZERO); Y2[p] = m - QE2; d = d + pmin(m, ONE) * C64; }
+					if (t_lo >= st0 && t_lo <= en0) prow[t_lo] = (uint8_t)d.x;
+					if (t_hi >= st0 && t_hi <= en0) prow[t_hi] = (uint8_t)d.y;
+				}
+				// H along the approximate path (ksw2_extd2_sse.c:367-384); no z-drop test without KSW_EZ_APPROX_DROP
+				if (r > 0) {
+					int d0 = 0, d1 = 0;
+					{
+						const int c0 = last_H0_t >> 6, l0 = last_H0_t & 63, c1 = (last_H0_t + 1) >> 6, l1 = (last_H0_t + 1) & 63;
+#pragma unroll
+						for (int p = 0; p < NP; ++p) {
+							if ((c0 >> 1) == p) { const int w2 = rl(as_i(V[p]), l0); d0 = (c0 & 1) ? w2 >> 16 : (int)(short)(w2 & 0xffff); }
+							if ((c1 >> 1) == p) { const int w2 = rl(as_i(U[p]), l1); d1 = (c1 & 1) ? w2 >> 16 : (int)(short)(w2 & 0xffff); }
+						}
+					}
+					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += d0;
+					else ++last_H0_t, H0 += d1;
+				} else { const int w2 = __builtin_amdgcn_readlane(as_i(V[0]), 0); H0 = (int)(short)(w2 & 0xffff) - qe_h; last_H0_t = 0; }
+				if (r == n_diag - 1 && en0 == tlen - 1) ez_score = H0;
+				// query bases move one lane up for the next diagonal; lane 0 takes query[r+1]
+				{
+					const int nr = r + 1;
+					if ((nr & 63) == 0) qblock = query_at(nr + lane);
+					const int qnew = rl(qblock, nr & 63);
+#pragma unroll
+					for (int p = NP - 1; p >= 0; --p) {
+						const unsigned own = (unsigned)__builtin_amdgcn_readlane(as_i(QB[p]), 63);
+						const unsigned prev = p > 0 ? (unsigned)__builtin_amdgcn_readlane(as_i(QB[p > 0 ? p - 1 : 0]), 63) >> 16 : (unsigned)qnew & 0xffffu;
+						QB[p] = as_s2(wave_shr1(as_i(QB[p]), (int)(prev | own << 16)));
+					}
+				}
+			}
+		} else {
 		int qblock = query_at(lane);                 // query[0..63]
 		qb[0] = lane == 0 ? __shfl(qblock, 0) : 0;   // diagonal 0: lane 0 needs query[0]
 
-		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
-		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
 		int H0 = 0, last_H0_t = 0;
 		const int n_diag = qlen + tlen - 1;
 
@@ -266,6 +373,8 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					qb[c] = wave_shr1(qb[c], carry);
 				}
 			}
+		}
+
 		}
 
 		// ---- backtrack (ksw2.h:127-159): lane 0 walks an LDS window refilled by the whole wave ----

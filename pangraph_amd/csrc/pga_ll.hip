@@ -17,7 +17,7 @@
 
 namespace pga {
 
-#define LL_NT 256
+#define LL_NT 1024          // a problem has a CU to itself (LDS): the waves are there to hide LDS latency
 
 __global__ __launch_bounds__(LL_NT)
 void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P, uint32_t *__restrict__ job_counter,
