@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=int(os.environ.get("PGA_BENCH_GENOMES", 128)), help="genomes PER GPU at the leaf level")
+    ap.add_argument("--genomes", type=int, default=int(os.environ.get("PGA_BENCH_GENOMES", 512)), help="genomes PER GPU at the leaf level")
     ap.add_argument("--length", type=int, default=int(os.environ.get("PGA_BENCH_LENGTH", 5_000_000)))
     ap.add_argument("--divergence", type=float, default=0.01)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 disables)")
@@ -143,7 +143,7 @@ def main():
         total_units = units
 
     st = last.stats
-    kern = [(st["kern_ms"][i], batch.KERNELS[i], st["kern_launches"][i], st["kern_alg_bytes"][i]) for i in range(4)]
+    kern = [(st["kern_ms"][i], batch.KERNELS[i], st["kern_launches"][i], st["kern_alg_bytes"][i]) for i in range(len(batch.KERNELS)) if st["kern_launches"][i] > 0]
     kms, kname, klaunch, kbytes = max(kern)
     achieved = (kbytes / klaunch) / (kms / klaunch * 1e-3) / 1e9 if klaunch and kms > 0 else 0.0
     out = {
@@ -167,7 +167,7 @@ def main():
                      "traffic": None, "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
                      "alg_bytes_per_launch": kbytes / klaunch if klaunch else None},
         "stages_s": {k: st[k] for k in ("sketch", "index", "seed", "chain", "align", "total")},
-        "kernels_ms": {batch.KERNELS[i]: st["kern_ms"][i] for i in range(4)},
+        "kernels_ms": {batch.KERNELS[i]: st["kern_ms"][i] for i in range(len(batch.KERNELS)) if st["kern_launches"][i] > 0},
         "counts": {k: st[k] for k in ("n_bases", "n_minimizers", "n_anchors", "n_dp_jobs", "n_dp_cells", "n_matches")},
     }
     if rank == 0:

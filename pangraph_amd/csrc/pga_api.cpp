@@ -181,7 +181,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	double t0 = now_s();
 	ix.d_mid_occ.upload(group_mid_occ(ix, opt), ix.st);
 	SeedResult SR;
-	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st);
+	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm);
 	double t1 = now_s();
 	ChainResult CR;
 	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st, &ix.tm);
@@ -498,13 +498,13 @@ extern "C" int pga_stage_chain(const pga_params_t *params, int32_t n, const char
 		mm_mapopt_update(&mo, &ix->hdr);
 		*mid_occ = mo.mid_occ;
 		check_supported(mo, io.k, io.w);
-		ix->d_mid_occ.upload(group_mid_occ(*ix, mo), 0);
-		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, ix->d_mid_occ, SR, 0);
-		std::vector<u128> a = SR.a.download(0); a.resize(SR.n_a);
+		ix->d_mid_occ.upload(group_mid_occ(*ix, mo), ix->st);
+		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, ix->d_mid_occ, SR, ix->st);
+		std::vector<u128> a = SR.a.download(ix->st); a.resize(SR.n_a);
 		std::vector<uint64_t> flat(a.size() * 2);
 		for (size_t i = 0; i < a.size(); ++i) flat[2 * i] = a[i].x, flat[2 * i + 1] = a[i].y;
 		*anchors_xy = dup_out(flat); *anchor_off = dup_out(SR.h_q_aoff); *rep_len = dup_out(SR.h_rep_len);
-		ChainResult CR; chain_all(ix->S, SR.a, SR.q_aoff, SR.n_a, mo, io.k, CR, 0);
+		ChainResult CR; chain_all(ix->S, SR.a, SR.q_aoff, SR.n_a, mo, io.k, CR, ix->st);
 		*n_u = dup_out(CR.n_u); *n_v = dup_out(CR.n_v);
 		std::vector<uint64_t> uu(CR.u.begin(), CR.u.end()); uu.resize(SR.n_a);
 		*u = dup_out(uu);

@@ -526,7 +526,9 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
-			tm->kern[K_EXTD2].ms += ms; tm->kern[K_EXTD2].launches += 1; tm->kern[K_EXTD2].alg_bytes += 0.5 * bases; tm->dp_bases += bases; // 2-bit packed q+t reads; CIGAR bytes added below
+			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below
+			const int kk = c == 6 ? K_LL : c <= 1 ? K_EXTD2 : K_EXTD2_WIDE;
+			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->dp_bases += bases;
 			if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		}
 		PinVec<DpRes> r;

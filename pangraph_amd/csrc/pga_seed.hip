@@ -276,7 +276,7 @@ template <class T> static void excl_scan(const T *in, uint64_t *out, size_t n, h
 }
 
 void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<uint32_t> &grp_of_mz, const mm_mapopt_t &opt,
-              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st)
+              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st, Timers *tm)
 {
 	const int n_seq = S.n_seq;
 	const uint64_t n = M.n;
@@ -383,7 +383,7 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
 	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, a_raw.p, q_tie.p);
 	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
-	replay_sort_segments(O.a.p, n_a, O.q_aoff.p, nullptr, n_seq, q_tie.p, st);
+	replay_sort_segments(O.a.p, n_a, O.q_aoff.p, nullptr, n_seq, q_tie.p, st, tm);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipStreamSynchronize(st));
 	if (getenv("PGA_VERBOSE")) {

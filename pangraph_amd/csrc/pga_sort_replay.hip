@@ -59,9 +59,10 @@ void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_
 
 // sorts every flagged array [off[s], off[s] + len[s]) of `a` by x exactly as radix_sort_128x would (flag == nullptr: all;
 // len == nullptr: the arrays are contiguous, off has n_seg+1 entries)
-void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st)
+void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st, Timers *tm)
 {
 	if (n_seg <= 0 || n_total == 0) return;
+	EventTimer et(st);
 	const uint32_t cap = (uint32_t)std::min<uint64_t>(n_total / 65 + (uint64_t)n_seg + 64, 0x7fffffffu);
 	DBuf<RsRun> q0(cap), q1(cap);
 	DBuf<uint32_t> ctr(2 * 9 + 2);            // per pass: queue length and work counter
@@ -74,6 +75,8 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 		std::swap(qin, qout);
 	}
 	PGA_HIP(hipGetLastError());
+	const double ms = et.stop();
+	if (tm) { tm->kern[K_SORT].ms += ms; tm->kern[K_SORT].launches += 1; tm->kern[K_SORT].alg_bytes += 32.0 * (double)n_total; }   // every record read and written once (per level, at least one)
 	std::vector<uint32_t> h = ctr.download(st);
 	for (int pass = 0; pass <= 8; ++pass) if (h[2 * pass] > cap) throw std::runtime_error("pga: run queue overflow in the sort replay");
 }
