@@ -958,11 +958,18 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 		for (int round = 0; round < 100000; ++round) {
 			// run what was requested
 			{
-				size_t n_pend = 0;
-				for (int qi = 0; qi < n_seq; ++qi) n_pend += Q[qi].pending.size();
-				std::vector<DpJob> jb; std::vector<std::pair<int,int>> owner;
-				jb.reserve(n_pend); owner.reserve(n_pend);
-				for (int qi = 0; qi < n_seq; ++qi) { for (int id : Q[qi].pending) { jb.push_back(Q[qi].jobs[id]); owner.emplace_back(qi, id); } Q[qi].pending.clear(); }
+				std::vector<size_t> poff((size_t)n_seq + 1, 0);
+				for (int qi = 0; qi < n_seq; ++qi) poff[qi + 1] = poff[qi] + Q[qi].pending.size();
+				const size_t n_pend = poff[n_seq];
+				std::vector<DpJob> jb(n_pend); std::vector<std::pair<int,int>> owner(n_pend);
+				std::vector<double> cells_of((size_t)n_seq, 0.0);
+				parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
+					QueryCtx &q = Q[qi];
+					size_t o = poff[qi]; double cells = 0;
+					for (int id : q.pending) { jb[o] = q.jobs[id]; owner[o] = std::make_pair((int)qi, id); cells += (double)q.jobs[id].qlen * q.jobs[id].tlen; ++o; }
+					q.pending.clear();
+					cells_of[qi] = cells;
+				});
 				n_requested = jb.size();
 				if (!jb.empty()) {
 					std::vector<DpRes> rs;
@@ -971,7 +978,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 					double t_dp = getenv("PGA_VERBOSE") ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
 					dp_run(S.d_nt4.p, jb, P, rs, cg, st, tm);
 					if (t_dp > 0) fprintf(stderr, "[pga]   round %d: %zu DP problems in %.3f s\n", round, jb.size(), std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dp);
-					if (tm) { tm->dp_jobs += (double)jb.size(); for (auto &j : jb) tm->dp_cells += (double)j.qlen * j.tlen; }
+					if (tm) { tm->dp_jobs += (double)jb.size(); for (double c : cells_of) tm->dp_cells += c; }
 					const uint32_t *base = cg.data();
 					parallel_for((rs.size() + 65535) / 65536, n_threads, [&](size_t blk) {
 						const size_t lo = blk * 65536, hi = std::min(rs.size(), lo + 65536);

@@ -231,10 +231,10 @@ struct Iter { int32_t stack[CMAXD]; int top; };
 // The inner scan of lchain.c:322-349 is evaluated without the t[] array: t[j]==i holds exactly when some
 // candidate visited earlier in the scan (one with a larger key, hence any candidate at all) has p[]==j and
 // passes the bandwidth test, so "marked" is a set-membership stamp; the n_skip walk itself stays sequential.
-#define CF_W 2048          // ring capacity (anchors): live window + the staged block
+// ring capacity (anchors: live window + the staged block) is a template parameter; 2048 covers the ~800-anchor windows of
+// max_gap = 10 kb with room to spare (1024 was tried: too many segments outgrow it and have to be swept twice)
 #define CF_WI 512          // inner-window ring capacity
 #define CF_MAXIN 256       // inner candidates handled by the fast path
-#define CF_M (CF_W - 1)
 
 // lchain.c:232-248 on unpacked fields (segment-local: x is the 32-bit target position)
 __device__ __forceinline__ int32_t score_pair32(int32_t xi, int32_t yi, int32_t xj, int32_t yj, int32_t span_j, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)
@@ -259,11 +259,13 @@ struct __attribute__((aligned(16))) CfEnt { double pri; int32_t y, x; };
 // is in flight while the current one is swept) and f/p leave through the rings once per block, so the per-anchor
 // critical path touches LDS only.  Inside the sweep the wave is its own synchronisation domain (wavefront-scope
 // fences: LDS operations of one wave execute in order).
+template <int CF_W>
 __global__ __launch_bounds__(64)
 void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
                   uint64_t n_total, const uint64_t *__restrict__ q_aoff, int n_seq, ChainParams P,
-                  int32_t *__restrict__ f, int32_t *__restrict__ pp, uint32_t *__restrict__ seg_flag, unsigned long long *__restrict__ prof)
+                  int32_t *__restrict__ f, int32_t *__restrict__ pp, uint32_t *__restrict__ seg_flag, const uint32_t *__restrict__ only_flagged, unsigned long long *__restrict__ prof)
 {
+	constexpr int CF_M = CF_W - 1;
 	__shared__ CfEnt r_e[CF_W];
 	__shared__ int32_t r_f[CF_W];
 	__shared__ uint8_t s_sp[CF_W];
@@ -274,6 +276,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 	const uint32_t sidx = blockIdx.x;
 	if (sidx >= n_seg) return;
 	const uint32_t sg = seg_order[sidx];
+	if (only_flagged && !only_flagged[sg]) return;           // second attempt (larger rings) of the segments the first one gave up on
 	const uint64_t b = seg_start[sg], e = sg + 1 < n_seg ? seg_start[sg + 1] : n_total;
 	const int32_t n = (int32_t)(e - b);
 	const u128 *A = a + b;
@@ -821,7 +824,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
 		DBuf<unsigned long long> cprof(16); cprof.zero(st);
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
-		if (use_fast) hipLaunchKernelGGL(k_chain_fast, dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p,
+		if (use_fast) hipLaunchKernelGGL(k_chain_fast<2048>, dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr,
 		                                 verbose ? cprof.p : (unsigned long long*)nullptr);
 		const double ms_fast = verbose ? et.stop() : 0.0;
 		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
