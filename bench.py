@@ -117,8 +117,12 @@ def main():
     rb = batch.ResidentBatch(pb)                     # H2D happens here, outside the timed region
     units = float(pb.total_bases)
 
+    # host threads of this rank: the ranks of a node share one CPU quota
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    n_threads = max(2, usable_cpus() // max(1, local_world))
+
     def step(want_raw):
-        res = rb.align(sensitivity=10, want_raw=want_raw)
+        res = rb.align(sensitivity=10, want_raw=want_raw, n_threads=n_threads)
         if world > 1:
             gather_blobs((res.raw_matches or b"") + (res.raw_cigars or b""), dev, dst=0)
         return res

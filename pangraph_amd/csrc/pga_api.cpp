@@ -187,6 +187,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st, &ix.tm);
 	double t2 = now_s();
 	if (n_threads <= 0) { n_threads = usable_cpus(); }
+	set_thread_budget(n_threads);
 	align_batch(ix.S, opt, ix.I.k, SR.h_q_aoff, CR, SR.h_rep_len, ix.results, n_threads, &ix.tm, ix.st);
 	double t3 = now_s();
 	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;

@@ -132,6 +132,9 @@ struct EventTimer {
 // stage entry points (each in its own .hip/.cpp)
 // number of CPUs this process may run on (the affinity mask, not the machine total)
 int usable_cpus();
+// host threads the calling thread's batch may use (pga_params_t.n_threads; 0 = usable_cpus())
+void set_thread_budget(int n);
+int thread_budget();
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st);
 void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm = nullptr);
 std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f, hipStream_t st);

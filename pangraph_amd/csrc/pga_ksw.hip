@@ -374,7 +374,7 @@ static int dp_class(const DpJob &j, size_t need)
 // a few host threads for the per-problem loops (classification, gather, scatter): millions of problems per round
 template <class F> static void host_parallel(size_t n, F f)
 {
-	const int nt = (int)std::min<size_t>((size_t)usable_cpus(), n / 65536 + 1);
+	const int nt = (int)std::min<size_t>((size_t)thread_budget(), n / 65536 + 1);
 	if (nt <= 1) { f(0, n); return; }
 	std::vector<std::thread> th;
 	const size_t per = (n + nt - 1) / nt;
@@ -402,7 +402,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	});
 	{
 		// bucket the problem ids by class, in index order, with per-thread partial counts
-		const int nt = (int)std::min<size_t>((size_t)usable_cpus(), n / 65536 + 1);
+		const int nt = (int)std::min<size_t>((size_t)thread_budget(), n / 65536 + 1);
 		const size_t per = (n + nt - 1) / nt;
 		std::vector<std::array<size_t, DP_NCLASS>> cnt((size_t)nt);
 		std::vector<std::array<size_t, DP_NCLASS>> mx((size_t)nt);

@@ -60,6 +60,10 @@ int usable_cpus()
 	return c;
 }
 
+static thread_local int t_thread_budget = 0;
+void set_thread_budget(int n) { t_thread_budget = n; }
+int thread_budget() { return t_thread_budget > 0 ? t_thread_budget : usable_cpus(); }
+
 static inline uint8_t nt4_host(uint8_t r)
 {
 	uint8_t c = r & 0xdf;
