@@ -54,6 +54,32 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+PMC_KERNEL_PREFIX = {"k_sketch_tiles": "void pga::k_sketch_tiles", "k_chain_fast": "void pga::k_chain_fast", "k_bt_list+k_bt_walk": "pga::k_bt_",
+                     "k_extd2_fast": "void pga::k_extd2_fast", "k_extd2_wide": "void pga::k_extd2_wide", "k_ll_i16": "pga::k_ll_i16", "k_rs_pass": "pga::k_rs_"}
+
+
+def pmc_traffic(kernel: str, genomes: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/r01_*_pmc_hbm_traffic_<genomes>genomes.json: FETCH_SIZE and WRITE_SIZE in separate passes, in KB; FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 -- an upper bound for the narrower accesses).  None if there is no
+    PMC summary for this configuration."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{genomes}genomes.json")))
+    pre = PMC_KERNEL_PREFIX.get(kernel)
+    if not files or not pre:
+        return None
+    d = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        disp = 0
+        for k, v in d.get(c, {}).items():
+            if k.startswith(pre):
+                tot += mul * v["sum"] * 1024.0
+                disp += v["dispatches"]
+        n = max(n, disp)
+    return tot / n if n else None
+
+
 def _cpu_worker(args):
     so, seqs, names = args
     from pangraph_amd.mm2ffi import Mm2Lib
@@ -168,7 +194,7 @@ def main():
                    "genomes_per_gpu": args.genomes, "genome_length": args.length, "groups_per_gpu": args.genomes // 2,
                    "parallelism": f"groups sharded over {world} rank(s), match-list gather to rank 0"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
+                     "traffic": pmc_traffic(kname, args.genomes), "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
                      "alg_bytes_per_launch": kbytes / klaunch if klaunch else None},
         "stages_s": {k: st[k] for k in ("sketch", "index", "seed", "chain", "align", "total")},
         "kernels_ms": {batch.KERNELS[i]: st["kern_ms"][i] for i in range(len(batch.KERNELS)) if st["kern_launches"][i] > 0},

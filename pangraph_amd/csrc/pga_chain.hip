@@ -253,7 +253,10 @@ __device__ __forceinline__ int32_t score_pair32(int32_t xi, int32_t yi, int32_t 
 	return sc;
 }
 
-struct __attribute__((aligned(16))) CfEnt { double pri; int32_t y, x; };
+// ring entry: the RMQ priority -(f + 0.5*pen_gap*(x+y)) (lchain.c:288) is recomputed from f, x, y where it is needed
+// (keeping it would cost 8 of 21 B per ring slot, and the sweep is bounded by LDS occupancy at large batches)
+struct __attribute__((aligned(8))) CfEnt { int32_t y, x; };
+__device__ __forceinline__ double cf_pri(int32_t f, int32_t x, int32_t y, float pen_gap) { return -((double)f + 0.5 * (double)pen_gap * (double)(x + y)); }
 
 // One WAVE per segment.  Anchors are staged into LDS rings 64 at a time (one coalesced load per block, the next block
 // is in flight while the current one is swept) and f/p leave through the rings once per block, so the per-anchor
@@ -331,7 +334,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					if (j >= st && j < jend) {
 						const CfEnt ej = r_e[j & CF_M];
 						const bool in = ej.y > y_lo && (ej.y < yi || (ej.y == yi && seg_is_query_start && j == 0));
-						if (in) { if (ej.pri < best) best = ej.pri, best_j = j, tie = false; else if (ej.pri == best) tie = true; }
+						if (in) { const double pj = cf_pri(r_f[j & CF_M], ej.x, ej.y, P.pen_gap); if (pj < best) best = pj, best_j = j, tie = false; else if (pj == best) tie = true; }
 					}
 				};
 				// (a) completed 64-anchor blocks below i0 are represented by their summaries (lane b holds ring block b): a block
@@ -474,7 +477,6 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			const long long k4 = clock64();
 			if (lane == 0) {
 				r_f[i & CF_M] = max_f; r_p[i & (CF_WI - 1)] = max_j;
-				r_e[i & CF_M].pri = -((double)max_f + 0.5 * (double)P.pen_gap * (double)(xi + yi));
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			const long long k5 = clock64();
@@ -485,8 +487,9 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 		if (blk + 64 <= n) {
 			// summary of the finished block: minimum priority (and whether it is unique), y range
 			const CfEnt eb = r_e[(blk + lane) & CF_M];
-			const double mp = wave_min_f64(eb.pri);
-			const unsigned long long who = __ballot(eb.pri == mp);
+			const double pb = cf_pri(r_f[(blk + lane) & CF_M], eb.x, eb.y, P.pen_gap);
+			const double mp = wave_min_f64(pb);
+			const unsigned long long who = __ballot(pb == mp);
 			const int32_t ymin = wave_min_i32(eb.y), ymax = wave_max_i32(eb.y);
 			if (lane == ((blk >> 6) & (CF_W / 64 - 1))) {
 				sm_pri = mp; sm_arg = __popcll(who) == 1 ? blk + (int32_t)(__ffsll((long long)who) - 1) : -1;
