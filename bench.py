@@ -150,7 +150,10 @@ def main():
     def step(want_raw):
         res = rb.align(sensitivity=10, want_raw=want_raw, n_threads=n_threads)
         if world > 1:
-            gather_blobs((res.raw_matches or b"") + (res.raw_cigars or b""), dev, dst=0)
+            # the match list (records, then the CIGAR pool) goes to the rank that owns the graph
+            gather_blobs(res.raw_matches, dev, dst=0, as_bytes=False)
+            gather_blobs(res.raw_cigars, dev, dst=0, as_bytes=False)
+        res.close()
         return res
 
     for _ in range(args.warmup):

@@ -110,8 +110,21 @@ class PreparedBatch:
 class BatchResult:
     groups: List[List[PafRow]]
     stats: dict
-    raw_matches: Optional[bytes] = None   # packed pga_match_t[] (for the multi-GPU gather)
-    raw_cigars: Optional[bytes] = None
+    raw_matches: Optional[object] = None  # packed pga_match_t[] as a uint8 numpy VIEW of the result (for the multi-GPU gather)
+    raw_cigars: Optional[object] = None   # the CIGAR pool, same
+    _handle: Optional[object] = None      # keeps the native result alive while the views are in use
+
+    def close(self):
+        if self._handle is not None:
+            lib().pga_result_free(self._handle)
+            self._handle = None
+            self.raw_matches = self.raw_cigars = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _stats_dict(st) -> dict:
@@ -181,16 +194,20 @@ def _unpack(pb: PreparedBatch, out, want_rows: bool, want_raw: bool) -> BatchRes
                 groups[r.group].append(PafRow(qname=pb.names[b + r.qry], qlen=r.qry_len, qs=r.qry_start, qe=r.qry_end, strand="-" if r.reverse else "+",
                                               tname=pb.names[b + r.ref], tlen=r.ref_len, rs=r.ref_start, re=r.ref_end, mlen=r.matches, blen=r.length,
                                               mapq=r.quality, AS=r.align, de=r.divergence, cg=cigar, n_ambi=r.n_ambi, inv=r.inv))
-        raw_m = raw_c = None
         if want_raw:
+            import numpy as np
             n = d.pga_result_n_matches(out)
             nops = C.c_uint64()
             cg = d.pga_result_cigars(out, C.byref(nops))
-            raw_m = C.string_at(d.pga_result_matches(out), n * C.sizeof(pga_match_t)) if n else b""
-            raw_c = C.string_at(cg, nops.value * 4) if nops.value else b""
-        return BatchResult(groups, stats, raw_m, raw_c)
+            raw_m = np.ctypeslib.as_array(C.cast(d.pga_result_matches(out), C.POINTER(C.c_uint8)), shape=(n * C.sizeof(pga_match_t),)) if n else np.zeros(0, np.uint8)
+            raw_c = np.ctypeslib.as_array(C.cast(cg, C.POINTER(C.c_uint8)), shape=(nops.value * 4,)) if nops.value else np.zeros(0, np.uint8)
+            res = BatchResult(groups, stats, raw_m, raw_c, out)    # the views point into the native result: freed by close()
+            out = None
+            return res
+        return BatchResult(groups, stats)
     finally:
-        d.pga_result_free(out)
+        if out is not None:
+            d.pga_result_free(out)
 
 
 def align_groups(groups, names=None, **kw) -> BatchResult:

@@ -16,6 +16,10 @@ def _worker(rank, world, port, q):
     mine = shard_groups(7, rank, world)
     blob = b"".join(bytes([g]) * (g + 1) for g in mine)           # variable length per rank
     got = gather_blobs(blob, dev, dst=0)
+    import numpy as np
+    got_np = gather_blobs(np.frombuffer(blob, dtype=np.uint8), dev, dst=0, as_bytes=False)      # zero-copy input, tensor output (bench.py's path)
+    if got_np is not None:
+        assert [bytes(t.numpy().tobytes()) for t in got_np] == got
     mx = max_over_ranks(float(rank + 1), dev)
     sm = sum_over_ranks(float(len(mine)), dev)
     q.put((rank, mine, got, mx, sm))
