@@ -951,24 +951,30 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	});
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   align: regions+plans %.3f s (%d threads)\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_align0, n_threads);
 	// ---- rounds ----
+	// The queries are dealt into a few SETS that run their rounds concurrently (one host thread, one stream and one
+	// device-memory arena each): while the GPU works on one set's problems the host classifies, collects and advances
+	// another's, and the short dependent rounds at the end of one set hide behind the bulk of the next.
 	if (opt.flag & MM_F_CIGAR) {
 		DpParams P{opt.q, opt.e, opt.q2, opt.e2, D.mat[0], D.mat[1], D.mat[24]};
+		auto run_rounds = [&](const std::vector<int> &qs, int set_id, int n_threads, hipStream_t st, Timers *tm) {
+		const size_t n_q = qs.size();
 		size_t n_requested = 0;
 		std::list<PinVec<uint32_t>> pools;
 		for (int round = 0; round < 100000; ++round) {
 			// run what was requested
 			{
-				std::vector<size_t> poff((size_t)n_seq + 1, 0);
-				for (int qi = 0; qi < n_seq; ++qi) poff[qi + 1] = poff[qi] + Q[qi].pending.size();
-				const size_t n_pend = poff[n_seq];
+				std::vector<size_t> poff(n_q + 1, 0);
+				for (size_t k = 0; k < n_q; ++k) poff[k + 1] = poff[k] + Q[qs[k]].pending.size();
+				const size_t n_pend = poff[n_q];
 				std::vector<DpJob> jb(n_pend); std::vector<std::pair<int,int>> owner(n_pend);
-				std::vector<double> cells_of((size_t)n_seq, 0.0);
-				parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
+				std::vector<double> cells_of(n_q, 0.0);
+				parallel_for(n_q, n_threads, [&](size_t k) {
+					const size_t qi = (size_t)qs[k];
 					QueryCtx &q = Q[qi];
-					size_t o = poff[qi]; double cells = 0;
+					size_t o = poff[k]; double cells = 0;
 					for (int id : q.pending) { jb[o] = q.jobs[id]; owner[o] = std::make_pair((int)qi, id); cells += (double)q.jobs[id].qlen * q.jobs[id].tlen; ++o; }
 					q.pending.clear();
-					cells_of[qi] = cells;
+					cells_of[k] = cells;
 				});
 				n_requested = jb.size();
 				if (!jb.empty()) {
@@ -977,7 +983,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 					PinVec<uint32_t> &cg = pools.back();          // stays alive until the batch is done: results point into it
 					double t_dp = getenv("PGA_VERBOSE") ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
 					dp_run(S.d_nt4.p, jb, P, rs, cg, st, tm);
-					if (t_dp > 0) fprintf(stderr, "[pga]   round %d: %zu DP problems in %.3f s\n", round, jb.size(), std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dp);
+					if (t_dp > 0) fprintf(stderr, "[pga]   set %d round %d: %zu DP problems in %.3f s\n", set_id, round, jb.size(), std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dp);
 					if (tm) { tm->dp_jobs += (double)jb.size(); for (double c : cells_of) tm->dp_cells += c; }
 					const uint32_t *base = cg.data();
 					parallel_for((rs.size() + 65535) / 65536, n_threads, [&](size_t blk) {
@@ -993,7 +999,8 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 			}
 			const double t_adv0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 			std::atomic<int> unfinished(0);
-			parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
+			parallel_for(n_q, n_threads, [&](size_t k) {
+				const size_t qi = (size_t)qs[k];
 				QueryCtx &q = Q[qi];
 				if (q.finished) return;
 				// walk the list in the reference's order (align.c:981-1010); stop at the first region that must wait
@@ -1034,12 +1041,50 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 				q.finished = true; q.pool.clear(); q.list.clear(); q.a.clear(); q.a.shrink_to_fit();
 			});
 			if (g_prof) { fprintf(stderr, "[pga]   host phases (thread-summed s): segments %.3f, fetch %.3f, update_extra %.3f, plan %.3f, finish %.3f; z-drop test skipped %lld, run %lld (%.3f s)\n", g_ns[0] * 1e-9, g_ns[1] * 1e-9, g_ns[2] * 1e-9, g_ns[3] * 1e-9, g_ns[4] * 1e-9, (long long)g_ns[5], (long long)g_ns[6], g_ns[7] * 1e-9); for (auto &x : g_ns) x = 0; }
-			if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   round %d: host advance %.3f s\n", round, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_adv0);
+			if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   set %d round %d: host advance %.3f s\n", set_id, round, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_adv0);
 			if (unfinished.load() == 0) break;
-			bool any_pending = false; for (auto &q : Q) any_pending |= !q.pending.empty();
+			bool any_pending = false; for (int qi : qs) any_pending |= !Q[qi].pending.empty();
 			if (!any_pending) throw std::runtime_error("pga: alignment driver stalled");
 			(void)n_requested;
 		}
+		};
+		// deal the queries by anchor count (largest first, round robin): balanced sets
+		// (two sets pay from a few hundred queries on; below that the few long problems of a set only get in each other's way)
+		int n_sets = getenv("PGA_ALIGN_SETS") ? atoi(getenv("PGA_ALIGN_SETS")) : (n_seq >= 256 ? 2 : 1);
+		if (n_sets < 1) n_sets = 1;
+		if (n_seq < 8 * n_sets) n_sets = 1;
+		std::vector<int> order((size_t)n_seq);
+		for (int i = 0; i < n_seq; ++i) order[i] = i;
+		std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Q[x].n_a > Q[y].n_a; });
+		std::vector<std::vector<int>> sets((size_t)n_sets);
+		for (int i = 0; i < n_seq; ++i) sets[(size_t)(i % n_sets)].push_back(order[i]);
+		for (auto &v : sets) std::sort(v.begin(), v.end());
+		if (n_sets == 1) run_rounds(sets[0], 0, n_threads, st, tm);
+		else {
+			int dev = 0; PGA_HIP(hipGetDevice(&dev));
+			const int arena0 = dev_get_arena();
+			std::vector<Timers> tms((size_t)n_sets);
+			std::vector<std::string> errs((size_t)n_sets);
+			std::vector<std::thread> th;
+			for (int k = 0; k < n_sets; ++k) th.emplace_back([&, k] {
+				hipStream_t ss = nullptr;
+				try {
+					PGA_HIP(hipSetDevice(dev));
+					dev_set_arena(arena0 * 16 + 1000 + k);
+					set_thread_budget(std::max(1, n_threads / n_sets));
+					PGA_HIP(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+					run_rounds(sets[(size_t)k], k, std::max(1, n_threads / n_sets), ss, tm ? &tms[(size_t)k] : nullptr);
+				} catch (std::exception &e) { errs[(size_t)k] = e.what(); if (errs[(size_t)k].empty()) errs[(size_t)k] = "unknown error"; }
+				if (ss) { (void)hipStreamSynchronize(ss); (void)hipStreamDestroy(ss); }
+			});
+			for (auto &t : th) t.join();
+			for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+			if (tm) for (const Timers &t : tms) {
+				tm->dp_jobs += t.dp_jobs; tm->dp_cells += t.dp_cells; tm->dp_bases += t.dp_bases; tm->dp_cigar_ops += t.dp_cigar_ops;
+				for (int i = 0; i < K_COUNT; ++i) { tm->kern[i].ms += t.kern[i].ms; tm->kern[i].launches += t.kern[i].launches; tm->kern[i].alg_bytes += t.kern[i].alg_bytes; }
+			}
+		}
+
 	} else {
 		for (int qi = 0; qi < n_seq; ++qi) {
 			QueryCtx &q = Q[qi];

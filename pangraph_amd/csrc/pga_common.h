@@ -24,7 +24,8 @@ namespace pga {
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_trim();        // release every idle block
-void dev_set_arena(int arena);   // calling thread: recycle device blocks only within this arena (one per concurrent sub-batch)
+void dev_set_arena(int arena);
+int dev_get_arena();   // calling thread: recycle device blocks only within this arena (one per concurrent sub-batch)
 
 // ---- device buffer ----
 template <class T> struct DBuf {

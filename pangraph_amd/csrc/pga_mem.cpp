@@ -42,6 +42,7 @@ size_t cache_limit()
 // that freed it; handing it to the same arena keeps every later use behind those kernels in stream order.  Concurrent
 // sub-batches (pga_api.cpp) run with one arena and one stream each.
 void dev_set_arena(int arena) { t_arena = arena; }
+int dev_get_arena() { return t_arena; }
 
 void *dev_alloc(size_t bytes)
 {
