@@ -202,6 +202,7 @@ def main():
         "stages_s": {k: st[k] for k in ("sketch", "index", "seed", "chain", "align", "total")},
         "kernels_ms": {batch.KERNELS[i]: st["kern_ms"][i] for i in range(len(batch.KERNELS)) if st["kern_launches"][i] > 0},
         "counts": {k: st[k] for k in ("n_bases", "n_minimizers", "n_anchors", "n_dp_jobs", "n_dp_cells", "n_matches")},
+        "aligned_span_gbp_s_per_gpu": st["aligned_span"] * args.steps / dt / 1e9,      # secondary: sum of (qe - qs) of this rank's matches per second
     }
     if rank == 0:
         if args.cpu_budget > 0 and world == 1:

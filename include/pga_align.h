@@ -49,6 +49,7 @@ typedef struct {                 /* stage wall times (s) and work counters of a 
 	 * [0] k_sketch_tiles  [1] k_chain_fast (+k_chain_segments)  [2] k_bt_list + k_bt_walk  [3] k_extd2_fast (register tiles)
 	 * [4] k_extd2_wide  [5] k_ll_i16  [6] k_rs_init + k_rs_pass (sort replay)  [7] unused */
 	double kern_ms[8], kern_launches[8], kern_alg_bytes[8];
+	double aligned_span;         /* sum of (qry_end - qry_start) over the emitted matches (secondary metric) */
 } pga_stats_t;
 
 /* seqs: n_seqs sequences, ASCII, NOT necessarily NUL-terminated (lengths in seq_lens); names: NUL-terminated

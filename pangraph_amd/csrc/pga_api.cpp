@@ -310,6 +310,7 @@ static void collect_results(PgaIdx &ixr, int g0, const std::vector<int64_t> &gof
 		m.cigar_off = R.cig.size(), m.n_cigar = (uint32_t)r.cigar.size();
 		R.cig.insert(R.cig.end(), r.cigar.begin(), r.cigar.end());
 		R.m.push_back(m);
+		R.st.aligned_span += (double)(r.qe - r.qs);
 	}
 	const Timers &t = ix->tm;
 	R.st.upload += t.upload, R.st.sketch += t.sketch, R.st.index += t.index, R.st.seed += t.seed, R.st.chain += t.chain, R.st.align += t.align;
