@@ -7,19 +7,34 @@
 #include "pga_common.h"
 #include "pga_sort_wave.h"
 #include "pga_pipeline.h"
+#include <cstdio>
 
 namespace pga {
 
-struct RsRun { uint64_t start; uint32_t len; int32_t shift; };
+struct RsRun { uint64_t start; uint64_t vary; uint32_t len; int32_t shift; };   // vary: bits that differ somewhere in the whole array (levels without any are skipped)
 
-__device__ __forceinline__ void rs_push(RsRun *out, uint32_t *n_out, uint32_t cap, uint64_t start, uint32_t len, int shift, int lane)
+// highest byte at or below `shift` in which the array's keys differ (-8: none)
+__device__ __forceinline__ int rs_next_level(uint64_t vary, int shift)
 {
-	if (lane == 0) { const uint32_t k = atomicAdd(n_out, 1u); if (k < cap) { out[k].start = start; out[k].len = len; out[k].shift = shift; } }
+	while (shift >= 0 && ((vary >> shift) & 255) == 0) shift -= 8;
+	return shift;
+}
+// runs of at most RS_SMALL records go to the queue of the LDS-resident sorter
+__device__ __forceinline__ void rs_push2(RsRun *out, uint32_t *n_out, RsRun *out_s, uint32_t *n_out_s, uint32_t cap, uint64_t start, uint32_t len, int shift, uint64_t vary, int lane);
+__device__ __forceinline__ void rs_push(RsRun *out, uint32_t *n_out, uint32_t cap, uint64_t start, uint32_t len, int shift, uint64_t vary, int lane)
+{
+	if (lane == 0) { const uint32_t k = atomicAdd(n_out, 1u); if (k < cap) { out[k].start = start; out[k].len = len; out[k].shift = shift; out[k].vary = vary; } }
+}
+
+__device__ __forceinline__ void rs_push2(RsRun *out, uint32_t *n_out, RsRun *out_s, uint32_t *n_out_s, uint32_t cap, uint64_t start, uint32_t len, int shift, uint64_t vary, int lane)
+{
+	if (len <= 1024) rs_push(out_s, n_out_s, cap, start, len, shift, vary, lane); else rs_push(out, n_out, cap, start, len, shift, vary, lane);
 }
 
 // one wave per array: small arrays are finished here, the others enter the run queue at their first non-trivial level
 __global__ __launch_bounds__(64)
-void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int64_t *__restrict__ len, int n_seg, const uint32_t *__restrict__ flag, RsRun *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t cap)
+void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int64_t *__restrict__ len, int n_seg, const uint32_t *__restrict__ flag, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap)
 {
 	__shared__ RsLds L;
 	const int s = blockIdx.x, lane = threadIdx.x;
@@ -31,13 +46,13 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 	const uint64_t vary = rs_varying_bits(a + b, n, lane);
 	if (vary == 0) return;
 	const int shift = (63 - __clzll((long long)vary)) & ~7;
-	rs_push(out, n_out, cap, b, (uint32_t)n, shift, lane);
+	rs_push2(out, n_out, out_s, n_out_s, cap, b, (uint32_t)n, shift, vary, lane);
 }
 
 // persistent waves over the run queue of this pass
 __global__ __launch_bounds__(64)
-void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t cap,
-               uint32_t *__restrict__ work)
+void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof)
 {
 	__shared__ RsLds L;
 	const int lane = threadIdx.x;
@@ -48,12 +63,138 @@ void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_
 		r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 		if (r >= n_runs) break;
 		const RsRun R = in[r];
+		const unsigned long long tk0 = wall_clock64();
 		u128 *beg = a + R.start;
 		const int64_t n = R.len;
 		int shift = R.shift;
-		while (!rs_level_wave(beg, n, shift, L, lane) && shift > 0) shift -= 8;     // levels that leave the run in one bucket
+		uint32_t cnt[4], off[4];
+		while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
+		const unsigned long long tk1 = wall_clock64();
+		if (prof && lane == 0) { atomicAdd(&prof[0], tk1 - tk0); atomicMax(&prof[1], tk1 - tk0); }
+		if (shift <= 0) continue;                                // nothing below the last byte
+		const int next = rs_next_level(R.vary, shift - 8);
+		// buckets of this level: <= 64 records are insertion-sorted now (ksort.h:142), larger ones queue for the next level that can split them
+		if (next < 0) continue;                                  // the keys of a bucket agree in every lower byte: nothing left to order
+		rs_split_buckets(beg, n, shift, cnt, off, L, lane, [&](int64_t rb, int64_t len) { rs_push2(out, n_out, out_s, n_out_s, cap, R.start + (uint64_t)rb, (uint32_t)len, next, R.vary, lane); });
+		if (prof && lane == 0) { const unsigned long long tk2 = wall_clock64(); atomicAdd(&prof[2], tk2 - tk1); atomicMax(&prof[3], tk2 - tk1); }
+	}
+}
+
+// ---- runs of at most RS_SMALL records: the whole remaining sort inside LDS, one wave per run ----
+// Same replay (ksort.h:118-149) with the records resident in LDS: a displacement step is two LDS accesses, buckets are
+// known from the head/tail arrays (no rescanning), buckets <= 64 are insertion-sorted one lane each, larger ones go on a
+// small LDS stack for the next level that can split them.  20 KB of LDS per wave, so eight waves share a CU.
+#define RS_SMALL 1024
+struct __attribute__((aligned(16))) RsSmallLds {
+	u128 buf[RS_SMALL];
+	uint32_t head[256], tail[256];
+	uint16_t st_start[32], st_len[32]; int8_t st_shift[32];
+};
+
+__device__ inline void rs_sort_small(u128 *beg, int n, int shift0, uint64_t vary, RsSmallLds &L, int lane)
+{
+	for (int i = lane; i < n; i += 64) L.buf[i] = ld128(&beg[i]);
+	int top = 0;
+	if (lane == 0) { L.st_start[0] = 0; L.st_len[0] = (uint16_t)n; L.st_shift[0] = (int8_t)shift0; }
+	top = 1;
+	rs_fence_wave();
+	while (top > 0) {
+		--top;
+		const int b0 = L.st_start[top], m = L.st_len[top];
+		int shift = L.st_shift[top];
+		u128 *B = L.buf + b0;
+		uint32_t cnt[4], off[4]; unsigned long long nonempty[4];
+		// first level at or below `shift` that splits the run
+		for (;;) {
+			for (int d = lane; d < 256; d += 64) L.head[d] = 0;
+			rs_fence_wave();
+			for (int i = lane; i < m; i += 64) atomicAdd(&L.head[(uint32_t)((B[i].x >> shift) & 255)], 1u);
+			rs_fence_wave();
+			uint32_t run = 0, n_ne = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				cnt[k] = L.head[lane + 64 * k];
+				nonempty[k] = __ballot(cnt[k] > 0);
+				const uint32_t inc = wave_prefix_sum_incl(cnt[k]);
+				off[k] = run + inc - cnt[k];
+				run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+				n_ne += (uint32_t)__popcll(nonempty[k]);
+			}
+			rs_fence_wave();
+			if (n_ne > 1) break;
+			shift = rs_next_level(vary, shift - 8);
+			if (shift < 0) break;
+		}
+		if (shift < 0) continue;                                 // all keys of the run are equal
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { L.head[lane + 64 * k] = off[k]; L.tail[lane + 64 * k] = off[k] + cnt[k]; }
+		rs_fence_wave();
+		// the walk
+#pragma unroll 1
+		for (int k = 0; k < 4; ++k) {
+			unsigned long long todo = nonempty[k];
+			while (todo) {
+				const int d = 64 * k + (__ffsll((long long)todo) - 1);
+				todo &= todo - 1;
+				uint32_t h = L.head[d]; const uint32_t tl = L.tail[d];
+				while (h < tl) {
+					const uint32_t pos = h + (uint32_t)lane;
+					const unsigned long long fm = __ballot(pos < tl && (uint32_t)((B[pos < tl ? pos : tl - 1].x >> shift) & 255) != (uint32_t)d);
+					if (fm == 0) { h += 64; continue; }
+					h += (uint32_t)(__ffsll((long long)fm) - 1);
+					u128 carry = B[h];
+					int dst = (int)((carry.x >> shift) & 255);
+					do {
+						const uint32_t hd = L.head[dst];
+						const u128 nxt = B[hd];
+						rs_fence_wave();
+						if (lane == 0) { B[hd] = carry; L.head[dst] = hd + 1; }
+						rs_fence_wave();
+						carry = nxt;
+						dst = (int)((carry.x >> shift) & 255);
+					} while (dst != d);
+					if (lane == 0) B[h] = carry;
+					rs_fence_wave();
+					++h;
+				}
+			}
+		}
 		if (shift == 0) continue;
-		rs_runs_wave(beg, n, shift, L, lane, [&](int64_t rb, int64_t len) { rs_push(out, n_out, cap, R.start + (uint64_t)rb, (uint32_t)len, shift - 8, lane); });
+		const int next = rs_next_level(vary, shift - 8);
+		if (next < 0) continue;
+		// buckets: small ones are sorted by their lane now, large ones wait on the stack
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool big = cnt[k] > 64;
+			if (!big && cnt[k] > 1) rs_insertion(B + off[k], B + off[k] + cnt[k]);
+			unsigned long long bm = __ballot(big);
+			while (bm) {
+				const int src = __ffsll((long long)bm) - 1;
+				bm &= bm - 1;
+				const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off[k], src), c = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k], src);
+				if (lane == 0) { L.st_start[top] = (uint16_t)(b0 + o); L.st_len[top] = (uint16_t)c; L.st_shift[top] = (int8_t)next; }
+				++top;
+			}
+		}
+		rs_fence_wave();
+	}
+	for (int i = lane; i < n; i += 64) beg[i] = L.buf[i];
+}
+
+__global__ __launch_bounds__(64)
+void k_rs_small(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, uint32_t cap, uint32_t *__restrict__ work)
+{
+	__shared__ RsSmallLds L;
+	const int lane = threadIdx.x;
+	const uint32_t n_runs = *n_in < cap ? *n_in : cap;
+	for (;;) {
+		uint32_t r = 0;
+		if (lane == 0) r = atomicAdd(work, 1u);
+		r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+		if (r >= n_runs) break;
+		const RsRun R = in[r];
+		rs_sort_small(a + R.start, (int)R.len, R.shift, R.vary, L, lane);
+		rs_fence_wg();
 	}
 }
 
@@ -64,21 +205,46 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	if (n_seg <= 0 || n_total == 0) return;
 	EventTimer et(st);
 	const uint32_t cap = (uint32_t)std::min<uint64_t>(n_total / 65 + (uint64_t)n_seg + 64, 0x7fffffffu);
-	DBuf<RsRun> q0(cap), q1(cap);
+	DBuf<RsRun> q0(cap), q1(cap), qs(cap);    // two generations of large runs, and the runs small enough for the LDS sorter
 	DBuf<uint32_t> ctr(2 * 9 + 2);            // per pass: queue length and work counter
 	ctr.zero(st);
-	hipLaunchKernelGGL(k_rs_init, dim3((unsigned)n_seg), dim3(64), 0, st, a, d_off, d_len, n_seg, d_flag, q0.p, ctr.p + 0, cap);
+	hipLaunchKernelGGL(k_rs_init, dim3((unsigned)n_seg), dim3(64), 0, st, a, d_off, d_len, n_seg, d_flag, q0.p, ctr.p + 0, qs.p, ctr.p + 18, cap);
 	const unsigned grid = 2048;
 	RsRun *qin = q0.p, *qout = q1.p;
+	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
+	DBuf<unsigned long long> dprof(32); dprof.zero(st);
+	double pass_ms[9] = {0};
+	if (verbose) { pass_ms[8] = et.stop(); }
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
-		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), cap, ctr.p + 2 * pass + 1);
+		EventTimer ep(st);
+		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr);
+		if (verbose) {
+			pass_ms[pass] = ep.stop();
+			uint32_t nr = 0; PGA_HIP(hipMemcpy(&nr, ctr.p + 2 * (pass + 1), 4, hipMemcpyDeviceToHost));
+			if (nr > 0 && nr <= cap) {
+				std::vector<RsRun> hr(nr); PGA_HIP(hipMemcpy(hr.data(), qout, (size_t)nr * sizeof(RsRun), hipMemcpyDeviceToHost));
+				uint64_t sum = 0; uint32_t mx = 0; int sh_min = 64, sh_max = -8;
+				for (auto &r : hr) { sum += r.len; mx = std::max(mx, r.len); sh_min = std::min(sh_min, r.shift); sh_max = std::max(sh_max, r.shift); }
+				fprintf(stderr, "[pga]     after pass %d: %u runs queued, %llu records, longest %u, shifts %d..%d\n", pass, nr, (unsigned long long)sum, mx, sh_min, sh_max);
+			}
+			{
+				std::vector<unsigned long long> pr = dprof.download(st);
+				fprintf(stderr, "[pga]     pass %d: %.1f ms; walks: sum %.1f ms, longest %.2f ms; bucket splitting: sum %.1f ms, longest %.2f ms\n", pass, pass_ms[pass], pr[4 * pass] * 1e-5, pr[4 * pass + 1] * 1e-5, pr[4 * pass + 2] * 1e-5, pr[4 * pass + 3] * 1e-5);
+			}
+		}
 		std::swap(qin, qout);
 	}
+	// the small runs were final the moment they were queued: one launch sorts them all
+	EventTimer es(st);
+	hipLaunchKernelGGL(k_rs_small, dim3(8192), dim3(64), 0, st, a, qs.p, ctr.p + 18, cap, ctr.p + 19);
+	const double ms_small = verbose ? es.stop() : 0.0;
 	PGA_HIP(hipGetLastError());
 	const double ms = et.stop();
 	if (tm) { tm->kern[K_SORT].ms += ms; tm->kern[K_SORT].launches += 1; tm->kern[K_SORT].alg_bytes += 32.0 * (double)n_total; }   // every record read and written once (per level, at least one)
 	std::vector<uint32_t> h = ctr.download(st);
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   sort replay: %llu records in %d arrays, %.3f ms; runs per pass: %u %u %u %u %u %u %u %u; ms: init %.1f, passes %.1f %.1f %.1f %.1f %.1f; %u small runs %.1f ms\n", (unsigned long long)n_total, n_seg, ms, h[0], h[2], h[4], h[6], h[8], h[10], h[12], h[14], pass_ms[8], pass_ms[0], pass_ms[1], pass_ms[2], pass_ms[3], pass_ms[4], h[18], ms_small);
 	for (int pass = 0; pass <= 8; ++pass) if (h[2 * pass] > cap) throw std::runtime_error("pga: run queue overflow in the sort replay");
+	if (h[18] > cap) throw std::runtime_error("pga: run queue overflow in the sort replay");
 }
 
 } // namespace pga

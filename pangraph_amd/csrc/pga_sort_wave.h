@@ -15,17 +15,19 @@
 #pragma once
 #include "pga_common.h"
 #include "pga_sort_exact.h"
+#include "pga_wave.h"
 
 namespace pga {
 
-#define RS_WIN 16
+#define RS_POOL 4096          // records of window space shared by the non-empty buckets of a level (64 KB)
 #define RS_NONE 0xffffffffu
 
 struct __attribute__((aligned(16))) RsLds {
-	u128 win[256 * RS_WIN];      // per-bucket window over [wbase, wbase+RS_WIN)
+	u128 win[RS_POOL];           // bucket b owns win[wslot[b] << wlog .. +(1 << wlog)): a write-back window over [wbase, wbase + (1 << wlog))
 	u128 ins[64];                // insertion-sort staging
 	uint32_t head[256], tail[256], wbase[256];
-	unsigned long long prof[4];  // ticks: varying-bit pass, histograms, walks, run windows (diagnostics)
+	uint8_t wslot[256];
+	unsigned long long prof[4];  // ticks (diagnostics)
 };
 
 __device__ __forceinline__ u128 ld128(const u128 *p) { u128 v; v.x = p->x; v.y = p->y; return v; }
@@ -34,87 +36,151 @@ __device__ __forceinline__ void rs_fence_wave() { __builtin_amdgcn_fence(__ATOMI
 __device__ __forceinline__ void rs_fence_wg() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // write the consumed part of bucket d's window back (positions [wbase, head))
-__device__ __forceinline__ void rs_flush(u128 *beg, RsLds &L, int d, int lane)
+__device__ __forceinline__ void rs_flush(u128 *beg, RsLds &L, int d, int wlog, int lane)
 {
 	const uint32_t wb = L.wbase[d];
 	if (wb == RS_NONE) return;
 	const uint32_t cnt = L.head[d] - wb;
-	if ((uint32_t)lane < cnt) beg[wb + lane] = L.win[d * RS_WIN + lane];
+	if ((uint32_t)lane < cnt) beg[wb + lane] = L.win[((uint32_t)L.wslot[d] << wlog) + lane];
 	rs_fence_wave();
 	if (lane == 0) L.wbase[d] = RS_NONE;
 	rs_fence_wave();
 }
 
-// one level (ksort.h:118-146) on [beg, beg+n)
-__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane)
+// one level (ksort.h:118-146) on [beg, beg+n); false if every record has the same digit (the walk is the identity)
+__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4])
 {
-	const unsigned long long t0 = wall_clock64();
 	for (int d = lane; d < 256; d += 64) L.head[d] = 0, L.wbase[d] = RS_NONE;
-	rs_fence_wg();
-	const uint32_t first = (uint32_t)((beg[0].x >> shift) & 255);
-	bool diff = false;
-	for (int64_t i = lane; i < n; i += 64) {
-		const uint32_t d = (uint32_t)((beg[i].x >> shift) & 255);
-		atomicAdd(&L.head[d], 1u);
-		diff |= d != first;
+	rs_fence_wave();
+	// digit histogram, four loads in flight per lane
+	for (int64_t i0 = 0; i0 < n; i0 += 256) {
+		uint32_t dg[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; dg[k] = i < n ? (uint32_t)((beg[i].x >> shift) & 255) : 256u; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) if (dg[k] < 256u) atomicAdd(&L.head[dg[k]], 1u);
 	}
-	rs_fence_wg();
-	const unsigned long long t1 = wall_clock64();
-	if (lane == 0) L.prof[1] += t1 - t0;
-	if (!__ballot(diff)) return false;                         // one bucket: the walk is the identity
-	if (lane == 0) { uint32_t pos = 0; for (int d = 0; d < 256; ++d) { const uint32_t c = L.head[d]; L.head[d] = pos; pos += c; L.tail[d] = pos; } }
-	rs_fence_wg();
-	for (int d = 0; d < 256; ++d) {
-		uint32_t h = L.head[d]; const uint32_t tl = L.tail[d];
-		rs_flush(beg, L, d, lane);                              // slots filled while d was a destination
-		// bucket d is scanned through a 64-record register window (slots at or beyond a head still hold the original
-		// records, and nothing but this loop writes them while d is the current bucket)
-		uint32_t cw = h; unsigned long long fm = 0; bool have = false, dirty = false;
-		u128 rec; rec.x = 0, rec.y = 0;
-		while (h < tl) {
-			if (!have || h - cw >= 64) {
-				if (dirty) beg[cw + (uint32_t)lane] = rec;
-				cw = h; dirty = false; have = true;
-				const uint32_t pos = cw + (uint32_t)lane;
-				if (pos < tl) rec = ld128(&beg[pos]);
-				fm = __ballot(pos < tl && (uint32_t)((rec.x >> shift) & 255) != (uint32_t)d);
-			}
-			const unsigned long long m = fm >> (h - cw);             // foreign records at positions >= h
-			if (m == 0) { h = cw + 64; continue; }
-			h += (uint32_t)(__ffsll((long long)m) - 1);
-			// displacement chain starting at the foreign record beg[h] (all lanes follow it; lane 0 owns the LDS writes)
-			const int sl = (int)(h - cw);
-			u128 carry;
-			carry.x = (uint64_t)(uint32_t)rl32((int)(uint32_t)rec.x, sl) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(rec.x >> 32), sl) << 32;
-			carry.y = (uint64_t)(uint32_t)rl32((int)(uint32_t)rec.y, sl) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(rec.y >> 32), sl) << 32;
-			int dst = (int)((carry.x >> shift) & 255);
-			do {
-				const uint32_t hd = L.head[dst];
-				uint32_t wb = L.wbase[dst];
-				if (wb == RS_NONE || hd - wb >= RS_WIN) {
-					rs_flush(beg, L, dst, lane);
-					const uint32_t p2 = hd + (uint32_t)lane;
-					if (lane < RS_WIN && p2 < L.tail[dst]) L.win[dst * RS_WIN + lane] = ld128(&beg[p2]);
-					if (lane == 0) L.wbase[dst] = hd;
-					wb = hd;
-					rs_fence_wave();
-				}
-				const u128 nxt = L.win[dst * RS_WIN + (hd - wb)];
-				rs_fence_wave();
-				if (lane == 0) { L.win[dst * RS_WIN + (hd - wb)] = carry; L.head[dst] = hd + 1; }
-				rs_fence_wave();
-				carry = nxt;
-				dst = (int)((carry.x >> shift) & 255);
-			} while (dst != d);
-			if (lane == sl) rec = carry, dirty = true;
-			++h;
+	rs_fence_wave();
+	// counts -> offsets: lane l holds buckets l, l+64, l+128, l+192
+	unsigned long long nonempty[4];
+	uint32_t run = 0, n_ne = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		cnt[k] = L.head[lane + 64 * k];
+		nonempty[k] = __ballot(cnt[k] > 0);
+		const uint32_t inc = wave_prefix_sum_incl(cnt[k]);
+		off[k] = run + inc - cnt[k];
+		run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+		n_ne += (uint32_t)__popcll(nonempty[k]);
+	}
+	if (n_ne <= 1) return false;
+	// window space: the non-empty buckets share the pool, 16 to 64 records each
+	int wlog = 4;
+	while (wlog < 6 && (n_ne << (wlog + 1)) <= RS_POOL) ++wlog;
+	const uint32_t W = 1u << wlog;
+	{
+		uint32_t rank0 = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int b = lane + 64 * k;
+			L.head[b] = off[k]; L.tail[b] = off[k] + cnt[k];
+			L.wslot[b] = (uint8_t)(rank0 + (uint32_t)__popcll(nonempty[k] & ((1ULL << lane) - 1)));
+			rank0 += (uint32_t)__popcll(nonempty[k]);
 		}
-		if (dirty) beg[cw + (uint32_t)lane] = rec;
-		if (lane == 0) L.head[d] = h;
-		rs_fence_wave();
+	}
+	rs_fence_wave();
+#pragma unroll 1
+	for (int k = 0; k < 4; ++k) {
+		unsigned long long todo = nonempty[k];
+		while (todo) {
+			const int d = 64 * k + (__ffsll((long long)todo) - 1);
+			todo &= todo - 1;
+			uint32_t h = L.head[d]; const uint32_t tl = L.tail[d];
+			rs_flush(beg, L, d, wlog, lane);                        // slots filled while d was a destination
+			// bucket d is scanned through a 64-record register window (slots at or beyond a head still hold the original
+			// records, and nothing but this loop writes them while d is the current bucket)
+			uint32_t cw = h; unsigned long long fm = 0; bool have = false, dirty = false;
+			u128 rec; rec.x = 0, rec.y = 0;
+			while (h < tl) {
+				if (!have || h - cw >= 64) {
+					if (dirty) beg[cw + (uint32_t)lane] = rec;
+					cw = h; dirty = false; have = true;
+					const uint32_t pos = cw + (uint32_t)lane;
+					if (pos < tl) rec = ld128(&beg[pos]);
+					fm = __ballot(pos < tl && (uint32_t)((rec.x >> shift) & 255) != (uint32_t)d);
+				}
+				const unsigned long long m = fm >> (h - cw);         // foreign records at positions >= h
+				if (m == 0) { h = cw + 64; continue; }
+				h += (uint32_t)(__ffsll((long long)m) - 1);
+				// displacement chain starting at the foreign record beg[h] (all lanes follow it; lane 0 owns the LDS writes)
+				const int sl = (int)(h - cw);
+				u128 carry;
+				carry.x = (uint64_t)(uint32_t)rl32((int)(uint32_t)rec.x, sl) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(rec.x >> 32), sl) << 32;
+				carry.y = (uint64_t)(uint32_t)rl32((int)(uint32_t)rec.y, sl) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(rec.y >> 32), sl) << 32;
+				int dst = (int)((carry.x >> shift) & 255);
+				int same = 0;
+				do {
+					if (same >= 8) {
+						// The last steps all landed in bucket dst and pushed out records that were already home there: the walk
+						// is shifting a run of home records one slot to the right, one record per step (ksort.h:134-137 displaces
+						// whatever sits at the head).  Do the whole run at once: find the first record at or after the head
+						// that does not belong to dst, move everything before it up by one (top-down, 256 records per round),
+						// put the carry at the head and continue with that record.
+						same = 0;
+						rs_flush(beg, L, dst, wlog, lane);
+						const uint32_t hd0 = L.head[dst], tl0 = L.tail[dst];
+						uint32_t p = hd0;
+						for (;;) {                                        // a foreign record exists before the tail (slot counting)
+							const uint32_t q = p + (uint32_t)lane;
+							const bool foreign = q < tl0 && (uint32_t)((beg[q].x >> shift) & 255) != (uint32_t)dst;
+							const unsigned long long fmk = __ballot(foreign || q >= tl0);
+							if (fmk) { p += (uint32_t)(__ffsll((long long)fmk) - 1); break; }
+							p += 64;
+						}
+						if (p < tl0 && p - hd0 >= 16) {
+							const u128 out = ld128(&beg[p]);
+							for (uint32_t hi = p; hi > hd0; ) {
+								u128 v[4]; uint32_t q[4];
+#pragma unroll
+								for (int k = 0; k < 4; ++k) { q[k] = hi - (uint32_t)lane - 64u * k; if ((int64_t)hi - lane - 64 * k > (int64_t)hd0) v[k] = ld128(&beg[q[k] - 1]); }
+#pragma unroll
+								for (int k = 0; k < 4; ++k) if ((int64_t)hi - lane - 64 * k > (int64_t)hd0) beg[q[k]] = v[k];
+								hi = hi - hd0 > 256 ? hi - 256 : hd0;
+							}
+							if (lane == 0) { beg[hd0] = carry; L.head[dst] = p + 1; }
+							rs_fence_wg();
+							carry = out;
+							dst = (int)((carry.x >> shift) & 255);
+							continue;
+						}
+					}
+					const uint32_t hd = L.head[dst];
+					uint32_t wb = L.wbase[dst];
+					const uint32_t ws = (uint32_t)L.wslot[dst] << wlog;
+					if (wb == RS_NONE || hd - wb >= W) {
+						rs_flush(beg, L, dst, wlog, lane);
+						const uint32_t p2 = hd + (uint32_t)lane;
+						if ((uint32_t)lane < W && p2 < L.tail[dst]) L.win[ws + lane] = ld128(&beg[p2]);
+						if (lane == 0) L.wbase[dst] = hd;
+						wb = hd;
+						rs_fence_wave();
+					}
+					const u128 nxt = L.win[ws + (hd - wb)];
+					rs_fence_wave();
+					if (lane == 0) { L.win[ws + (hd - wb)] = carry; L.head[dst] = hd + 1; }
+					rs_fence_wave();
+					carry = nxt;
+					{ const int nd = (int)((carry.x >> shift) & 255); same = nd == dst ? same + 1 : 0; dst = nd; }
+				} while (dst != d);
+				if (lane == sl) rec = carry, dirty = true;
+				++h;
+			}
+			if (dirty) beg[cw + (uint32_t)lane] = rec;
+			if (lane == 0) L.head[d] = h;
+			rs_fence_wave();
+		}
 	}
 	rs_fence_wg();
-	if (lane == 0) L.prof[2] += wall_clock64() - t1;
 	return true;
 }
 
@@ -129,6 +195,47 @@ __device__ __forceinline__ void rs_small_wave(u128 *beg, int64_t b, int64_t e, R
 	rs_fence_wave();
 	if (lane < m) beg[b + lane] = L.ins[lane];
 	rs_fence_wg();
+}
+
+// After a level: the buckets (lane l holds buckets l, l+64, l+128, l+192: cnt/off from rs_level_wave) of <= 64 records are
+// insertion-sorted (ksort.h:142), one lane per bucket, inside LDS -- the 64 buckets of a group are staged together when they
+// fit the window pool; larger buckets are handed to big(offset, length).
+template <class Big>
+__device__ inline void rs_split_buckets(u128 *beg, int64_t n, int shift, const uint32_t (&cnt)[4], const uint32_t (&off)[4], RsLds &L, int lane, Big big)
+{
+#pragma unroll 1
+	for (int k = 0; k < 4; ++k) {
+		const uint32_t g_lo = (uint32_t)__builtin_amdgcn_readlane((int)off[k], 0);
+		const uint32_t g_hi = (uint32_t)__builtin_amdgcn_readlane((int)(off[k] + cnt[k]), 63);
+		if (g_hi == g_lo) continue;
+		unsigned long long bm = __ballot(cnt[k] > 64);
+		const unsigned long long sm = __ballot(cnt[k] > 1 && cnt[k] <= 64);
+		while (bm) {
+			const int src = __ffsll((long long)bm) - 1;
+			bm &= bm - 1;
+			big((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)off[k], src), (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)cnt[k], src));
+		}
+		if (!sm) continue;
+		if (g_hi - g_lo <= RS_POOL) {
+			for (uint32_t i = g_lo + (uint32_t)lane; i < g_hi; i += 64) L.win[i - g_lo] = ld128(&beg[i]);
+			rs_fence_wave();
+			bool changed = false;
+			if (cnt[k] > 1 && cnt[k] <= 64) {
+				u128 *b0 = L.win + (off[k] - g_lo), *b1 = b0 + cnt[k];
+				for (u128 *q = b0 + 1; q < b1; ++q) if (q->x < (q - 1)->x) { changed = true; break; }
+				if (changed) rs_insertion(b0, b1);
+			}
+			rs_fence_wave();
+			if (__ballot(changed)) {
+				for (uint32_t i = g_lo + (uint32_t)lane; i < g_hi; i += 64) beg[i] = L.win[i - g_lo];
+				rs_fence_wg();
+			}
+		} else {
+			// the group spans more than the pool: generic window scan over its range (large buckets were queued above)
+			rs_runs_wave(beg + g_lo, (int64_t)(g_hi - g_lo), shift, L, lane, [&](int64_t, int64_t) {});
+		}
+	}
+	(void)n;
 }
 
 // Runs of records that agree on x >> hi_shift, found 64 records at a time: runs of <= 64 records are insertion-sorted
@@ -211,19 +318,6 @@ __device__ inline uint64_t rs_varying_bits(const u128 *beg, int64_t n, int lane)
 		alo &= (uint32_t)__shfl_xor((int)alo, d); ahi &= (uint32_t)__shfl_xor((int)ahi, d);
 	}
 	return ((uint64_t)ohi << 32 | olo) ^ ((uint64_t)ahi << 32 | alo);
-}
-
-// the whole sort by one wave (small arrays, e.g. the chains of one query)
-__device__ inline void radix_sort_128x_wave(u128 *beg, int64_t n, RsLds &L, int lane)
-{
-	if (n <= 64) { rs_small_wave(beg, 0, n, L, lane); return; }
-	const uint64_t vary = rs_varying_bits(beg, n, lane);
-	bool single_run = true;                                   // no level above has split the array yet
-	for (int shift = 56; shift >= 0; shift -= 8) {
-		if (((vary >> shift) & 255) == 0) continue;            // identity at this level for every run
-		if (single_run) { rs_level_wave(beg, n, shift, L, lane); single_run = false; continue; }
-		rs_runs_wave(beg, n, shift + 8, L, lane, [&](int64_t rb, int64_t len) { rs_level_wave(beg + rb, len, shift, L, lane); });
-	}
 }
 
 } // namespace pga

@@ -64,6 +64,22 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 }
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v) { return -wave_min_i32(-v); }   // y is a sequence coordinate: never INT32_MIN
 
+// inclusive prefix sum over the wave (lane order), DPP only
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add_step(uint32_t v)
+{
+	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_prefix_sum_incl(uint32_t v)
+{
+	v = dpp_add_step<0x111, 0xf>(v);     // row_shr:1
+	v = dpp_add_step<0x112, 0xf>(v);     // row_shr:2
+	v = dpp_add_step<0x114, 0xf>(v);     // row_shr:4
+	v = dpp_add_step<0x118, 0xf>(v);     // row_shr:8
+	v = dpp_add_step<0x142, 0xa>(v);     // row_bcast15
+	v = dpp_add_step<0x143, 0xc>(v);     // row_bcast31
+	return v;
+}
+
 // maximum of a signed 64-bit key over the wave; the result is uniform
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ long long dpp_max_step_i64(long long v)
 {
