@@ -344,7 +344,9 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 				bool part = false;
 				if (lane < CF_W / 64 && sm_blk >= 0 && sm_blk + 64 > st && sm_blk + 64 <= S) {
 					const bool none = sm_ymax <= y_lo || sm_ymin > yi || (sm_ymin == yi && !(seg_is_query_start && sm_blk == 0));
-					if (sm_blk >= st && sm_ymin > y_lo && sm_ymax < yi) { best = sm_pri; best_j = sm_arg < 0 ? sm_blk : sm_arg; tie = sm_arg < 0; }
+					// wholly inside the window -- or partly evicted, but the block's unique minimum is still inside: then it is also
+					// the (unique) minimum of the surviving part
+					if ((sm_blk >= st || sm_arg >= st) && sm_ymin > y_lo && sm_ymax < yi) { best = sm_pri; best_j = sm_arg < 0 ? sm_blk : sm_arg; tie = sm_arg < 0; }
 					else if (!none) part = true;
 				}
 				unsigned long long pm = __ballot(part);
