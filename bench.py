@@ -132,11 +132,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    # PGA_BENCH_SINGLE_DEVICE=1 (debugging on a 1-GPU box): every rank computes on GPU 0 and the collectives run over gloo
+    single = os.environ.get("PGA_BENCH_SINGLE_DEVICE") == "1"
+    if single:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     batch.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if single:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cdev = torch.device("cpu") if single else dev          # where the collectives' tensors live
 
     groups, names = make_groups(20260928 + rank, args.genomes, args.length, args.divergence)
     pb = batch.PreparedBatch(groups, names)
@@ -151,8 +159,8 @@ def main():
         res = rb.align(sensitivity=10, want_raw=want_raw, n_threads=n_threads)
         if world > 1:
             # the match list (records, then the CIGAR pool) goes to the rank that owns the graph
-            gather_blobs(res.raw_matches, dev, dst=0, as_bytes=False)
-            gather_blobs(res.raw_cigars, dev, dst=0, as_bytes=False)
+            gather_blobs(res.raw_matches, cdev, dst=0, as_bytes=False)
+            gather_blobs(res.raw_cigars, cdev, dst=0, as_bytes=False)
         res.close()
         return res
 
@@ -170,8 +178,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        dt = max_over_ranks(dt, dev)
-        total_units = sum_over_ranks(units, dev)
+        dt = max_over_ranks(dt, cdev)
+        total_units = sum_over_ranks(units, cdev)
     else:
         total_units = units
 
