@@ -18,6 +18,7 @@
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_wave.h"
+#include "pga_pk16.h"
 
 namespace pga {
 
@@ -37,16 +38,6 @@ __device__ __forceinline__ long long wave_max64f(long long v)
 	}
 	return v;
 }
-
-typedef short s2_t __attribute__((ext_vector_type(2)));
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int as_i(s2_t v) { return __builtin_bit_cast(int, v); }
-__device__ __forceinline__ s2_t as_s2(int v) { return __builtin_bit_cast(s2_t, v); }
-__device__ __forceinline__ s2_t splat2(int x) { s2_t r; r.x = (short)x; r.y = (short)x; return r; }
-__device__ __forceinline__ s2_t pmax(s2_t a, s2_t b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ s2_t pmin(s2_t a, s2_t b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ s2_t pminu(s2_t a, s2_t b) { return __builtin_bit_cast(s2_t, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b))); }
-__device__ __forceinline__ int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }   // mask ? a : b, bitwise
 
 #define BT_ROWS 64
 #define BT_COLS 64

@@ -18,6 +18,7 @@
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_wave.h"
+#include "pga_pk16.h"
 
 namespace pga {
 
@@ -110,6 +111,7 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			for (int j = tid; j < qlen; j += WIDE_NT) qq[j] = (uint8_t)query_at(j);
 		}
 		int init_hi = R - 1;                               // highest column whose slot holds that column's state
+		const bool packed_ok = !right && w >= qlen && w >= tlen && R == T && sc_mch >= 0 && sc_mch < 127;
 		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
 		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
 		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
@@ -171,6 +173,40 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			}
 			__syncthreads();
 			uint8_t *prow = pmat + (size_t)r * n_col - st;
+			if (packed_ok) {
+				// unbanded, left-aligned gaps, whole target in the ring (slot == column): two adjacent columns per thread in packed
+				// 16-bit arithmetic.  No int8 wrap is emulated here: inside an unbinding band every cell in [st0,en0] depends only on
+				// cells in range or on boundary values (see pga_ksw_fast.hip), and those stay within int8 by construction.
+				const s2_t ZERO = splat2(0), ONE = splat2(1), MCH = splat2(sc_mch), Q1 = splat2(q), Q2 = splat2(q2), QE = splat2(qe), QE2 = splat2(qe2);
+				const s2_t EIGHT = splat2(8), C16 = splat2(16), C32 = splat2(32), C64 = splat2(64);
+				for (int t = st + 2 * tid; t <= en; t += 2 * WIDE_NT) {
+					const int xl = t == st ? x1 : (int)xr[t - 1], vl = t == st ? v1 : (int)vr[t - 1], x2l = t == st ? x21 : (int)x2r[t - 1];
+					const s2_t xt1 = pack2(xl, (int)xr[t]), vt1 = pack2(vl, (int)vr[t]), x2t1 = pack2(x2l, (int)x2r[t]);
+					const s2_t ut = unpack_i8x2(*reinterpret_cast<const uint16_t*>(u + t)), yt = unpack_i8x2(*reinterpret_cast<const uint16_t*>(y + t));
+					const s2_t y2t = unpack_i8x2(*reinterpret_cast<const uint16_t*>(y2 + t));
+					s2_t z = unpack_i8x2(*reinterpret_cast<const uint16_t*>(s + t));
+					s2_t a = xt1 + vt1, b = yt + ut, a2 = x2t1 + vt1, b2 = y2t + ut;
+					const s2_t zm = pmax(pmax(pmax(z, a), pmax(b, a2)), b2);
+					s2_t d;
+					{
+						const s2_t n0 = pminu(zm - z, ONE), n1 = pminu(zm - a, ONE), n2 = pminu(zm - b, ONE), n3 = pminu(zm - a2, ONE);
+						d = n0 * (ONE + n1 * (ONE + n2 * (ONE + n3)));
+					}
+					z = pmin(zm, MCH);
+					const s2_t un = z - vt1, vn = z - ut;
+					s2_t tmp = z - Q1; a = a - tmp; b = b - tmp;
+					tmp = z - Q2; a2 = a2 - tmp; b2 = b2 - tmp;
+					s2_t xn, yn, x2n, y2n;
+					{ const s2_t m = pmax(a, ZERO);  xn  = m - QE;  d = d + pmin(m, ONE) * EIGHT; }
+					{ const s2_t m = pmax(b, ZERO);  yn  = m - QE;  d = d + pmin(m, ONE) * C16; }
+					{ const s2_t m = pmax(a2, ZERO); x2n = m - QE2; d = d + pmin(m, ONE) * C32; }
+					{ const s2_t m = pmax(b2, ZERO); y2n = m - QE2; d = d + pmin(m, ONE) * C64; }
+					*reinterpret_cast<uint16_t*>(u + t) = pack_i8x2(un); *reinterpret_cast<uint16_t*>(vw + t) = pack_i8x2(vn);
+					*reinterpret_cast<uint16_t*>(xw + t) = pack_i8x2(xn); *reinterpret_cast<uint16_t*>(y + t) = pack_i8x2(yn);
+					*reinterpret_cast<uint16_t*>(x2w + t) = pack_i8x2(x2n); *reinterpret_cast<uint16_t*>(y2 + t) = pack_i8x2(y2n);
+					*reinterpret_cast<uint16_t*>(prow + t) = pack_i8x2(d);
+				}
+			} else
 			for (int t = st + tid; t <= en; t += WIDE_NT) {
 				const int k = sl(t), k1 = t == st ? k : sl(t - 1);
 				const int xt1 = t == st ? x1 : (int)xr[k1], vt1 = t == st ? v1 : (int)vr[k1], x2t1 = t == st ? x21 : (int)x2r[k1];
