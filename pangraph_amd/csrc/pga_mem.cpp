@@ -3,7 +3,7 @@
 // A batch allocates a few dozen device arrays per stage and the DP stage a scratch slab of tens of GB; hipMalloc and
 // hipFree cost from 0.1 ms to tens of ms each and hipFree synchronises the device, so freed blocks are kept in
 // per-device, size-rounded free lists and handed out again (a level of `pangraph build` repeats the same sizes call
-// after call).  The cache is bounded: beyond PGA_CACHE_GB (default 96) of idle blocks the largest are released.
+// after call).  The cache is bounded: beyond PGA_CACHE_GB (default 200) of idle blocks the largest are released.
 #include "pga_common.h"
 #include <map>
 #include <mutex>
@@ -33,7 +33,7 @@ size_t round_size(size_t b)
 }
 size_t cache_limit()
 {
-	static size_t lim = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 96.0; return (size_t)(g * (double)(1ull << 30)); }();
+	static size_t lim = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 200.0; return (size_t)(g * (double)(1ull << 30)); }();
 	return lim;
 }
 }
