@@ -18,6 +18,7 @@
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_wave.h"
+#include <cstdio>
 #include "pga_pk16.h"
 
 namespace pga {
@@ -52,6 +53,7 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 	extern __shared__ __align__(16) uint8_t dyn[];
 	__shared__ uint32_t s_job;
 	__shared__ long long s_part[WIDE_NT / 64];
+	__shared__ int s_hprev;
 	__builtin_amdgcn_s_setprio(3);      // few, latency-bound workgroups: win issue arbitration against the tile kernels sharing the CU
 	__shared__ uint8_t s_win[WBT * WBT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,12 +108,15 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			x2b[0][t] = x2b[1][t] = (int8_t)(-q2 - e2);
 			if (!approx_max) H[t] = KSW_NEG_INF;
 		}
+		const bool packed_ok = !right && w >= qlen && w >= tlen && R == T && sc_mch >= 0 && sc_mch < 127;
+		const bool swar_profile = packed_ok && seq_lds;     // query stored REVERSED with 32 zero bytes on either side: column t of diagonal r reads qq[t + 32+qlen-1-r]
 		if (seq_lds) {
-			for (int i = tid; i < tlen; i += WIDE_NT) tq[i] = (uint8_t)target_at(i);
-			for (int j = tid; j < qlen; j += WIDE_NT) qq[j] = (uint8_t)query_at(j);
+			for (int i = tid; i < seq_cap; i += WIDE_NT) tq[i] = i < tlen ? (uint8_t)target_at(i) : (uint8_t)0;
+			if (swar_profile) {
+				for (int p = tid; p < seq_cap + 64; p += WIDE_NT) { const int j = qlen - 1 - (p - 32); qq[p] = (j >= 0 && j < qlen) ? (uint8_t)query_at(j) : (uint8_t)0; }
+			} else for (int j = tid; j < qlen; j += WIDE_NT) qq[j] = (uint8_t)query_at(j);
 		}
 		int init_hi = R - 1;                               // highest column whose slot holds that column's state
-		const bool packed_ok = !right && w >= qlen && w >= tlen && R == T && sc_mch >= 0 && sc_mch < 127;
 		int ez_max = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
 		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
 		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
@@ -120,8 +125,10 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		__syncthreads();
 
 		int base = 0;                                       // multiple of R with base <= st-16: slot(t) = t-base (-R)
+		int pend_slot = -1, pend_val = 0;
 		for (int r = 0; r < n_diag; ++r) {
 			r_done = r + 1;
+			if (pend_slot >= 0) { if (tid == 0) H[pend_slot] = pend_val; pend_slot = -1; }   // last diagonal's H[en0] (nobody reads H before two more barriers)
 			int st0, en0;
 			diag_range_w(r, qlen, tlen, w, st0, en0);
 			if (st0 > en0) { ez_zdropped = 1; break; }
@@ -160,6 +167,22 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 				y[k] = (int8_t)(-q - e), y2[k] = (int8_t)(-q2 - e2);
 				u[k] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
 			}
+			if (swar_profile) {
+				// four columns per thread and iteration on 32-bit words: equal bytes <=> zero bytes of a ^ b (all values <= 4, so +0x7f sets
+				// bit 7 exactly for non-zero bytes without carries); the score bytes are picked by v_perm from {match, mismatch, N, N}.
+				// (writes may spill a few columns beyond the reference's 16-column blocks: unbanded problems never read those)
+				const int off_r = 32 + qlen - 1 - r;
+				const uint32_t sc_tab = (uint32_t)(uint8_t)sc_mch | (uint32_t)(uint8_t)sc_mis << 8 | (uint32_t)(uint8_t)sc_N << 16 | (uint32_t)(uint8_t)sc_N << 24;
+				for (int t4 = (st0 & ~3) + 4 * tid; t4 < st0 + span && t4 < T; t4 += 4 * WIDE_NT) {
+					const uint32_t a4 = *reinterpret_cast<const uint32_t*>(tq + t4);
+					const int idx = t4 + off_r;
+					const uint32_t lo = *reinterpret_cast<const uint32_t*>(qq + (idx & ~3)), hi = *reinterpret_cast<const uint32_t*>(qq + (idx & ~3) + 4);
+					const uint32_t b4 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(idx & 3));
+					const uint32_t nz = ((a4 ^ b4) + 0x7f7f7f7fu) >> 7 & 0x01010101u;
+					const uint32_t nn = (a4 | b4) >> 2 & 0x01010101u;
+					*reinterpret_cast<uint32_t*>(s + t4) = __builtin_amdgcn_perm(0u, sc_tab, nz | nn << 1);
+				}
+			} else
 			for (int o = tid; o < span; o += WIDE_NT) {
 				const int t = st0 + o;
 				if (t < T) {
@@ -245,42 +268,49 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			__syncthreads();
 			bool stop = false;
 			if (!approx_max) {
-				int max_H, max_t;
+				int max_H, max_t, h_en_now = 0, h_st_now = 0;
 				if (r > 0) {
-					const int Hen = en0 > 0 ? H[sl(en0 - 1)] + u[sl(en0)] : H[sl(en0)] + vw[sl(en0)];
-					__syncthreads();
+					// H[t] += v[t] for st0 <= t < en0, H[en0] = H[en0-1](before its update) + u[en0]  (ksw2_extd2_sse.c:325-340).
+					// The old H[en0-1] is posted by the thread that updates it, so the update loop needs no barrier in front of it.
 					const int en1 = st0 + (en0 - st0) / 4 * 4;
-					long long best = ((long long)Hen << 32) | 0xffffffffu;
+					long long best = (long long)KSW_NEG_INF * 4294967296LL;
 					for (int t = st0 + tid; t < en0; t += WIDE_NT) {
 						const int k = sl(t);
-						const int h = H[k] + vw[k];
+						const int hold = H[k], h = hold + vw[k];
+						if (t == en0 - 1) s_hprev = hold;
 						H[k] = h;
 						const unsigned ord = t < en1 ? 1u + ((unsigned)((t - st0) & 3) << 28) + (unsigned)t : 1u + (4u << 28) + (unsigned)t;
 						const long long key = ((long long)h << 32) | (0xffffffffu - ord);
 						best = key > best ? key : best;
 					}
-					if (tid == 0) H[sl(en0)] = Hen;
 					best = wave_max_i64(best);
 					if (lane == 0) s_part[wave] = best;
 					__syncthreads();
-#pragma unroll
-					for (int k = 0; k < WIDE_NT / 64; ++k) { const long long o = s_part[k]; best = o > best ? o : best; }
-					max_H = (int)(best >> 32);
-					const unsigned ord = 0xffffffffu - (unsigned)(best & 0xffffffffLL);
+					const int hprev = en0 > 0 ? (en0 - 1 >= st0 ? s_hprev : H[sl(en0 - 1)]) : 0;
+					const int Hen = en0 > 0 ? hprev + u[sl(en0)] : H[sl(en0)] + vw[sl(en0)];
+					long long bb = lane < WIDE_NT / 64 ? s_part[lane] : (long long)KSW_NEG_INF * 4294967296LL;
+					bb = wave_max_i64(bb);
+					{ const long long hk = ((long long)Hen << 32) | 0xffffffffu; if (hk > bb) bb = hk; }
+					max_H = (int)(bb >> 32);
+					const unsigned ord = 0xffffffffu - (unsigned)(bb & 0xffffffffLL);
 					max_t = ord == 0 ? en0 : (int)((ord - 1) & 0x0fffffffu);
+					h_en_now = Hen;
+					h_st_now = st0 == en0 ? Hen : H[sl(st0)];
+					if (en0 == 0) __syncthreads();                    // (one-column target: H[0] itself was an input above)
+					pend_slot = sl(en0); pend_val = Hen;             // H[en0] is replaced at the top of the next diagonal, behind its first barrier
 				} else {
-					if (tid == 0) H[sl(0)] = vw[sl(0)] - qe_h;
-					__syncthreads();
-					max_H = H[sl(0)], max_t = 0;
+					const int h0 = vw[sl(0)] - qe_h;
+					pend_slot = sl(0); pend_val = h0;
+					max_H = h0, max_t = 0; h_en_now = h0; h_st_now = h0;
 				}
-				if (en0 == tlen - 1) { const int h = H[sl(en0)]; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
-				if (r - st0 == qlen - 1) { const int h = H[sl(st0)]; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+				if (en0 == tlen - 1) { const int h = h_en_now; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
+				if (r - st0 == qlen - 1) { const int h = h_st_now; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
 				if (max_H > ez_max) ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
 				else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
 					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
 					if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
 				}
-				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = H[sl(tlen - 1)];
+				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = h_en_now;
 			} else {
 				if (r > 0) {
 					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
@@ -300,7 +330,8 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 			}
 			if (stop) break;
 			last_st = st, last_en = en;
-			__syncthreads();       // the H / profile reads of this diagonal are done before the next one rewrites them
+			// no barrier here: what the next diagonal writes before its own first barrier (score profile, entering columns, the
+			// joining column's first-row values, the pending H[en0]) is read by nobody in the phase above
 		}
 
 		// ---- backtrack by wave 0 (ksw2.h:127-159), LDS window, fences only ----
@@ -370,7 +401,7 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 	}
 }
 
-size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact) { return (size_t)r_cap * 10 + (exact ? (size_t)r_cap * 4 : 0) + 2 * (size_t)seq_cap; }
+size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact) { return (size_t)r_cap * 10 + (exact ? (size_t)r_cap * 4 : 0) + (seq_cap > 0 ? 2 * (size_t)seq_cap + 128 : 0); }
 
 template <int NT> static void launch_wide_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab,
                                              size_t slab_bytes, int r_cap, int seq_cap, int exact, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
