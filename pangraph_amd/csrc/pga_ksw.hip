@@ -343,7 +343,9 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //          per CU), <= 76 KB (two), <= 152 KB (one)
 //   5      single-wave kernel with rows in the HBM slab (targets wider than LDS can hold; not reached by pangraph's windows)
 //   6      local-alignment score queries of the inversion test (pga_ll.hip)
-#define DP_NCLASS 7
+//   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
+//          first passes of class 4 keep room for their sequences in LDS)
+#define DP_NCLASS 8
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -367,7 +369,7 @@ static int dp_class(const DpJob &j, size_t need)
 	const size_t rows = (size_t)14 * wide_ring(j), l = rows + 2 * (size_t)wide_seqcap(j);
 	if (l <= 48 * 1024) return 2;
 	if (l <= 76 * 1024) return 3;
-	if (rows <= WIDE_LDS_MAX) return 4;
+	if (rows <= WIDE_LDS_MAX) return (j.flag & EZ_APPROX_MAX) ? 4 : 7;
 	return 5;
 }
 
@@ -389,7 +391,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	if (n == 0) return;
 	const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	std::vector<uint32_t> cls[DP_NCLASS];
-	size_t slab_max[DP_NCLASS] = {0, 0, 0, 0, 0, 0, 0};
+	size_t slab_max[DP_NCLASS] = {};
 	std::vector<size_t> need(n);
 	std::vector<uint8_t> cls_of(n);
 	unsigned long long cig_total = 0;
@@ -440,7 +442,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
 	static hipStream_t lane_stream_dev[16][4] = {};
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
 	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
@@ -459,7 +461,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
-		size_t n_waves = c == 6 ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
+		size_t n_waves = (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
 		waves_of[c] = n_waves;
@@ -503,12 +505,12 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
 			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
 		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		else if (c <= 4) {
+		else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
 			// few problems: each workgroup effectively owns a CU, so give it the waves to hide its LDS latency
-			const int nt = (c == 4 || ids.size() <= 256) ? 1024 : (c == 3 || ids.size() <= 512) ? 512 : 256;
+			const int nt = (c == 4 || c == 7 || ids.size() <= 256) ? 1024 : (c == 3 || ids.size() <= 512) ? 512 : 256;
 			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
@@ -527,14 +529,14 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below
-			const int kk = c == 6 ? K_LL : c <= 1 ? K_EXTD2 : K_EXTD2_WIDE;
+			const int kk = c == 6 ? K_LL : c <= 1 ? K_EXTD2 : K_EXTD2_WIDE;   // (classes 2-5 and 7)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->dp_bases += bases;
 		}
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
 		download_to(r, X.d_r.p, ids.size(), lane_stream[lane_of_class[c]]);
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
-		if (c >= 2 && c <= 4 && verbose) {
+		if (((c >= 2 && c <= 4) || c == 7) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
