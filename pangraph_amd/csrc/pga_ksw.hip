@@ -509,8 +509,11 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
-			// few problems: each workgroup effectively owns a CU, so give it the waves to hide its LDS latency
-			const int nt = (c == 4 || c == 7 || ids.size() <= 256) ? 1024 : (c == 3 || ids.size() <= 512) ? 512 : 256;
+			// few problems: each workgroup effectively owns a CU, so give it the waves to hide its LDS latency -- as far as the
+			// band has work for them (every wave of the group pays every phase of a diagonal): ~2 columns per thread
+			int nt = 256;
+			if (c == 4 || c == 7 || ids.size() <= 512) nt = r_cap >= 3000 ? 1024 : r_cap >= 1200 ? 512 : 256;
+			else if (c == 3) nt = 512;
 			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
