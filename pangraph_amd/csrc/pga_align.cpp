@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cassert>
 #include <list>
+#include <deque>
 #include <chrono>
 #include <cstdio>
 #include <mutex>
@@ -579,6 +580,7 @@ struct QueryCtx {
 	bool finished = false;
 	// DP problems of this query (ids are per query; filled between the threaded phases)
 	std::vector<DpJob> jobs; std::vector<DpRes> res; std::vector<const uint32_t*> cig; std::vector<int> pending;   // cig[id] points into a per-round CIGAR pool
+	std::deque<uint32_t> own_cig;     // one-operation CIGARs of the gap fills answered without a DP problem (stable addresses)
 };
 
 struct Driver {
@@ -604,6 +606,45 @@ struct Driver {
 		Q.res.push_back(r); Q.cig.push_back(nullptr);
 		if (!r.pad) Q.pending.push_back(id);
 		return id;
+	}
+
+	// First-pass gap fill (KSW_EZ_APPROX_MAX) of two equally long, N-free windows that differ in so few positions that the main
+	// diagonal is provably the unique optimum ((a+b)*m < a + 2*min(q+e, q2+e2): every other alignment has an insertion and a
+	// deletion -- the proof and its parity test are with the tile kernel, pga_ksw_fast.hip): the answer is "nM" with score
+	// a*(n-m) - b*m, and no problem is sent to the GPU at all.  Returns false if the windows do not qualify.
+	bool gap_fill_by_identity(QueryCtx &Q, int rev, int rid, int32_t qs, int32_t ts, int32_t n, int &id_out)
+	{
+		if (n <= 0) return false;
+		const int a_ = mat[0], b_ = -mat[1];
+		const int g1 = std::min(opt.q + opt.e, opt.q2 + opt.e2);
+		const int64_t lim = (int64_t)a_ + 2 * g1;                  // (a+b)*m < lim
+		if (a_ <= 0 || b_ <= 0) return false;
+		const uint8_t *t = acc.tptr(Q.base + rid) + ts, *q = acc.tptr(Q.qid);
+		int m = 0;
+		if (!rev) {
+			const uint8_t *qq = q + qs;
+			for (int32_t i = 0; i < n; ++i) {
+				const uint8_t x = t[i], y = qq[i];
+				if ((x | y) > 3) return false;
+				if (x != y && (int64_t)(a_ + b_) * ++m >= lim) return false;
+			}
+		} else {
+			const uint8_t *qq = q + (Q.qlen - 1 - qs);                // base i of the reverse strand window = 3 - q[qlen-1-(qs+i)]
+			for (int32_t i = 0; i < n; ++i) {
+				const uint8_t x = t[i], y = qq[-i];
+				if ((x | y) > 3) return false;
+				if (x != (uint8_t)(3 - y) && (int64_t)(a_ + b_) * ++m >= lim) return false;
+			}
+		}
+		DpJob j; memset(&j, 0, sizeof(j));
+		j.t_off = S.off[Q.base + rid] + (uint64_t)ts; j.q_off = S.off[Q.qid]; j.qlen_full = Q.qlen; j.qs = qs; j.qlen = n; j.tlen = n; j.flag = EZ_APPROX_MAX;
+		DpRes r; memset(&r, 0, sizeof(r));
+		r.max = 0; r.max_q = r.max_t = r.mqe_t = r.mte_q = -1; r.mqe = r.mte = NEG_INF;
+		r.score = a_ * (n - m) - b_ * m; r.n_cigar = 1; r.pad = 1;
+		Q.own_cig.push_back((uint32_t)n << 4);
+		id_out = (int)Q.jobs.size();
+		Q.jobs.push_back(j); Q.res.push_back(r); Q.cig.push_back(&Q.own_cig.back());
+		return true;
 	}
 
 	// ---- plan (align.c:583-700): everything mm_align1 decides before its first DP call ----
@@ -683,7 +724,8 @@ struct Driver {
 			if (i == cnt1 - 1 || (a[as1+i].y & SEED_LONG_JOIN) || (qe - qs >= opt.min_ksw_len && re - rs >= opt.min_ksw_len)) {
 				Seg sg; sg.i = i, sg.rs = rs, sg.qs = qs, sg.re = re, sg.qe = qe, sg.bw1 = bw_long;
 				if (a[as1+i].y & SEED_LONG_JOIN) sg.bw1 = qe - qs > re - rs ? qe - qs : re - rs;
-				sg.job1 = request(Q, T.rev, T.rid, qs, qe - qs, rs, re - rs, 0, sg.bw1, -1, opt.zdrop, EZ_APPROX_MAX);
+				if (!(qe - qs == re - rs && sg.bw1 >= qe - qs && gap_fill_by_identity(Q, T.rev, T.rid, qs, rs, qe - qs, sg.job1)))
+					sg.job1 = request(Q, T.rev, T.rid, qs, qe - qs, rs, re - rs, 0, sg.bw1, -1, opt.zdrop, EZ_APPROX_MAX);
 				T.segs.push_back(sg);
 				rs = re, qs = qe;
 			}
