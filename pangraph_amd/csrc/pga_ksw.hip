@@ -343,9 +343,11 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //          per CU), <= 76 KB (two), <= 152 KB (one)
 //   5      single-wave kernel with rows in the HBM slab (targets wider than LDS can hold; not reached by pangraph's windows)
 //   6      local-alignment score queries of the inversion test (pga_ll.hip)
+//   8      first-pass gap fills of nearly equal length: corridor kernel with an exactness proof per problem (pga_ksw_band.hip);
+//          the few it cannot prove come back flagged and take their normal class in a second pass
 //   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
 //          first passes of class 4 keep room for their sequences in LDS)
-#define DP_NCLASS 8
+#define DP_NCLASS 9
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -359,10 +361,16 @@ size_t ll_lds_bytes(int t_cap);
 void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter,
                    unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st);
 
-static int dp_class(const DpJob &j, size_t need)
+#define BAND_MAXLEN 1024
+size_t band_slab_bytes(int max_diag);
+void launch_gapfill_band(unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
+
+static int dp_class(const DpJob &j, bool allow_band)
 {
-	(void)need;
 	if (j.flag & PGA_JOB_LL) return 6;
+	if (allow_band && j.flag == EZ_APPROX_MAX && j.w >= j.qlen && j.w >= j.tlen && j.qlen >= 1 && j.tlen >= 1 && j.qlen <= BAND_MAXLEN && j.tlen <= BAND_MAXLEN &&
+	    j.tlen - j.qlen <= 12 && j.qlen - j.tlen <= 12) return 8;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
@@ -384,7 +392,27 @@ template <class F> static void host_parallel(size_t n, F f)
 	for (auto &t : th) t.join();
 }
 
+static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band);
+
 void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
+{
+	dp_run_impl(d_nt4, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr);
+	// problems the corridor kernel could not prove exact: full matrix, results spliced in (their CIGARs go behind the pool)
+	std::vector<uint32_t> redo;
+	for (size_t i = 0; i < res.size(); ++i) if (res[i].n_cigar == -9) redo.push_back((uint32_t)i);
+	if (redo.empty()) return;
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     corridor kernel: %zu of %zu problems not proven, full matrix\n", redo.size(), jobs.size());
+	std::vector<DpJob> jb(redo.size());
+	for (size_t k = 0; k < redo.size(); ++k) jb[k] = jobs[redo[k]];
+	std::vector<DpRes> r2; PinVec<uint32_t> c2;
+	dp_run_impl(d_nt4, jb, P, r2, c2, st, tm, false);
+	const size_t base = cigars.size();
+	cigars.resize(base + c2.size());
+	if (c2.size()) memcpy(cigars.data() + base, c2.data(), c2.size() * sizeof(uint32_t));
+	for (size_t k = 0; k < redo.size(); ++k) { res[redo[k]] = r2[k]; res[redo[k]].cigar_off += base; }
+}
+
+static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band)
 {
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
@@ -398,8 +426,8 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	host_parallel(n, [&](size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
 			const bool is_ll = jobs[i].flag & PGA_JOB_LL;
-			need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
-			cls_of[i] = (uint8_t)dp_class(jobs[i], need[i]);
+			cls_of[i] = (uint8_t)dp_class(jobs[i], allow_band);
+			need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : cls_of[i] == 8 ? band_slab_bytes(jobs[i].qlen + jobs[i].tlen) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
 		}
 	});
 	{
@@ -442,7 +470,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
 	static hipStream_t lane_stream_dev[16][4] = {};
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
 	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
@@ -461,8 +489,9 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
-		size_t n_waves = (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
+		size_t n_waves = c == 8 ? 256 * 16 : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
+		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
 		waves_of[c] = n_waves;
 		lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], n_waves * slab_max[c]);
@@ -476,7 +505,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		std::vector<uint32_t> &ids = cls[c];
 		// biggest problems first, so that the persistent waves finish together (the many small tiles of the
 		// register-resident classes are uniform enough to skip the sort)
-		if (c >= 2 || ids.size() < 100000)
+		if ((c >= 2 && c != 8) || ids.size() < 100000)
 			std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
 		PinVec<DpJob> jb; jb.resize(ids.size());
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
@@ -500,7 +529,8 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		hipStream_t cs = ls;
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
-		if (c == 6) {
+		if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		else if (c == 6) {
 			int t_cap = 16;
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
 			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
@@ -532,7 +562,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below
-			const int kk = c == 6 ? K_LL : c <= 1 ? K_EXTD2 : K_EXTD2_WIDE;   // (classes 2-5 and 7)
+			const int kk = c == 6 ? K_LL : (c <= 1 || c == 8) ? K_EXTD2 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->dp_bases += bases;
 		}
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
