@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import pangraph_amd  # noqa: E402  (sets the HIP runtime defaults of the backend before anything initialises HIP)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 

@@ -469,7 +469,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static hipStream_t lane_stream_dev[16][4] = {};
+	static thread_local hipStream_t lane_stream_dev[16][4] = {};   // per host thread: concurrent query sets do not queue behind each other
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
