@@ -262,7 +262,9 @@ __device__ __forceinline__ double cf_pri(int32_t f, int32_t x, int32_t y, float 
 // is in flight while the current one is swept) and f/p leave through the rings once per block, so the per-anchor
 // critical path touches LDS only.  Inside the sweep the wave is its own synchronisation domain (wavefront-scope
 // fences: LDS operations of one wave execute in order).
-template <int CF_W>
+// (the phase clocks of the profile cost ~600 clocks per anchor: they only exist in the PROF instantiation)
+#define CF_CLK() (PROF ? (long long)clock64() : 0LL)
+template <int CF_W, bool PROF>
 __global__ __launch_bounds__(64)
 void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
                   uint64_t n_total, const uint64_t *__restrict__ q_aoff, int n_seq, ChainParams P,
@@ -295,27 +297,60 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 	int32_t st = 0, st_in = 0, i0 = 0;
 	bool bail = false;
 	double sm_pri = 1e300; int32_t sm_arg = -1, sm_blk = -1, sm_ymin = 0, sm_ymax = 0;   // lane b: summary of ring block b
+	// Shortcut for the co-linear stretch: when the anchor just before i is a candidate (its x differs, it is inside the x and y
+	// ranges) and its priority is STRICTLY below that of every anchor inserted before it (p_floor: a running minimum, refreshed
+	// from the block summaries once per block so that it forgets evicted anchors), it is the unique range minimum whatever the
+	// window holds -- the eviction search, the scans and the wave reduction are skipped and st is brought up to date later.
+	double p_floor = 1e300, p_last = 1e300;
+	const bool shortcut_ok = P.cap >= CF_W;                  // (the tree-size cap of lchain.c:304 cannot bind inside the ring)
 	const unsigned long long c0 = wall_clock64();
-	unsigned long long n_scan = 0, n_inner = 0, n_incand = 0, n_slow = 0;
+	unsigned long long n_scan = 0, n_inner = 0, n_incand = 0, n_slow = 0, n_pev = 0, n_py = 0;
 	long long tk_scan = 0, tk_red = 0, tk_best = 0, tk_inner = 0, tk_store = 0;
 	u128 nxtv; nxtv.x = 0, nxtv.y = 0;
 	if (lane < n) nxtv = A[lane];
 	for (int32_t blk = 0; blk < n && !bail; blk += 64) {
 		// stage this block, start the load of the next one
-		if (blk + lane < n) { const int32_t s = (blk + lane) & CF_M; r_e[s].x = (int32_t)nxtv.x; r_e[s].y = (int32_t)nxtv.y; s_sp[s] = (uint8_t)(nxtv.y >> 32 & 0xff); }
+		// lane l also keeps anchor blk+l in registers: the sweep reads the anchor it is at, and the candidates of its own block
+		// (the ones whose f is youngest), with v_readlane instead of an LDS round trip
+		const int32_t bx = (int32_t)nxtv.x, by = (int32_t)nxtv.y, bsp = (int32_t)(nxtv.y >> 32 & 0xff);
+		int32_t bf = 0;
+		if (blk + lane < n) { const int32_t s = (blk + lane) & CF_M; r_e[s].x = bx; r_e[s].y = by; s_sp[s] = (uint8_t)bsp; }
 		if (blk + 64 + lane < n) nxtv = A[blk + 64 + lane];
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		{
+			// bring the window start up to date for the block's first anchor (the shortcut leaves it behind) and rebuild p_floor
+			// from the summaries of the blocks that still hold live anchors: every anchor below blk is in one of them
+			const int32_t xb = __builtin_amdgcn_readlane(bx, 0);
+			for (;;) {
+				const int32_t j = st + lane;
+				const bool keep = j >= i0 || !(xb - r_e[j & CF_M].x > max_dist);
+				const unsigned long long m = __ballot(keep);
+				if (m) { st += __ffsll((long long)m) - 1; break; }
+				st += 64;
+			}
+			p_floor = wave_min_f64_key((lane < CF_W / 64 && sm_blk >= 0 && sm_blk + 64 > st) ? sm_pri : 1e300);
+		}
 		// the ring must hold [st, blk+128)
 		if (blk + 128 - st > CF_W) { bail = true; break; }
 		const int32_t blk_end = blk + 64 < n ? blk + 64 : n;
 		for (int32_t i = blk; i < blk_end; ++i) {
-			const int32_t xi = r_e[i & CF_M].x, yi = r_e[i & CF_M].y, q_span = s_sp[i & CF_M];
+			const int il = i - blk;
+			const int32_t xi = __builtin_amdgcn_readlane(bx, il), yi = __builtin_amdgcn_readlane(by, il), q_span = __builtin_amdgcn_readlane(bsp, il);
 			int32_t max_f = q_span, max_j = -1;
+			long long k0 = CF_CLK(), k1 = k0, k2 = k0;
+			int32_t best_j = -1;
+			bool shortcut = false;
+			if (shortcut_ok && il > 0 && i0 == i - 1) {
+				const int32_t xp = __builtin_amdgcn_readlane(bx, il - 1), yp = __builtin_amdgcn_readlane(by, il - 1);
+				if (xp != xi && xi - xp <= max_dist && yp < yi && yp > yi - max_dist && p_last < p_floor) { shortcut = true; best_j = i - 1; i0 = i; }
+			}
+			if (il > 0 && p_last < p_floor) p_floor = p_last;    // from here on p_floor covers every anchor below i
+			if (!shortcut) {
 			// 1. late insertion (lchain.c:281-293): anchors that share x with i are not yet candidates; priorities were stored when f was known
-			if (i0 < i && r_e[i0 & CF_M].x != xi) i0 = i;
+			if (i0 < i) { const int32_t x0 = i0 >= blk ? __builtin_amdgcn_readlane(bx, i0 - blk) : r_e[i0 & CF_M].x; if (x0 != xi) i0 = i; }
 			// 2+3. eviction (lchain.c:295-309) folded into the range-min scan: x ascends inside a segment, so "evicted" is the
 			// predicate x_i - x_j > max_dist; st trails the true window start and catches up while scanning
-			const long long k0 = clock64();
+			k0 = CF_CLK();
 			// 2. eviction (lchain.c:295-309): x ascends inside a segment, so the window start is a forward search
 			for (;;) {
 				const int32_t j = st + lane;
@@ -325,7 +360,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 				st += 64;
 			}
 			// 3. range-min over [st, i0) with keys in ((y_i-max_dist, +inf), (y_i, query anchor 0)]
-			double best = 1e300; int32_t best_j = -1; bool tie = false;
+			double best = 1e300; bool tie = false;
 			{
 				const int32_t y_lo = yi - max_dist;
 				auto scan64 = [&](int32_t j0, int32_t jend) {
@@ -356,28 +391,44 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					const int32_t bb = __builtin_amdgcn_readlane(sm_blk, bsel);
 					scan64(bb, bb + 64);
 				}
-				// (b) anchors not covered by a summary: the block being swept and blocks reaching beyond i0
-				for (int32_t tj = S > st ? S : st; tj < i0; tj += 64) scan64(tj, i0);
+				// (b) anchors not covered by a summary: the block being swept (from the registers), or the one i0 still lingers in
+				if (i0 > blk) {
+					++n_scan;
+					const int32_t j = blk + lane;
+					if (j >= st && j < i0) {
+						const bool in = by > y_lo && (by < yi || (by == yi && seg_is_query_start && j == 0));
+						if (in) { const double pj = cf_pri(bf, bx, by, P.pen_gap); if (pj < best) best = pj, best_j = j, tie = false; else if (pj == best) tie = true; }
+					}
+				} else for (int32_t tj = S > st ? S : st; tj < i0; tj += 64) scan64(tj, i0);
 			}
 			if (i0 - st > P.cap) { bail = true; break; }             // size cap of the tree (lchain.c:304): not handled here
-			const long long k1 = clock64();
+			k1 = CF_CLK();
 			{
-				const double wb = wave_min_f64(best);
-				const unsigned long long who = __ballot(best_j >= 0 && best == wb);
+				// the wave minimum of a double, as two 32-bit DPP reductions over its order-preserving integer image
+				const unsigned long long bits = (unsigned long long)__double_as_longlong(best);
+				const unsigned long long key = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ULL);
+				const uint32_t khi = (uint32_t)(key >> 32), klo = (uint32_t)key;
+				const uint32_t mhi = wave_min_u32(khi);
+				const uint32_t mlo = wave_min_u32(khi == mhi ? klo : 0xffffffffu);
+				const bool is_min = khi == mhi && klo == mlo;
+				const unsigned long long who = __ballot(best_j >= 0 && is_min);
 				if (who == 0) best_j = -1;
 				else {
-					if (__popcll(who) > 1 || __ballot(tie && best == wb)) { bail = true; break; }
+					if (__popcll(who) > 1 || __ballot(tie && is_min)) { bail = true; break; }
 					best_j = __builtin_amdgcn_readlane(best_j, __ffsll((long long)who) - 1);
 				}
 			}
-			const long long k2 = clock64();
+			}
+			k2 = CF_CLK();
 			long long k3 = k2;
 			if (best_j >= 0) {
 				int32_t exact, width; const int32_t j = best_j;
-				const CfEnt ej = r_e[j & CF_M];
-				int32_t sc = r_f[j & CF_M] + score_pair32(xi, yi, ej.x, ej.y, s_sp[j & CF_M], P.pen_gap, P.pen_skip, &exact, &width);
+				CfEnt ej; int32_t fj, spj;
+				if (j >= blk) { const int jl = j - blk; ej.x = __builtin_amdgcn_readlane(bx, jl); ej.y = __builtin_amdgcn_readlane(by, jl); fj = __builtin_amdgcn_readlane(bf, jl); spj = __builtin_amdgcn_readlane(bsp, jl); }
+				else { ej = r_e[j & CF_M]; fj = r_f[j & CF_M]; spj = s_sp[j & CF_M]; }
+				int32_t sc = fj + score_pair32(xi, yi, ej.x, ej.y, spj, P.pen_gap, P.pen_skip, &exact, &width);
 				if (width <= P.bw && sc > max_f) max_f = sc, max_j = j;
-				k3 = clock64();
+				k3 = CF_CLK();
 				if (!exact && max_dist_inner > 0 && yi > 0) {
 					// inner window start (lchain.c:300-303), exact; it is only needed here, so it is brought up to date here
 					if (st_in < st) st_in = st;
@@ -476,20 +527,22 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					}
 				}
 			}
-			const long long k4 = clock64();
+			const long long k4 = CF_CLK();
+			if (lane == il) bf = max_f;
+			p_last = cf_pri(max_f, xi, yi, P.pen_gap);
 			if (lane == 0) {
 				r_f[i & CF_M] = max_f; r_p[i & (CF_WI - 1)] = max_j;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			const long long k5 = clock64();
+			const long long k5 = CF_CLK();
 			tk_scan += k1 - k0; tk_red += k2 - k1; tk_best += k3 - k2; tk_inner += k4 - k3; tk_store += k5 - k4;
 		}
 		if (bail) break;
-		if (blk + lane < n) { F[blk + lane] = r_f[(blk + lane) & CF_M]; PP[blk + lane] = r_p[(blk + lane) & (CF_WI - 1)]; }
+		if (blk + lane < n) { F[blk + lane] = bf; PP[blk + lane] = r_p[(blk + lane) & (CF_WI - 1)]; }
 		if (blk + 64 <= n) {
 			// summary of the finished block: minimum priority (and whether it is unique), y range
-			const CfEnt eb = r_e[(blk + lane) & CF_M];
-			const double pb = cf_pri(r_f[(blk + lane) & CF_M], eb.x, eb.y, P.pen_gap);
+			CfEnt eb; eb.x = bx, eb.y = by;
+			const double pb = cf_pri(bf, eb.x, eb.y, P.pen_gap);
 			const double mp = wave_min_f64(pb);
 			const unsigned long long who = __ballot(pb == mp);
 			const int32_t ymin = wave_min_i32(eb.y), ymax = wave_max_i32(eb.y);
@@ -500,13 +553,15 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 		}
 	}
 	if (lane == 0) seg_flag[sg] = bail ? 1u : 0u;
-	if (prof && lane == 0) {
+	if (PROF && prof && lane == 0) {
 		const unsigned long long dt = wall_clock64() - c0;
 		atomicAdd(&prof[0], dt); atomicMax(&prof[1], dt); atomicMax(&prof[2], (unsigned long long)n);
+		atomicAdd(&prof[12], n_pev); atomicAdd(&prof[13], n_py);
 		atomicAdd(&prof[3], n_scan); atomicAdd(&prof[4], n_inner); atomicAdd(&prof[5], n_incand); atomicAdd(&prof[6], n_slow);
 		atomicAdd(&prof[7], (unsigned long long)tk_scan); atomicAdd(&prof[8], (unsigned long long)tk_red); atomicAdd(&prof[9], (unsigned long long)tk_best); atomicAdd(&prof[10], (unsigned long long)tk_inner); atomicAdd(&prof[11], (unsigned long long)tk_store);
 	}
 }
+#undef CF_CLK
 
 // one lane per segment: the sweep of lchain.c:276-357 restricted to anchors [b,e) (tree empty at b)
 __global__ void k_chain_segments(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_order, uint32_t n_seg,
@@ -829,8 +884,9 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
 		DBuf<unsigned long long> cprof(16); cprof.zero(st);
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
-		if (use_fast) hipLaunchKernelGGL(k_chain_fast<2048>, dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr,
-		                                 verbose ? cprof.p : (unsigned long long*)nullptr);
+		const bool prof_on = verbose && getenv("PGA_CHAIN_PROF");
+		if (use_fast && prof_on) hipLaunchKernelGGL((k_chain_fast<2048, true>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, cprof.p);
+		else if (use_fast) hipLaunchKernelGGL((k_chain_fast<2048, false>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
 		const double ms_fast = verbose ? et.stop() : 0.0;
 		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
 		                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
@@ -840,9 +896,9 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 			std::vector<uint32_t> fl = seg_flag.download(st); size_t nf = 0; for (uint32_t v : fl) nf += v;
 			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel, %.3f ms (fast kernel %.3f ms)\n", n_seg, nf, ms, ms_fast);
 			std::vector<unsigned long long> pr = cprof.download(st);
-			fprintf(stderr, "[pga]   chain fast: longest segment %llu anchors, slowest %.2f ms, sum %.1f ms; scan iterations %.2f/anchor, inner scans %.3f/anchor with %.1f candidates, %llu unsorted\n",
+			if (prof_on) fprintf(stderr, "[pga]   chain fast: longest segment %llu anchors, slowest %.2f ms, sum %.1f ms; scan iterations %.2f/anchor, inner scans %.3f/anchor with %.1f candidates, %llu unsorted\n",
 			        pr[2], pr[1] * 1e-5, pr[0] * 1e-5, (double)pr[3] / (double)n_a, (double)pr[4] / (double)n_a, pr[4] ? (double)pr[5] / (double)pr[4] : 0.0, pr[6]);
-			fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a);
+			if (prof_on) fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f; block rescans/anchor: partly evicted %.3f, y range %.3f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a, (double)pr[12] / n_a, (double)pr[13] / n_a);
 		}
 		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
 	}

@@ -34,6 +34,35 @@ __device__ __forceinline__ double wave_min_f64(double v)
 	return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_minu_step(uint32_t v)
+{
+	const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+	return o < v ? o : v;
+}
+// unsigned minimum over the wave, returned to every lane
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+	v = dpp_minu_step<0xB1, 0xf>(v);
+	v = dpp_minu_step<0x4E, 0xf>(v);
+	v = dpp_minu_step<0x141, 0xf>(v);
+	v = dpp_minu_step<0x140, 0xf>(v);
+	v = dpp_minu_step<0x142, 0xa>(v);
+	v = dpp_minu_step<0x143, 0xc>(v);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// minimum of a double over the wave (no NaNs), to every lane: two 32-bit reductions over the order-preserving integer image
+__device__ __forceinline__ double wave_min_f64_key(double v)
+{
+	const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+	const unsigned long long key = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ULL);
+	const uint32_t khi = (uint32_t)(key >> 32), klo = (uint32_t)key;
+	const uint32_t mhi = wave_min_u32(khi);
+	const uint32_t mlo = wave_min_u32(khi == mhi ? klo : 0xffffffffu);
+	const unsigned long long mk = ((unsigned long long)mhi << 32) | mlo;
+	return __longlong_as_double((long long)((mk >> 63) ? (mk & 0x7fffffffffffffffULL) : ~mk));
+}
+
 // inclusive prefix maximum over the wave (lane order), DPP only
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ int32_t dpp_max_step(int32_t v)
 {
