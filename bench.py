@@ -56,7 +56,8 @@ def usable_cpus() -> int:
 
 
 PMC_KERNEL_PREFIX = {"k_sketch_tiles": "void pga::k_sketch_tiles", "k_chain_fast": "void pga::k_chain_fast", "k_bt_list+k_bt_walk": "pga::k_bt_",
-                     "k_extd2_fast": "void pga::k_extd2_fast", "k_extd2_wide": "void pga::k_extd2_wide", "k_ll_i16": "pga::k_ll_i16", "k_rs_pass": "pga::k_rs_"}
+                     "k_extd2_fast": "void pga::k_extd2_fast", "k_extd2_wide": "void pga::k_extd2_wide", "k_ll_i16": "pga::k_ll_i16", "k_rs_pass": "pga::k_rs_",
+                     "k_gapfill_band": "pga::k_gapfill_band"}
 
 
 def pmc_traffic(kernel: str, genomes: int):

@@ -47,8 +47,8 @@ typedef struct {                 /* stage wall times (s) and work counters of a 
 	double n_bases, n_minimizers, n_anchors, n_dp_jobs, n_dp_cells, n_matches, n_dp_bases;
 	/* the path's own kernels, device time from HIP events on the launch stream:
 	 * [0] k_sketch_tiles  [1] k_chain_fast (+k_chain_segments)  [2] k_bt_list + k_bt_walk  [3] k_extd2_fast (register tiles)
-	 * [4] k_extd2_wide  [5] k_ll_i16  [6] k_rs_init + k_rs_pass (sort replay)  [7] unused */
-	double kern_ms[8], kern_launches[8], kern_alg_bytes[8];
+	 * [4] k_extd2_wide  [5] k_ll_i16  [6] k_rs_init + k_rs_pass (sort replay)  [7] k_gapfill_band (corridor gap fills)  [8], [9] unused */
+	double kern_ms[10], kern_launches[10], kern_alg_bytes[10];
 	double aligned_span;         /* sum of (qry_end - qry_start) over the emitted matches (secondary metric) */
 } pga_stats_t;
 

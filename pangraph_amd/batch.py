@@ -30,10 +30,10 @@ class pga_match_t(C.Structure):
 class pga_stats_t(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("upload", "sketch", "index", "seed", "chain", "align", "total", "n_bases", "n_minimizers", "n_anchors",
                                           "n_dp_jobs", "n_dp_cells", "n_matches", "n_dp_bases")] + \
-               [("kern_ms", C.c_double * 8), ("kern_launches", C.c_double * 8), ("kern_alg_bytes", C.c_double * 8), ("aligned_span", C.c_double)]
+               [("kern_ms", C.c_double * 10), ("kern_launches", C.c_double * 10), ("kern_alg_bytes", C.c_double * 10), ("aligned_span", C.c_double)]
 
 
-KERNELS = ("k_sketch_tiles", "k_chain_fast", "k_bt_list+k_bt_walk", "k_extd2_fast", "k_extd2_wide", "k_ll_i16", "k_rs_pass", "-")
+KERNELS = ("k_sketch_tiles", "k_chain_fast", "k_bt_list+k_bt_walk", "k_extd2_fast", "k_extd2_wide", "k_ll_i16", "k_rs_pass", "k_gapfill_band", "-", "-")
 
 
 class PgaError(RuntimeError):

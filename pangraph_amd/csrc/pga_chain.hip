@@ -342,7 +342,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			bool shortcut = false;
 			if (shortcut_ok && il > 0 && i0 == i - 1) {
 				const int32_t xp = __builtin_amdgcn_readlane(bx, il - 1), yp = __builtin_amdgcn_readlane(by, il - 1);
-				if (xp != xi && xi - xp <= max_dist && yp < yi && yp > yi - max_dist && p_last < p_floor) { shortcut = true; best_j = i - 1; i0 = i; }
+				if (xp != xi && xi - xp <= max_dist && yp < yi && yp > yi - max_dist && p_last < p_floor) { shortcut = true; best_j = i - 1; i0 = i; if (PROF) ++n_py; }
 			}
 			if (il > 0 && p_last < p_floor) p_floor = p_last;    // from here on p_floor covers every anchor below i
 			if (!shortcut) {
@@ -454,6 +454,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					for (int k = 0; k < CF_MAXIN / 64; ++k) {
 						const int32_t jc = i0 - 1 - (lane + 64 * k);
 						c_val[k] = false; c_ok[k] = false; c_mk[k] = false; c_sc[k] = 0; c_j[k] = jc;
+						if (64 * k >= n_in) continue;                        // (uniform: most inner windows fill one or two groups)
 						if (jc >= st_in) {
 							const CfEnt ec = r_e[jc & CF_M];
 							if (jc + 1 < i0 && r_e[(jc + 1) & CF_M].y < ec.y) unsorted = true;
@@ -468,7 +469,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					}
 					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
-					for (int k = 0; k < CF_MAXIN / 64; ++k) c_mk[k] = c_val[k] && r_t[c_j[k] & (CF_WI - 1)] == i;
+					for (int k = 0; k < CF_MAXIN / 64; ++k) if (64 * k < n_in) c_mk[k] = c_val[k] && r_t[c_j[k] & (CF_WI - 1)] == i;
 					if (__ballot(unsorted)) {
 						// general case: rank by descending (y, j) among valid candidates (all-pairs count), scatter, reload in scan order
 						++n_slow;
@@ -898,7 +899,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 			std::vector<unsigned long long> pr = cprof.download(st);
 			if (prof_on) fprintf(stderr, "[pga]   chain fast: longest segment %llu anchors, slowest %.2f ms, sum %.1f ms; scan iterations %.2f/anchor, inner scans %.3f/anchor with %.1f candidates, %llu unsorted\n",
 			        pr[2], pr[1] * 1e-5, pr[0] * 1e-5, (double)pr[3] / (double)n_a, (double)pr[4] / (double)n_a, pr[4] ? (double)pr[5] / (double)pr[4] : 0.0, pr[6]);
-			if (prof_on) fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f; block rescans/anchor: partly evicted %.3f, y range %.3f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a, (double)pr[12] / n_a, (double)pr[13] / n_a);
+			if (prof_on) fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f; block rescans/anchor: partly evicted %.3f; shortcut taken %.3f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a, (double)pr[12] / n_a, (double)pr[13] / n_a);
 		}
 		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
 	}

@@ -489,7 +489,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
-		size_t n_waves = c == 8 ? 256 * 16 : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * 3 : 256 * 16;
+		size_t n_waves = c == 8 ? 256 * 16 : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
@@ -518,7 +518,8 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		PGA_HIP(hipStreamSynchronize(st));                   // jb goes out of scope at the end of this iteration
-		hipStream_t &ls = lane_stream[lane_of_class[c]];
+		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
+		hipStream_t &ls = lane_stream[serial ? 0 : lane_of_class[c]];
 		static std::mutex lane_mu;
 		std::lock_guard<std::mutex> lane_lk(lane_mu);
 		if (!ls) {
@@ -539,6 +540,10 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
 			if (wide_lds_bytes(r_cap, seq_cap, exact) > WIDE_LDS_MAX) seq_cap = 0;      // sequences stay in HBM for this launch
+			// thousands of end extensions (class 2): they are bound by the per-diagonal latency of a workgroup, not by throughput, so
+			// what counts is how many of them a CU holds -- without the 2 x 10 KB sequence copies six fit instead of three (-20 %)
+			static const int c2_seq = getenv("PGA_C2_SEQ") ? atoi(getenv("PGA_C2_SEQ")) : 0;
+			if (c == 2 && ids.size() > 1536 && !c2_seq) seq_cap = 0;
 			// few problems: each workgroup effectively owns a CU, so give it the waves to hide its LDS latency -- as far as the
 			// band has work for them (every wave of the group pays every phase of a diagonal): ~2 columns per thread
 			int nt = 256;
@@ -562,12 +567,12 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		if (tm) {
 			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below
-			const int kk = c == 6 ? K_LL : (c <= 1 || c == 8) ? K_EXTD2 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7)
+			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c <= 1 ? K_EXTD2 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->dp_bases += bases;
 		}
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
-		download_to(r, X.d_r.p, ids.size(), lane_stream[lane_of_class[c]]);
+		download_to(r, X.d_r.p, ids.size(), lane_stream[getenv("PGA_DP_SERIAL") ? 0 : lane_of_class[c]]);
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
 		if (((c >= 2 && c <= 4) || c == 7) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
