@@ -9,30 +9,34 @@
 //   * te is the LAST target row whose maximum equals the global maximum (ksw2_ll_sse.c:139: >=);
 //   * qe is read from that row in the memory order of the striped layout, last hit wins (ksw2_ll_sse.c:145-150):
 //     column j sits at memory index (j % slen) * 8 + j / slen.
-// One 256-thread workgroup per problem sweeps anti-diagonals; a thread owns the target rows i = tid (mod 256), so F and
-// the row's own H stay private to it; H (three diagonals) and E (two) are exchanged through LDS with one barrier per
-// diagonal.  int16 arithmetic never saturates for the sizes accepted (the launcher checks a * qlen < 32000).
+// One 1024-thread workgroup per problem.  Thread t owns R = ceil(tlen/1024) CONSECUTIVE target rows and sweeps the query
+// column by column, one step behind thread t-1: at step s it computes the cells (i, j = s - t) of its rows top to bottom with
+// H(i, j-1) and F(i, j-1) of its rows in registers.  What a column needs from the row above the block -- H and E of that row
+// in the same column -- is what thread t-1 produced one step earlier: one DPP lane shift inside a wave, a double-buffered LDS
+// slot across waves, one barrier per step.  A cell costs ~16 VALU operations and no LDS access (the anti-diagonal version this
+// replaces read five int16 values per cell from LDS and took 2.3 us per diagonal of a 10 kb x 10 kb problem; this one 1.0 us per
+// column step).  Scores are int32 here; they never leave the int16 range for the sizes accepted (the launcher checks
+// a * qlen < 32000), so the reference's saturating arithmetic is the plain one.
 #include "pga_common.h"
 #include "pga_dp.h"
+#include "pga_wave.h"
 
 namespace pga {
 
-#define LL_NT 1024          // a problem has a CU to itself (LDS): the waves are there to hide LDS latency
+#define LL_NT 1024          // a problem has a CU to itself: the waves hide each other's latencies
+#define LL_RMAX 10          // rows per thread: PGA_LL_MAX_LEN / LL_NT
 
 __global__ __launch_bounds__(LL_NT)
 void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P, uint32_t *__restrict__ job_counter,
               unsigned long long *__restrict__ rowkey_all, size_t rowkey_stride, int t_cap, DpRes *__restrict__ res)
 {
-	extern __shared__ __align__(16) uint8_t dyn[];
+	extern __shared__ __align__(16) uint8_t dyn[];            // the query, padded to a multiple of 8 columns (t_cap bytes)
 	__shared__ uint32_t s_job;
 	__shared__ unsigned long long s_part[LL_NT / 64];
+	__shared__ int s_xh[2][LL_NT / 64], s_xe[2][LL_NT / 64];  // hand-off across wave boundaries, by step parity
+	(void)rowkey_all; (void)rowkey_stride;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	__builtin_amdgcn_s_setprio(3);
-	int16_t *Hb[3] = { (int16_t*)dyn, (int16_t*)dyn + t_cap, (int16_t*)dyn + 2 * t_cap };
-	int16_t *Eb[2] = { (int16_t*)dyn + 3 * t_cap, (int16_t*)dyn + 4 * t_cap };
-	int16_t *Fr = (int16_t*)dyn + 5 * t_cap;
-	uint8_t *tb = (uint8_t*)((int16_t*)dyn + 6 * t_cap), *qb = tb + t_cap;
-	unsigned long long *rowkey = rowkey_all + (size_t)blockIdx.x * rowkey_stride;
+	uint8_t *qb = dyn;
 	const int gapoe = P.q + P.e, ge = P.e;                    // the caller passes the single-affine pair in (q, e)
 	const int sc_mch = P.sc_mch, sc_mis = P.sc_mis, sc_N = P.sc_ambi;
 
@@ -46,11 +50,9 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
 		const int qlen = J.qlen, tlen = J.tlen;
 		const int slen = (qlen + 7) / 8, qlen8 = slen * 8;
-		for (int i = tid; i < tlen; i += LL_NT) {
-			tb[i] = t_base[J.seq_rev ? tlen - 1 - i : i];
-			Hb[0][i] = Hb[1][i] = Hb[2][i] = 0; Eb[0][i] = Eb[1][i] = 0; Fr[i] = 0;
-			rowkey[i] = 0;
-		}
+		const int R = (tlen + LL_NT - 1) / LL_NT;              // rows per thread (uniform)
+		const int n_act = (tlen + R - 1) / R;                  // threads that own at least one row
+		const int i0 = tid * R;
 		for (int j = tid; j < qlen8; j += LL_NT) {
 			int c = 4;
 			if (j < qlen) {
@@ -60,41 +62,56 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 			}
 			qb[j] = (uint8_t)(j < qlen ? c : 5);                // 5: padding column, score 0
 		}
+		// this thread's rows: target base, and the mismatch score it pays (N rows pay the ambiguity score against everything)
+		int ta[LL_RMAX], tm[LL_RMAX], Hl[LL_RMAX], Fl[LL_RMAX];
+#pragma unroll
+		for (int k = 0; k < LL_RMAX; ++k) {
+			const int i = i0 + k;
+			const int a = (k < R && i < tlen) ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 4;
+			ta[k] = a; tm[k] = a == 4 ? sc_N : sc_mis; Hl[k] = 0; Fl[k] = 0;
+		}
+		if (tid < 2 * (LL_NT / 64)) { (&s_xh[0][0])[tid] = 0; (&s_xe[0][0])[tid] = 0; }
 		__syncthreads();
-		int tbest = 1;                                         // row keys are only kept for cells that could still be the maximum
-		const int n_diag = tlen + qlen8 - 1;
-		for (int r = 0; r < n_diag; ++r) {
-			const int ilo = r - (qlen8 - 1) > 0 ? r - (qlen8 - 1) : 0, ihi = r < tlen - 1 ? r : tlen - 1;
-			const int16_t *H1 = Hb[(r + 2) % 3], *H2 = Hb[(r + 1) % 3]; int16_t *H0 = Hb[r % 3];   // H1: diagonal r-1, H2: diagonal r-2
-			const int16_t *E1 = Eb[(r + 1) & 1]; int16_t *E0 = Eb[r & 1];
-			int i = ilo + ((tid - ilo) & (LL_NT - 1));            // first row >= ilo owned by this thread
-			for (; i <= ihi; i += LL_NT) {
-				const int j = r - i;
-				const int a = tb[i], b = qb[j];
-				int s = b == 5 ? 0 : (a == 4 || b == 4) ? sc_N : (a == b ? sc_mch : sc_mis);
-				const int hd = (i > 0 && j > 0) ? (int)H2[i - 1] : 0;                 // H(i-1, j-1)
-				const int hu = i > 0 ? (int)H1[i - 1] : 0, eu = i > 0 ? (int)E1[i - 1] : 0;  // H(i-1, j), E(i-1, j)
-				const int hl = j > 0 ? (int)H1[i] : 0, fl = j > 0 ? (int)Fr[i] : 0;          // H(i, j-1), F(i, j-1)
-				int e = eu - ge; { const int t = hu - gapoe; e = e > t ? e : t; } if (e < 0) e = 0;
-				int f = fl - ge; { const int t = hl - gapoe; f = f > t ? f : t; } if (f < 0) f = 0;
-				if (i == 0) e = 0;
-				if (j == 0) f = 0;
-				int h = hd + s; h = h > e ? h : e; h = h > f ? h : f;
-				H0[i] = (int16_t)h; E0[i] = (int16_t)e; Fr[i] = (int16_t)f;
-				if (h >= tbest) {
-					tbest = h;
-					const unsigned long long key = ((unsigned long long)(unsigned)h << 32) | (unsigned)((j % slen) * 8 + j / slen);
-					if (key > rowkey[i]) rowkey[i] = key;
+		int out_h = 0, out_e = 0, diag_up = 0;                 // H, E of this thread's last row in the column of the previous step; H above the block one column back
+		unsigned long long best = 0;                           // max over (h, row, striped memory index), only cells with h >= 1
+		int bh = 1;
+		int jm = 0, jd = 0;                                    // j % slen, j / slen of the column this thread is at
+		const int n_step = qlen8 + n_act - 1;
+		for (int s = 0; s < n_step; ++s) {
+			const int j = s - tid;
+			// what the row above the block holds in column j: produced by thread tid-1 one step ago
+			int up_h = wave_shr1(out_h, 0), up_e = wave_shr1(out_e, 0);
+			if (lane == 0 && wave > 0) { up_h = s_xh[(s + 1) & 1][wave - 1]; up_e = s_xe[(s + 1) & 1][wave - 1]; }
+			if (tid < n_act && j >= 0 && j < qlen8) {
+				const int b = qb[j];
+				const bool b_special = b >= 4;
+				const int sv = b == 5 ? 0 : sc_N;
+				const int midx = jm * 8 + jd;
+				int hu = up_h, eu = up_e, hd = diag_up;
+#pragma unroll
+				for (int k = 0; k < LL_RMAX; ++k) {
+					if (k >= R) break;                                 // uniform
+					int sc = ta[k] == b ? sc_mch : tm[k];
+					if (b_special) sc = sv;
+					const int hl = Hl[k];
+					int e = max(max(eu - ge, hu - gapoe), 0);
+					int f = max(max(Fl[k] - ge, hl - gapoe), 0);
+					const int h = max(max(hd + sc, e), f);
+					if (h >= bh && i0 + k < tlen) {
+						bh = h;
+						const unsigned long long key = ((unsigned long long)(unsigned)h << 32) | ((unsigned)(i0 + k) << 16) | (unsigned)midx;
+						best = key > best ? key : best;
+					}
+					hd = hl; Hl[k] = h; Fl[k] = f; hu = h; eu = e;
 				}
+				diag_up = up_h;
+				out_h = hu; out_e = eu;
+				if (++jm == slen) jm = 0, ++jd;
 			}
+			if (lane == 63) { s_xh[s & 1][wave] = out_h; s_xe[s & 1][wave] = out_e; }
 			__syncthreads();
 		}
-		// global maximum, last row holding it, and that row's last hit in striped memory order
-		unsigned long long best = 0;
-		for (int i = tid; i < tlen; i += LL_NT) {
-			const unsigned long long k = ((rowkey[i] >> 32) << 32) | (unsigned)i;
-			best = k > best ? k : best;
-		}
+		// global maximum: highest score, then the LAST row holding it, then that row's last hit in striped memory order
 #pragma unroll
 		for (int d = 32; d >= 1; d >>= 1) {
 			const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(best & 0xffffffffULL), d), hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), d);
@@ -106,19 +123,18 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 		if (tid == 0) {
 			for (int k = 0; k < LL_NT / 64; ++k) best = s_part[k] > best ? s_part[k] : best;
 			const int gmax = (int)(best >> 32);
-			DpRes R; memset(&R, 0, sizeof(R));
-			R.score = gmax;
+			DpRes Rr; memset(&Rr, 0, sizeof(Rr));
+			Rr.score = gmax;
 			if (gmax > 0) {
-				const int te = (int)(best & 0xffffffffULL);
-				const int mi = (int)(rowkey[te] & 0xffffffffULL);
-				R.max_t = te; R.max_q = mi / 8 + mi % 8 * slen;
-			} else { R.max_t = tlen - 1; R.max_q = qlen8 - 1; }    // all-zero matrix: the last row and the last memory slot win the ties
-			res[jid] = R;
+				const int te = (int)((best >> 16) & 0xffffULL), mi = (int)(best & 0xffffULL);
+				Rr.max_t = te; Rr.max_q = mi / 8 + mi % 8 * slen;
+			} else { Rr.max_t = tlen - 1; Rr.max_q = qlen8 - 1; }  // all-zero matrix: the last row and the last memory slot win the ties
+			res[jid] = Rr;
 		}
 	}
 }
 
-size_t ll_lds_bytes(int t_cap) { return (size_t)t_cap * 14; }
+size_t ll_lds_bytes(int t_cap) { return (size_t)t_cap + 64; }
 
 void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter,
                    unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st)
