@@ -426,15 +426,31 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
 	fix_cigar(r, qseq, tseq, &qshift, &tshift);
 	qseq += qshift, tseq += tshift;
 	r.blen = r.mlen = 0;
+	const int a_match = mat[0];
+	const bool same_match = a_match > 0 && mat[6] == a_match && mat[12] == a_match && mat[18] == a_match;
 	for (uint32_t k = 0; k < r.cigar.size(); ++k) {
 		uint32_t op = r.cigar[k] & 0xf, len = r.cigar[k] >> 4;
 		if (op == 0) {
 			int n_ambi = 0, n_diff = 0;
-			for (uint32_t l = 0; l < len; ++l) {
-				int cq = qseq[qoff + l], ct = tseq[toff + l];
+			// stretches of identical unambiguous bases, eight at a time: every step adds the same positive match score, so s only
+			// grows (no clamp) and the running maximum is s at the end of the stretch; all values are integers plus the few
+			// fractional bits of earlier gap terms, far inside a double's mantissa, so s + 8a is the stepwise sum exactly
+			const uint8_t *pq = qseq + qoff, *pt = tseq + toff;
+			for (uint32_t l = 0; l < len;) {
+				if (same_match) {
+					const uint32_t l0 = l;
+					while (l + 8 <= len) {
+						uint64_t wq, wt; memcpy(&wq, pq + l, 8); memcpy(&wt, pt + l, 8);
+						if (wq != wt || (wq & 0xFCFCFCFCFCFCFCFCULL)) break;
+						l += 8;
+					}
+					if (l > l0) { s += (double)a_match * (double)(l - l0); max = max > s ? max : s; if (l == len) break; }
+				}
+				int cq = pq[l], ct = pt[l];
 				if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
 				s += mat[ct * 5 + cq];
 				if (s < 0) s = 0; else max = max > s ? max : s;
+				++l;
 			}
 			r.blen += len - n_ambi, r.mlen += len - (n_ambi + n_diff), r.n_ambi += n_ambi;
 			toff += len, qoff += len;
