@@ -768,13 +768,30 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 			int32_t wb = e0 - 63; if (wb < 0) wb = 0;
 			int32_t wp = -1, wf = 0, wt = 1;
 			{ const int32_t idx = wb + lane; if (idx <= e0) wp = p[idx], wf = f[idx], wt = t[idx]; }
-			int32_t cur = e0, m = 0, kept = 0, max_s = 0, myv = 0;
+			int32_t cur = e0, m = 0, kept = 0, max_s = 0;
 			const int64_t n_v0 = n_v;
 			for (;;) {
+				// Co-linear stretch inside the window, all at once: while the path steps to the anchor just below (p[j] == j-1), that
+				// anchor is unused (t == 0) and scores less (f[j-1] < f[j]), every step is a new maximum of z.x - f -- provided the
+				// last step was one too (kept == m; at the start both sides are 0) -- so nothing can break the walk and `run` steps
+				// collapse into an update of (cur, m, kept, max_s) and one coalesced store of the path
+				if (kept == m) {
+					const int32_t c = cur - wb, idx = wb + lane;
+					const int32_t f_lo = wave_shr1(wf, 0), t_lo = wave_shr1(wt, 1);
+					const bool ok = lane > 0 && lane <= c && wp == idx - 1 && t_lo == 0 && f_lo < wf;
+					const unsigned long long mk = __ballot(ok);
+					const unsigned long long sh = mk << (63 - c);                 // lane c -> bit 63
+					const int run = ~sh ? __clzll((long long)~sh) : 64;
+					if (run > 0) {
+						if (lane < run) v[n_v0 + m + lane] = cur - lane;
+						cur -= run; m += run; kept = m;
+						max_s = zx - rl(wf, cur - wb);
+						continue;
+					}
+				}
 				const int32_t nxt = rl(wp, cur - wb);
-				if ((m & 63) == lane) myv = cur;
+				if (lane == 0) v[n_v0 + m] = cur;
 				++m;
-				if ((m & 63) == 0) v[n_v0 + m - 64 + lane] = myv;
 				int32_t sv, tn = 1;
 				if (nxt < 0) sv = zx;
 				else {
@@ -792,7 +809,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 				if (nxt < 0 || tn != 0) break;
 				cur = nxt;
 			}
-			if ((m & 63) != 0 && lane < (m & 63)) v[n_v0 + (m & ~63) + lane] = myv;
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");              // the path was stored by whichever lanes held it
 			// kept part: the first `kept` path elements (the walk stops before max_i, lchain.c:72); marks stay even if the chain is dropped
 			for (int32_t c = lane; c < kept; c += 64) t[v[n_v0 + c]] = 1;
 			// score of the chain: z.x - f[max_i]; max_i is the path element number `kept` (or -1 past the root)
