@@ -465,6 +465,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
 	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
+	PGA_HIP(hipStreamSynchronize(st));                      // the only use of the caller's stream: everything below is ordered inside the lane streams
 	// The classes are independent persistent launches: each gets its own stream, so the handful of huge problems
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
@@ -473,7 +474,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
-	struct Launch { int c; std::vector<uint32_t> *ids; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
+	struct Launch { int c; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
 	size_t budget = (size_t)64 << 30;                       // per class; the four lane slabs together stay well inside HBM
@@ -507,17 +508,16 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		// register-resident classes are uniform enough to skip the sort)
 		if ((c >= 2 && c != 8) || ids.size() < 100000)
 			std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (size_t)jobs[a].qlen * jobs[a].tlen > (size_t)jobs[b].qlen * jobs[b].tlen; });
-		PinVec<DpJob> jb; jb.resize(ids.size());
-		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
 		L.emplace_back();
 		Launch &X = L.back();
 		X.c = c; X.ids = &ids;
-		X.d_jobs.upload(jb.data(), jb.size(), st);
+		PinVec<DpJob> &jb = X.jb; jb.resize(ids.size());       // stays alive until the class has been collected
+		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
+		X.d_jobs.alloc(ids.size());
 		X.d_r.alloc(ids.size());
-		X.d_cnt.alloc(1); X.d_cnt.zero(st);
+		X.d_cnt.alloc(1);
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
-		PGA_HIP(hipStreamSynchronize(st));                   // jb goes out of scope at the end of this iteration
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
 		hipStream_t &ls = lane_stream[serial ? 0 : lane_of_class[c]];
 		static std::mutex lane_mu;
@@ -528,6 +528,10 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			PGA_HIP(hipStreamCreateWithPriority(&ls, hipStreamNonBlocking, lane_of_class[c] == 0 ? prio_lo : prio_hi));
 		}
 		hipStream_t cs = ls;
+		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
+		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
+		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
+		PGA_HIP(hipMemsetAsync(X.d_cnt.p, 0, sizeof(uint32_t), cs));
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
 		if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
