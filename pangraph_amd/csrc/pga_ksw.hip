@@ -490,7 +490,8 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
-		size_t n_waves = c == 8 ? 256 * 16 : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
+		static const int c8w = getenv("PGA_C8_WAVES") ? atoi(getenv("PGA_C8_WAVES")) : 16;
+		size_t n_waves = c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
