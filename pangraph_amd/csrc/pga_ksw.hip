@@ -553,6 +553,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			// band has work for them (every wave of the group pays every phase of a diagonal): ~2 columns per thread
 			int nt = 256;
 			if (c == 4 || c == 7 || ids.size() <= 512) nt = r_cap >= 3000 ? 1024 : r_cap >= 1200 ? 512 : 256;
+			if (getenv("PGA_WIDE_NT")) nt = atoi(getenv("PGA_WIDE_NT"));
 			else if (c == 3) nt = 512;
 			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
