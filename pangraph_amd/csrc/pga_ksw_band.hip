@@ -141,7 +141,7 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
 			if (i_lo <= 0 || d_hi <= 0 || u_lo >= score || u_hi >= score) ok = false;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // direction bytes written by the other lanes of the group
-		// ---- backtrack (ksw2.h:127-159), both groups at once: lane 0 of each group walks, its 32 lanes refill the window ----
+		// ---- backtrack (ksw2.h:127-159), both groups at once, each with its 32 lanes ----
 		int n_cigar = 0;
 		{
 			int i = ok ? tlen - 1 : -1, j = ok ? qlen - 1 : -1, state = 0;
@@ -160,22 +160,36 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
 					}
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				if (gl == 0) {
-					while (i >= 0 && j >= 0) {
-						const int r = i + j, row = r_hi - r;
-						if (row >= BAND_ROWS) break;
-						const int col = i - ((r + c - 30) >> 1);
-						const uint32_t tmp = (col >= 0 && col < 32) ? s_win[g][row * 32 + col] : 0u;
-						if (state == 0) state = tmp & 7;
-						else if (!(tmp >> (state + 2) & 1)) state = 0;
-						if (state == 0) state = tmp & 7;
-						uint32_t op;
-						if (state == 0) op = 0, --i, --j;
-						else if (state == 1 || state == 3) op = 2, --i;
-						else op = 1, --j;
-						if (op != last_op) { if (n_cigar >= BAND_MAXCIG) { n_cigar = -9; i = j = -1; break; } cig[n_cigar] = 1u << 4 | op; ++n_cigar; last_op = op; }
-						else cig[n_cigar - 1] += 1u << 4;
+				// the 32 lanes of a group walk together (their i, j, state agree); a straight stretch of the diagonal -- the same corridor
+				// column on every other diagonal, direction 0 in every cell -- is taken up to 32 cells at a time
+				while (i >= 0 && j >= 0) {
+					const int r = i + j, row = r_hi - r;
+					if (row >= BAND_ROWS) break;
+					const int col = i - ((r + c - 30) >> 1);
+					if (state == 0) {
+						const int rk = row + 2 * gl;
+						const bool inw = rk < BAND_ROWS && i - gl >= 0 && j - gl >= 0 && col >= 0 && col < 32;
+						const uint32_t tk = inw ? (uint32_t)s_win[g][rk * 32 + col] : 0xffu;
+						const unsigned long long okm = __ballot((tk & 7) == 0);
+						const unsigned ok32 = (unsigned)(g ? okm >> 32 : okm & 0xffffffffULL);
+						const int run = ok32 == 0xffffffffu ? 32 : __ffs((int)~ok32) - 1;
+						if (run > 0) {
+							if (0u != last_op) { if (n_cigar >= BAND_MAXCIG) { n_cigar = -9; i = j = -1; break; } if (gl == 0) cig[n_cigar] = (uint32_t)run << 4; ++n_cigar; last_op = 0; }
+							else if (gl == 0) cig[n_cigar - 1] += (uint32_t)run << 4;
+							i -= run; j -= run;
+							continue;
+						}
 					}
+					const uint32_t tmp = (col >= 0 && col < 32) ? s_win[g][row * 32 + col] : 0u;
+					if (state == 0) state = tmp & 7;
+					else if (!(tmp >> (state + 2) & 1)) state = 0;
+					if (state == 0) state = tmp & 7;
+					uint32_t op;
+					if (state == 0) op = 0, --i, --j;
+					else if (state == 1 || state == 3) op = 2, --i;
+					else op = 1, --j;
+					if (op != last_op) { if (n_cigar >= BAND_MAXCIG) { n_cigar = -9; i = j = -1; break; } if (gl == 0) cig[n_cigar] = 1u << 4 | op; ++n_cigar; last_op = op; }
+					else if (gl == 0) cig[n_cigar - 1] += 1u << 4;
 				}
 				i = __shfl(i, 32 * g); j = __shfl(j, 32 * g);
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
