@@ -42,7 +42,7 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
                     DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
 	__shared__ uint8_t s_t[2][BAND_MAXLEN], s_q[2][BAND_MAXLEN];
-	__shared__ uint8_t s_win[2][BAND_ROWS * 32];
+	__shared__ __align__(16) uint8_t s_win[2][BAND_ROWS * 32];
 	__shared__ uint32_t s_cig[2][BAND_MAXCIG + 8];
 	const int lane = threadIdx.x, g = lane >> 5, gl = lane & 31;
 	uint8_t *slab = slab_all + (size_t)blockIdx.x * slab_bytes + (size_t)g * (slab_bytes / 2);
@@ -154,9 +154,13 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
 				if (++guard > 4096) { n_cigar = -7; break; }
 				const int r_hi = i + j;                            // window: diagonals r_hi-63 .. r_hi
 				if (walking) {
-					for (int row = 0; row < BAND_ROWS; ++row) {
-						const int r = r_hi - row;
-						s_win[g][row * 32 + gl] = r >= 0 ? slab[(size_t)r * 32 + gl] : (uint8_t)0;
+					// 64 diagonals x 32 bytes are contiguous in the slab: four 16-byte loads per lane, rows stored top-down
+#pragma unroll
+					for (int it = 0; it < BAND_ROWS * 32 / 16 / 32; ++it) {
+						const int idx = it * 32 + gl, r = r_hi - (BAND_ROWS - 1) + (idx >> 1);
+						uint4 v = make_uint4(0, 0, 0, 0);
+						if (r >= 0) v = *reinterpret_cast<const uint4*>(slab + (size_t)r * 32 + (idx & 1) * 16);
+						*reinterpret_cast<uint4*>(&s_win[g][(r_hi - r) * 32 + (idx & 1) * 16]) = v;
 					}
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
