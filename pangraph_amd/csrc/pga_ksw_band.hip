@@ -98,8 +98,11 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
 			}
 			int Hd = H2;                                         // (r-2, t-1): always this lane's own
 			// matrix borders (global alignment: H(-1,-1) = 0, first row / column pay the cheaper affine gap, no gap state there)
-			if (t == 0) { Hl = -band_gap(jq + 1, q, e, q2, e2); El = E2l = BAND_NEG; Hd = -band_gap(jq, q, e, q2, e2); }
-			if (jq == 0) { Hu = -band_gap(t + 1, q, e, q2, e2); Fu = F2u = BAND_NEG; Hd = -band_gap(t, q, e, q2, e2); }
+			// (a lane sits on a border only early on: column 0 needs st(r) <= 0, row 0 needs r - st(r) < 32, i.e. r < 40 for |c| <= 6)
+			if (r < 48) {
+				if (t == 0) { Hl = -band_gap(jq + 1, q, e, q2, e2); El = E2l = BAND_NEG; Hd = -band_gap(jq, q, e, q2, e2); }
+				if (jq == 0) { Hu = -band_gap(t + 1, q, e, q2, e2); Fu = F2u = BAND_NEG; Hd = -band_gap(t, q, e, q2, e2); }
+			}
 			const bool act = on && r < n_diag && t >= 0 && t < tlen && jq >= 0 && jq < qlen;
 			int h = BAND_NEG, E = BAND_NEG, F = BAND_NEG, E2 = BAND_NEG, F2 = BAND_NEG, d = 0;
 			if (act) {
