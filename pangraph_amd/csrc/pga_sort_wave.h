@@ -27,6 +27,7 @@ struct __attribute__((aligned(16))) RsLds {
 	u128 ins[64];                // insertion-sort staging
 	uint32_t head[256], tail[256], wbase[256];
 	uint8_t wslot[256];
+	uint32_t ppos[256]; uint32_t pk[256];   // the cycle being followed by the run-length walk: slot and bucket of every stop
 	unsigned long long prof[4];  // ticks (diagnostics)
 };
 
@@ -47,8 +48,164 @@ __device__ __forceinline__ void rs_flush(u128 *beg, RsLds &L, int d, int wlog, i
 	rs_fence_wave();
 }
 
+// ---- the walk of ksort.h:128-141 over RUNS of records ----
+// The reference's walk is one token moving between buckets: at bucket l it drops the record it carries at the bucket's head and
+// picks up the record that was there, whose digit is the next bucket.  Slots at or beyond a head still hold their original
+// records, so where the token goes depends only on the ORIGINAL digit sequence in front of the heads.  If the records at the
+// heads of all buckets of a cycle (leader i -> l1 -> l2 ... -> back to i) are each followed by M-1 records with the same digit,
+// the next M-1 cycles visit the same buckets one slot further along: M cycles are M independent rotations of disjoint slots, one
+// lane each.  Anchor positions and chain scores grow or fall steadily along an array, so at the upper levels a digit run is
+// hundreds to thousands of records long and a level that costs 190 ns per record as a token walk is a few hundred such events.
+// rend[p] = end of the digit run of the ORIGINAL record at p.  Cycles that are not simple (a bucket met twice: the token is pushing
+// a run of records that are already home) fall back to the token walk of that one cycle, home runs moved in bulk.
+__device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, RsLds &L, int lane, const unsigned long long (&nonempty)[4])
+{
+	auto digit_at = [&](uint32_t p) -> uint32_t { return (uint32_t)((beg[p].x >> shift) & 255); };
+#pragma unroll 1
+	for (int kk = 0; kk < 4; ++kk) {
+		unsigned long long todo = nonempty[kk];
+		while (todo) {
+			const uint32_t i = (uint32_t)(64 * kk + (__ffsll((long long)todo) - 1));
+			todo &= todo - 1;
+			uint32_t h = L.head[i]; const uint32_t tl = L.tail[i];
+			while (h < tl) {
+				const uint32_t d0 = digit_at(h);
+				uint32_t re = rend[h]; if (re > tl) re = tl;
+				if (d0 == i) { h = re; continue; }                      // a run of records that are home already
+				// follow the cycle that starts with beg[h] without moving anything
+				uint32_t M = re - h, k = d0; int Lc = 0; bool simple = true;
+				for (;;) {
+					bool hit = false;
+#pragma unroll
+					for (int c = 0; c < 4; ++c) hit |= lane + 64 * c < Lc && L.pk[lane + 64 * c] == k;
+					if (__ballot(hit) || Lc == 256) { simple = false; break; }
+					const uint32_t pos = L.head[k], tk = L.tail[k];
+					const uint32_t dd = digit_at(pos);
+					if (dd == k) { simple = false; break; }               // the record at the head is home: the token would push it along
+					uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk; r2 -= pos;
+					if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; }
+					rs_fence_wave();
+					++Lc;
+					if (r2 < M) M = r2;
+					if (dd == i) break;
+					k = dd;
+				}
+				if (simple) {
+					if (lane == 0) { L.prof[0] += 1; L.prof[1] += M; }
+					// M rotations, one per lane: the record of the leader's slot goes to the first stop, every stop's record to the next
+					// stop, the last one (digit i) into the leader's slot
+					for (uint32_t m = (uint32_t)lane; m < M; m += 64) {
+						u128 t = ld128(&beg[h + m]);
+						for (int q = 0; q < Lc; ++q) { u128 *slot = &beg[L.ppos[q] + m]; const u128 o = ld128(slot); *slot = t; t = o; }
+						beg[h + m] = t;
+					}
+					for (int q = lane; q < Lc; q += 64) L.head[L.pk[q]] += M;   // (distinct buckets: the cycle is simple)
+					rs_fence_wave();
+					h += M;
+					continue;
+				}
+				// the token walk of this one cycle (every lane follows it; lane 0 owns the stores).  A cycle over mirrored runs bounces
+				// between the same few buckets for as long as the digit runs at their heads last (k -> k' -> k -> k' ...): from the
+				// token's position the path is followed until it meets a bucket it has already stopped at; the stops from there on
+				// form a LOOP that repeats T times, T = the shortest run remainder among them, and T rounds are again independent
+				// slot-to-slot copies (stop j takes the records of stop j-1, the first stop those of the last stop one round earlier)
+				if (lane == 0) L.prof[2] += 1;
+				u128 carry = ld128(&beg[h]);
+				uint32_t dst = d0;
+				while (dst != i) {
+					int Lc = 0, q0 = -1; uint32_t k = dst, T = 0xffffffffu; bool home = false;
+					for (;;) {
+						int hitq = 0x7fffffff;
+#pragma unroll
+						for (int c = 0; c < 4; ++c) if (lane + 64 * c < Lc && L.pk[lane + 64 * c] == k) hitq = lane + 64 * c;
+						hitq = wave_min_i32(hitq);
+						if (hitq != 0x7fffffff) { q0 = hitq; break; }
+						if (Lc == 256) break;
+						const uint32_t pos = L.head[k], tk = L.tail[k];
+						const uint32_t dd = digit_at(pos);
+						if (dd == k) { home = true; break; }
+						if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; }
+						rs_fence_wave();
+						++Lc;
+						if (dd == i) break;
+						k = dd;
+					}
+					if (q0 >= 0) {
+						for (int q = q0; q < Lc; ++q) { const uint32_t pos = L.ppos[q], tk = L.tail[L.pk[q]]; uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk; r2 -= pos; if (r2 < T) T = r2; }
+					}
+					// the stops before the loop (or all of them, when there is no loop worth taking): ordinary steps
+					const int n_plain = (q0 >= 0 && T >= 2) ? q0 : Lc;
+					for (int q = 0; q < n_plain; ++q) {
+						u128 *slot = &beg[L.ppos[q]];
+						const u128 nxt = ld128(slot);
+						if (lane == 0) { *slot = carry; L.head[L.pk[q]] = L.ppos[q] + 1; }
+						carry = nxt;
+						if (lane == 0) L.prof[3] += 1;
+					}
+					rs_fence_wave();
+					if (n_plain < Lc) {
+						// T rounds of the loop [q0, Lc)
+						if (lane == 0) { L.prof[0] += 1; L.prof[1] += T; }
+						const uint32_t p_first = L.ppos[q0], p_last = L.ppos[Lc - 1];
+						for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+							const uint32_t t = t0 + (uint32_t)lane;
+							const bool on = t < T;
+							u128 last; last.x = 0, last.y = 0;
+							if (on) last = ld128(&beg[p_last + t]);
+							for (int j = Lc - 1; j > q0; --j) if (on) { const u128 v = ld128(&beg[L.ppos[j - 1] + t]); beg[L.ppos[j] + t] = v; }
+							// the first stop takes the last stop's record of the round before: lane l from lane l-1, lane 0 the carry
+							u128 prev;
+							prev.x = (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)last.x, (int)(uint32_t)carry.x) | (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)(last.x >> 32), (int)(uint32_t)(carry.x >> 32)) << 32;
+							prev.y = (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)last.y, (int)(uint32_t)carry.y) | (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)(last.y >> 32), (int)(uint32_t)(carry.y >> 32)) << 32;
+							if (on) beg[p_first + t] = prev;
+							const int top = (int)(T - t0 > 64 ? 63 : T - t0 - 1);
+							carry.x = (uint64_t)(uint32_t)rl32((int)(uint32_t)last.x, top) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(last.x >> 32), top) << 32;
+							carry.y = (uint64_t)(uint32_t)rl32((int)(uint32_t)last.y, top) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(last.y >> 32), top) << 32;
+						}
+						for (int q = q0 + lane; q < Lc; q += 64) L.head[L.pk[q]] = L.ppos[q] + T;
+						rs_fence_wg();
+					}
+					dst = (uint32_t)((carry.x >> shift) & 255);
+					if (!home || dst == i) continue;
+					// the head of dst holds a record that is home: one step, or the whole run of home records moved up in bulk
+					{
+						const uint32_t hd = L.head[dst], tk = L.tail[dst];
+						uint32_t p = rend[hd]; if (p > tk) p = tk;
+						if (p - hd >= 8 && p < tk) {
+							const u128 out = ld128(&beg[p]);
+							for (uint32_t hi = p; hi > hd; ) {
+								u128 v[4]; uint32_t q[4];
+#pragma unroll
+								for (int c = 0; c < 4; ++c) { q[c] = hi - (uint32_t)lane - 64u * c; if ((int64_t)hi - lane - 64 * c > (int64_t)hd) v[c] = ld128(&beg[q[c] - 1]); }
+#pragma unroll
+								for (int c = 0; c < 4; ++c) if ((int64_t)hi - lane - 64 * c > (int64_t)hd) beg[q[c]] = v[c];
+								hi = hi - hd > 256 ? hi - 256 : hd;
+							}
+							if (lane == 0) { beg[hd] = carry; L.head[dst] = p + 1; }
+							rs_fence_wg();
+							carry = out;
+						} else {
+							const u128 nxt = ld128(&beg[hd]);
+							if (lane == 0) { beg[hd] = carry; L.head[dst] = hd + 1; }
+							rs_fence_wave();
+							carry = nxt;
+						}
+						if (lane == 0) L.prof[3] += 1;
+						dst = (uint32_t)((carry.x >> shift) & 255);
+					}
+				}
+				if (lane == 0) beg[h] = carry;
+				++h;
+			}
+			if (lane == 0) L.head[i] = h;
+			rs_fence_wave();
+		}
+	}
+	rs_fence_wg();
+}
+
 // one level (ksort.h:118-146) on [beg, beg+n); false if every record has the same digit (the walk is the identity)
-__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4])
+__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4], uint32_t *rend = nullptr)
 {
 	for (int d = lane; d < 256; d += 64) L.head[d] = 0, L.wbase[d] = RS_NONE;
 	rs_fence_wave();
@@ -74,6 +231,32 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 		n_ne += (uint32_t)__popcll(nonempty[k]);
 	}
 	if (n_ne <= 1) return false;
+	if (rend && n >= 4096) {
+		// digit runs of the original order, back to front: rend[p] = first position after p whose digit differs
+		uint32_t nb = 0, carry_end = (uint32_t)n;
+		for (int64_t c0 = (n - 1) & ~63LL; c0 >= 0; c0 -= 64) {
+			const int64_t p = c0 + lane;
+			const uint32_t dg = p < n ? (uint32_t)((beg[p].x >> shift) & 255) : 256u;
+			const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)257, (int)dg, 0x130, 0xf, 0xf, false);   // wave_shl:1, lane 63 sees "no neighbour"
+			// digit of position c0+64 (the first of the chunk handled before this one) decides whether lane 63 ends a run
+			const bool last_of_run = p < n && (lane == 63 ? (p + 1 >= n || (uint32_t)((beg[p + 1 < n ? p + 1 : p].x >> shift) & 255) != dg) : nx != dg);
+			const unsigned long long bm = __ballot(last_of_run);
+			nb += (uint32_t)__popcll(bm);
+			const unsigned long long up = bm >> lane;                  // run ends at or after this lane
+			const uint32_t e = up ? (uint32_t)(p + (__ffsll((long long)up) - 1) + 1) : carry_end;
+			if (p < n) rend[p] = e;
+			// the run that reaches beyond this chunk's start continues into the chunk below: its end is the end of lane 0's run
+			carry_end = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
+		}
+		rs_fence_wg();
+		if ((uint64_t)n >= 64ull * nb) {                          // digit runs of 64+ records on average: below that the token walk through the LDS windows is faster
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const int b = lane + 64 * k; L.head[b] = off[k]; L.tail[b] = off[k] + cnt[k]; }
+			rs_fence_wave();
+			rs_walk_runs(beg, shift, rend, L, lane, nonempty);
+			return true;
+		}
+	}
 	// window space: the non-empty buckets share the pool, 16 to 64 records each
 	int wlog = 4;
 	while (wlog < 6 && (n_ne << (wlog + 1)) <= RS_POOL) ++wlog;
