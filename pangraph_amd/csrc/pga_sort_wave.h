@@ -19,7 +19,7 @@
 
 namespace pga {
 
-#define RS_POOL 4096          // records of window space shared by the non-empty buckets of a level (64 KB)
+#define RS_POOL 2048          // records of window space shared by the non-empty buckets of a level (32 KB: four waves per CU)
 #define RS_NONE 0xffffffffu
 
 struct __attribute__((aligned(16))) RsLds {
@@ -258,7 +258,7 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 		}
 	}
 	// window space: the non-empty buckets share the pool, 16 to 64 records each
-	int wlog = 4;
+	int wlog = 3;
 	while (wlog < 6 && (n_ne << (wlog + 1)) <= RS_POOL) ++wlog;
 	const uint32_t W = 1u << wlog;
 	{
