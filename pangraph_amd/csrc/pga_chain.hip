@@ -337,6 +337,29 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			const int il = i - blk;
 			const int32_t xi = __builtin_amdgcn_readlane(bx, il), yi = __builtin_amdgcn_readlane(by, il), q_span = __builtin_amdgcn_readlane(bsp, il);
 			int32_t max_f = q_span, max_j = -1;
+			// Co-linear stretch inside the block, all at once: anchors that each follow their predecessor on the same diagonal within its
+			// span (dr == dq <= span: "exact" in lchain.c:322, so no inner scan) chain to it with f = f_pred + dr -- the shortcut's
+			// conditions hold for every one of them (priorities fall strictly along the stretch), so f is f_first + (x - x_first) and
+			// the stretch is written out by its lanes
+			if (shortcut_ok && il > 0 && i0 == i - 1 && p_last < p_floor) {
+				const int32_t xpl = wave_shr1(bx, 0), ypl = wave_shr1(by, 0), spl = wave_shr1(bsp, 0);
+				const int32_t dr = bx - xpl, dq = by - ypl;
+				const int32_t f_l = __builtin_amdgcn_readlane(bf, il - 1) + (bx - __builtin_amdgcn_readlane(bx, il - 1));
+				const bool c_ok = lane >= il && blk + lane < blk_end && dr > 0 && dr <= max_dist && dq == dr && dr <= spl && dr < max_dist && f_l > bsp;
+				const unsigned long long m2 = __ballot(c_ok) >> il;
+				const int R = ~m2 ? __ffsll((long long)~m2) - 1 : 64;
+				if (R >= 2) {
+					if (lane >= il && lane < il + R) { bf = f_l; r_f[(blk + lane) & CF_M] = f_l; r_p[(blk + lane) & (CF_WI - 1)] = blk + lane - 1; }
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+					const int la = il + R - 2, lb = il + R - 1;
+					p_floor = cf_pri(__builtin_amdgcn_readlane(bf, la), __builtin_amdgcn_readlane(bx, la), __builtin_amdgcn_readlane(by, la), P.pen_gap);
+					p_last = cf_pri(__builtin_amdgcn_readlane(bf, lb), __builtin_amdgcn_readlane(bx, lb), __builtin_amdgcn_readlane(by, lb), P.pen_gap);
+					if (PROF) n_py += R;
+					i0 = i + R - 1;
+					i += R - 1;
+					continue;
+				}
+			}
 			long long k0 = CF_CLK(), k1 = k0, k2 = k0;
 			int32_t best_j = -1;
 			bool shortcut = false;
