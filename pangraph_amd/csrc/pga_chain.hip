@@ -302,6 +302,12 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 	// from the block summaries once per block so that it forgets evicted anchors), it is the unique range minimum whatever the
 	// window holds -- the eviction search, the scans and the wave reduction are skipped and st is brought up to date later.
 	double p_floor = 1e300, p_last = 1e300;
+	// The inner scan (lchain.c:322-349) only ever changes (max_f, max_j), and a candidate j scores at most f[j] + span[j] (the
+	// penalties only subtract).  fs_floor = max of f + span over the anchors below i-1 (kept like p_floor: running, rebuilt from
+	// the block summaries), fs_last = that of anchor i-1: when no candidate other than the one already taken can beat max_f, the
+	// scan is skipped.
+	const int32_t FS_NONE = -(1 << 30);
+	int32_t fs_floor = FS_NONE, fs_last = FS_NONE, sm_fs = FS_NONE;
 	const bool shortcut_ok = P.cap >= CF_W;                  // (the tree-size cap of lchain.c:304 cannot bind inside the ring)
 	const unsigned long long c0 = wall_clock64();
 	unsigned long long n_scan = 0, n_inner = 0, n_incand = 0, n_slow = 0, n_pev = 0, n_py = 0;
@@ -329,6 +335,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 				st += 64;
 			}
 			p_floor = wave_min_f64_key((lane < CF_W / 64 && sm_blk >= 0 && sm_blk + 64 > st) ? sm_pri : 1e300);
+			fs_floor = wave_max_i32((lane < CF_W / 64 && sm_blk >= 0 && sm_blk + 64 > st) ? sm_fs : FS_NONE);
 		}
 		// the ring must hold [st, blk+128)
 		if (blk + 128 - st > CF_W) { bail = true; break; }
@@ -354,6 +361,11 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					const int la = il + R - 2, lb = il + R - 1;
 					p_floor = cf_pri(__builtin_amdgcn_readlane(bf, la), __builtin_amdgcn_readlane(bx, la), __builtin_amdgcn_readlane(by, la), P.pen_gap);
 					p_last = cf_pri(__builtin_amdgcn_readlane(bf, lb), __builtin_amdgcn_readlane(bx, lb), __builtin_amdgcn_readlane(by, lb), P.pen_gap);
+					{
+						const int32_t fsm = wave_max_i32((lane >= il && lane < il + R - 1) ? bf + bsp : FS_NONE);
+						fs_floor = max(max(fs_floor, fs_last), fsm);
+						fs_last = __builtin_amdgcn_readlane(bf, lb) + __builtin_amdgcn_readlane(bsp, lb);
+					}
 					if (PROF) n_py += R;
 					i0 = i + R - 1;
 					i += R - 1;
@@ -452,9 +464,16 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 				int32_t sc = fj + score_pair32(xi, yi, ej.x, ej.y, spj, P.pen_gap, P.pen_skip, &exact, &width);
 				if (width <= P.bw && sc > max_f) max_f = sc, max_j = j;
 				k3 = CF_CLK();
+				if (!exact && (j == i - 1 ? fs_floor : max(fs_floor, fs_last)) <= max_f) { exact = 1; if (PROF) ++n_pev; }   // nobody left who could do better
 				if (!exact && max_dist_inner > 0 && yi > 0) {
 					// inner window start (lchain.c:300-303), exact; it is only needed here, so it is brought up to date here
 					if (st_in < st) st_in = st;
+					{
+						// x ascends: if the anchor CF_MAXIN+1 slots back already lies outside the inner window, so does everything before it
+						// (after a long shortcut stretch st_in is far behind and the forward search would crawl there 64 slots at a time)
+						const int32_t lo = i0 - (CF_MAXIN + 1);
+						if (lo > st_in && xi - r_e[lo & CF_M].x > max_dist_inner) st_in = lo + 1;
+					}
 					for (;;) {
 						const int32_t jj = st_in + lane;
 						const bool keep = jj >= i0 || !(xi - r_e[jj & CF_M].x > max_dist_inner);
@@ -554,6 +573,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			const long long k4 = CF_CLK();
 			if (lane == il) bf = max_f;
 			p_last = cf_pri(max_f, xi, yi, P.pen_gap);
+			fs_floor = max(fs_floor, fs_last); fs_last = max_f + q_span;
 			if (lane == 0) {
 				r_f[i & CF_M] = max_f; r_p[i & (CF_WI - 1)] = max_j;
 			}
@@ -569,8 +589,9 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			const double pb = cf_pri(bf, eb.x, eb.y, P.pen_gap);
 			const double mp = wave_min_f64(pb);
 			const unsigned long long who = __ballot(pb == mp);
-			const int32_t ymin = wave_min_i32(eb.y), ymax = wave_max_i32(eb.y);
+			const int32_t ymin = wave_min_i32(eb.y), ymax = wave_max_i32(eb.y), fsb = wave_max_i32(bf + bsp);
 			if (lane == ((blk >> 6) & (CF_W / 64 - 1))) {
+				sm_fs = fsb;
 				sm_pri = mp; sm_arg = __popcll(who) == 1 ? blk + (int32_t)(__ffsll((long long)who) - 1) : -1;
 				sm_blk = blk; sm_ymin = ymin; sm_ymax = ymax;
 			}
@@ -939,7 +960,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 			std::vector<unsigned long long> pr = cprof.download(st);
 			if (prof_on) fprintf(stderr, "[pga]   chain fast: longest segment %llu anchors, slowest %.2f ms, sum %.1f ms; scan iterations %.2f/anchor, inner scans %.3f/anchor with %.1f candidates, %llu unsorted\n",
 			        pr[2], pr[1] * 1e-5, pr[0] * 1e-5, (double)pr[3] / (double)n_a, (double)pr[4] / (double)n_a, pr[4] ? (double)pr[5] / (double)pr[4] : 0.0, pr[6]);
-			if (prof_on) fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f; block rescans/anchor: partly evicted %.3f; shortcut taken %.3f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a, (double)pr[12] / n_a, (double)pr[13] / n_a);
+			if (prof_on) fprintf(stderr, "[pga]   chain fast clocks/anchor: scan %.0f reduce %.0f best %.0f inner %.0f store %.0f; inner scans skipped by the f + span bound %.3f/anchor; shortcut taken %.3f\n", (double)pr[7] / n_a, (double)pr[8] / n_a, (double)pr[9] / n_a, (double)pr[10] / n_a, (double)pr[11] / n_a, (double)pr[12] / n_a, (double)pr[13] / n_a);
 		}
 		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
 	}
