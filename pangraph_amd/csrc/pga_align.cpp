@@ -637,19 +637,34 @@ struct Driver {
 		if (a_ <= 0 || b_ <= 0) return false;
 		const uint8_t *t = acc.tptr(Q.base + rid) + ts, *q = acc.tptr(Q.qid);
 		int m = 0;
+		// eight bases per step: codes are 0..3 (anything else disqualifies), a differing byte has bit 0 or bit 1 set in the XOR
+		const int64_t m_max = (lim - 1) / (a_ + b_);               // (a+b)*m < lim  <=>  m <= m_max
+		int32_t i = 0;
 		if (!rev) {
 			const uint8_t *qq = q + qs;
-			for (int32_t i = 0; i < n; ++i) {
+			for (; i + 8 <= n; i += 8) {
+				uint64_t wt, wq; memcpy(&wt, t + i, 8); memcpy(&wq, qq + i, 8);
+				if ((wt | wq) & 0xFCFCFCFCFCFCFCFCULL) return false;
+				const uint64_t d = wt ^ wq;
+				if (d) { m += __builtin_popcountll((d | d >> 1) & 0x0101010101010101ULL); if (m > m_max) return false; }
+			}
+			for (; i < n; ++i) {
 				const uint8_t x = t[i], y = qq[i];
 				if ((x | y) > 3) return false;
-				if (x != y && (int64_t)(a_ + b_) * ++m >= lim) return false;
+				if (x != y && ++m > m_max) return false;
 			}
 		} else {
 			const uint8_t *qq = q + (Q.qlen - 1 - qs);                // base i of the reverse strand window = 3 - q[qlen-1-(qs+i)]
-			for (int32_t i = 0; i < n; ++i) {
+			for (; i + 8 <= n; i += 8) {
+				uint64_t wt, wq; memcpy(&wt, t + i, 8); memcpy(&wq, qq - i - 7, 8);
+				if ((wt | wq) & 0xFCFCFCFCFCFCFCFCULL) return false;
+				const uint64_t d = wt ^ (__builtin_bswap64(wq) ^ 0x0303030303030303ULL);   // reversed, complemented (3 - y == y ^ 3 for 0..3)
+				if (d) { m += __builtin_popcountll((d | d >> 1) & 0x0101010101010101ULL); if (m > m_max) return false; }
+			}
+			for (; i < n; ++i) {
 				const uint8_t x = t[i], y = qq[-i];
 				if ((x | y) > 3) return false;
-				if (x != (uint8_t)(3 - y) && (int64_t)(a_ + b_) * ++m >= lim) return false;
+				if (x != (uint8_t)(3 - y) && ++m > m_max) return false;
 			}
 		}
 		DpJob j; memset(&j, 0, sizeof(j));
