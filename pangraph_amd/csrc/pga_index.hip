@@ -95,9 +95,11 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 	hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, st, orig.p, n);
 	{
 		size_t tmp_bytes = 0;
-		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, 0, 64, st));
+		// x = hash << 8 | span with a 2k-bit hash and span == k for every minimizer (sketch.c:136 without HPC): only bits [8, 8+2k) vary
+		const int lo_bit = 8, hi_bit = std::min(64, 8 + 2 * k);
+		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, lo_bit, hi_bit, st));
 		DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
-		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, 0, 64, st));
+		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kx.p, kx2.p, orig.p, orig2.p, n, lo_bit, hi_bit, st));
 	}
 	uint64_t *kxs = kx2.p; uint32_t *origs = orig2.p; const uint32_t *gks = nullptr;
 	if (S.n_grp > 1) {
