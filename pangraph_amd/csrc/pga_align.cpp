@@ -788,6 +788,11 @@ struct Driver {
 		while (T.seg_k < T.segs.size() && !T.dropped) {
 			Seg &sg = T.segs[T.seg_k];
 			if (!have(Q, sg.job1)) return false;
+			// results and CIGARs of the following segments lie wherever their kernels finished: start fetching them now
+			for (size_t ahead = 2; ahead <= 4; ahead += 2) if (T.seg_k + ahead < T.segs.size()) {
+				const int nj = T.segs[T.seg_k + ahead].job1;
+				if (nj >= 0 && (size_t)nj < Q.res.size()) { __builtin_prefetch(&Q.res[nj]); if (Q.cig[nj]) __builtin_prefetch(Q.cig[nj]); }
+			}
 			T.re1 = sg.re, T.qe1 = sg.qe;
 			int final_job = sg.job1;
 			if (sg.zcode < 0 && sg.ll_job < 0) {
