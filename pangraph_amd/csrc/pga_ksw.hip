@@ -502,7 +502,11 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) { PGA_HIP(hipDeviceSynchronize()); lane_slab[l].alloc(lane_need[l]); }
 	// every class is prepared and launched in turn, the classes with few, long problems first: they are already running
 	// while the host still lays out the million-tile classes
-	for (int c = DP_NCLASS - 1; c >= 0; --c) {
+	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
+	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
+	static const int launch_order[DP_NCLASS] = {7, 6, 5, 4, 3, 2, 8, 1, 0};
+	for (int oi = 0; oi < DP_NCLASS; ++oi) {
+		const int c = launch_order[oi];
 		if (cls[c].empty()) continue;
 		std::vector<uint32_t> &ids = cls[c];
 		// biggest problems first, so that the persistent waves finish together (the many small tiles of the
