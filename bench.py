@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- aligned Gbp/s of the pairwise block-alignment backend on synthetic genomes (BASELINE.json metric).
+"""bench.py -- aligned Gbp/s of the pairwise block-alignment backend over a WHOLE `pangraph build` of 1000 synthetic
+5 Mbp genomes (BASELINE.json metric and configuration C5).
 
-A STEP is one pass of the whole hot path (sketch -> index -> seed/anchor -> chain -> banded DP extension ->
-records) over one guide-tree LEVEL: every rank aligns its own G all-vs-all groups in ONE batch.  The workload is
-the leaf level of `pangraph build` on synthetic bacterial-like genomes (SURVEY.md section 8d generator: random
-ancestor, SNPs, indels, inversions, HGT-like insertions, deletions): group g = two sibling genomes, exactly the
-block set of the first `find_matches` call of that merge (graph_merging.rs:98).  Units U = bases handed to the
-aligner (sum of sequence lengths of all groups); value = U * steps / wall, summed over ranks
-(weak scaling: per-rank work is fixed).  Sequences are copied to HBM before the timed region (pga_batch_create);
-the timed region runs pga_batch_align() and, for N>1, the RCCL gather of the match lists to rank 0.
+Workload: `pangraph_amd.levels.Population(20260928, 1000, 5_000_000)` -- genomes evolved along a random tree with SNPs,
+indels, inversions, HGT insertions, deletions and duplications -- and, for every merge of the guide tree, the block sets the
+reference would hand to its aligner: round 0 (joined child graphs) and round 1 (merged graph) of the self-merge loop
+(graph_merging.rs:26-69).  A WAVE is what a level-synchronous host can align at once: all merges of one tree height, one round.
+A STEP is the whole build: every wave in dependency order, each through `pga_batch_create` (host hand-over: upload + encoding)
+and `pga_batch_align` (sketch -> index -> seed -> chain -> extend -> records), followed -- for N > 1 -- by the RCCL gather of
+the wave's match list to rank 0.  Units U = bases handed to the aligner, summed over all waves (every sequence of every
+`find_matches` call counts once); value = U * steps / wall time INCLUDING the hand-over of the sequences
+(8d's definition); `resident_gbp_s` is the same without the hand-over (bases already in HBM).
 
-The line also carries
-  roofline      the dominant kernel of the run (largest device time): algorithmic bytes / HIP-event time vs 8 TB/s
-  cpu_baseline  the REFERENCE's own C (oracle/_ref/libmm2ref.so, compiled from /root/reference by oracle/Makefile),
-                one process per host core, on a bounded sample of the same groups
+N > 1: the FIXED workload is sharded (strong scaling): the groups of every wave are dealt to the ranks balanced by base count,
+no data-path collective, one match-list gather per wave.  `python bench.py --gpus N` spawns the N ranks itself when it is not
+already running under torch.distributed.run.
+
+The JSON line also carries
+  roofline      the kernel with the largest device time and a per-kernel table: algorithmic bytes / HIP-event time vs 8 TB/s for the
+                HBM-bound kernels, evaluated DP cells per second for the DP kernels
+  cpu_baseline  the REFERENCE's own C (oracle/_ref/libmm2ref.so, compiled from /root/reference by oracle/Makefile), one process
+                per host core, on a bounded sample of the same waves
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,21 +34,6 @@ sys.path.insert(0, ROOT)
 import pangraph_amd  # noqa: E402  (sets the HIP runtime defaults of the backend before anything initialises HIP)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-def make_groups(seed: int, n_genomes: int, length: int, div: float):
-    """n_genomes/2 sibling pairs; every pair descends from its own ancestor (leaf merges are independent)."""
-    import numpy as np
-    from pangraph_amd.synth import random_seq, mutate
-    groups, names = [], []
-    for g in range(n_genomes // 2):
-        rng = np.random.default_rng(seed * 1000003 + g)
-        anc = random_seq(rng, length)
-        ev = max(2000, min(50000, length // 40))
-        kids = [mutate(rng, anc, snp=div / 2, indel=div / 20, n_inv=2, n_ins=6, n_del=4, max_event=ev) for _ in range(2)]
-        groups.append([k.tobytes() for k in kids])
-        names.append([str(2 * g), str(2 * g + 1)])
-    return groups, names
 
 
 def usable_cpus() -> int:
@@ -55,27 +48,20 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-PMC_KERNEL_PREFIX = {"k_sketch_tiles": "void pga::k_sketch_tiles", "k_chain_fast": "void pga::k_chain_fast", "k_bt_list+k_bt_walk": "pga::k_bt_",
-                     "k_extd2_fast": "void pga::k_extd2_fast", "k_extd2_wide": "void pga::k_extd2_wide", "k_ll_i16": "pga::k_ll_i16", "k_rs_pass": "pga::k_rs_",
-                     "k_gapfill_band": "pga::k_gapfill_band"}
-
-
-def pmc_traffic(kernel: str, genomes: int):
+def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/r01_*_pmc_hbm_traffic_<genomes>genomes.json: FETCH_SIZE and WRITE_SIZE in separate passes, in KB; FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for gfx950 -- an upper bound for the narrower accesses).  None if there is no
-    PMC summary for this configuration."""
+    (profiles/r*_pmc_hbm_traffic_c5.json: FETCH_SIZE and WRITE_SIZE in separate passes, in KB; FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  NOT measured in this run; None if there is no PMC summary."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{genomes}genomes.json")))
-    pre = PMC_KERNEL_PREFIX.get(kernel)
-    if not files or not pre:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_c5.json")))
+    if not files:
         return None
     d = json.load(open(files[-1]))
     tot, n = 0.0, 0
     for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         disp = 0
         for k, v in d.get(c, {}).items():
-            if k.startswith(pre):
+            if kernel in k:
                 tot += mul * v["sum"] * 1024.0
                 disp += v["dispatches"]
         n = max(n, disp)
@@ -87,51 +73,82 @@ def _cpu_worker(args):
     from pangraph_amd.mm2ffi import Mm2Lib
     lib = Mm2Lib(so)
     t0 = time.time()
-    rows = lib.align_all([s.decode() for s in seqs], names, sensitivity=10)
+    rows = lib.align_all([s.tobytes().decode() for s in seqs], names, sensitivity=10)
     return time.time() - t0, sum(len(s) for s in seqs), len(rows)
 
 
-def cpu_baseline(groups, names, budget_s: float):
-    """The reference C on the host cores: one group per process, as many groups as cores (bounded sample)."""
+def cpu_baseline(waves, budget_s: float):
+    """The reference C on the host cores: one group per process, one group from every wave until the budget is used."""
     import multiprocessing as mp
     so = os.path.join(ROOT, "oracle", "_ref", "libmm2ref.so")
     kind = "reference"
     if not os.path.exists(so):
         so, kind = os.path.join(ROOT, "oracle", "libpgoracle.so"), "port"
     cores = usable_cpus()
-    n = min(cores, len(groups))
-    # calibrate on one group, then size the sample to the budget
-    t1, b1, _ = _cpu_worker((so, groups[0], names[0]))
-    rounds = max(1, min(4, int(budget_s / max(t1, 1e-3))))
-    jobs = [(so, groups[i % len(groups)], names[i % len(groups)]) for i in range(n * rounds)]
+    # calibrate on the smallest group of the first wave, then take one group per wave (the largest that fits what is left)
+    _, g0, n0 = waves[0]
+    i0 = min(range(len(g0)), key=lambda i: sum(len(s) for s in g0[i]))
+    t1, b1, _ = _cpu_worker((so, g0[i0], n0[i0]))
+    rate1 = b1 / max(t1, 1e-3)
+    budget_bases = rate1 * budget_s * cores
+    per_job_cap = rate1 * budget_s * 1.2          # no single job longer than ~the budget
+    jobs, used = [], 0.0
+    for _, groups, names in waves:
+        sizes = [sum(len(s) for s in g) for g in groups]
+        cand = [i for i in range(len(groups)) if sizes[i] <= per_job_cap and used + sizes[i] <= budget_bases]
+        if cand:
+            i = max(cand, key=lambda j: sizes[j])
+            jobs.append((so, groups[i], names[i]))
+            used += sizes[i]
+    if not jobs:
+        jobs = [(so, g0[i0], n0[i0])]
+    n = min(cores, len(jobs))
+    jobs.sort(key=lambda j: -sum(len(s) for s in j[1]))
     t0 = time.time()
     with mp.get_context("spawn").Pool(n) as pool:
-        res = pool.map(_cpu_worker, jobs)
+        res = pool.map(_cpu_worker, jobs, chunksize=1)
     wall = time.time() - t0
     bases = sum(r[1] for r in res)
     return {"value": bases / wall / 1e9, "unit": "Gbp/s", "cores": n, "kind": kind,
-            "sample": f"{len(jobs)} leaf-pair groups ({bases / 1e6:.1f} Mbp), {n} processes x 1 thread, {wall:.1f} s; 1 core: {b1 / t1 / 1e9:.5f} Gbp/s"}
+            "sample": f"{len(jobs)} groups, one from every wave that fits ({bases / 1e6:.1f} Mbp), {n} processes x 1 thread, {wall:.1f} s wall, "
+                      f"{sum(r[0] for r in res):.1f} core-s; 1 core on a leaf pair: {rate1 / 1e9:.5f} Gbp/s"}
+
+
+def respawn_under_torchrun(n: int):
+    port = 29500 + os.getpid() % 20000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + sys.argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=int(os.environ.get("PGA_BENCH_GENOMES", 512)), help="genomes PER GPU at the leaf level")
+    ap.add_argument("--genomes", type=int, default=int(os.environ.get("PGA_BENCH_GENOMES", 1000)), help="genomes of the whole build (not per GPU)")
     ap.add_argument("--length", type=int, default=int(os.environ.get("PGA_BENCH_LENGTH", 5_000_000)))
-    ap.add_argument("--divergence", type=float, default=0.01)
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 disables)")
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--leaf-only", action="store_true", help="diagnosis: only the waves of height 1")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work per core (0 disables)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from pangraph_amd import batch
-    from pangraph_amd.dist import gather_blobs, max_over_ranks, sum_over_ranks
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pangraph_amd import batch
+    from pangraph_amd.dist import gather_matches, max_over_ranks, shard_groups_balanced
+    from pangraph_amd.levels import Population, waves_bases
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
     # PGA_BENCH_SINGLE_DEVICE=1 (debugging on a 1-GPU box): every rank computes on GPU 0 and the collectives run over gloo
@@ -148,79 +165,142 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     cdev = torch.device("cpu") if single else dev          # where the collectives' tensors live
 
-    groups, names = make_groups(20260928 + rank, args.genomes, args.length, args.divergence)
-    pb = batch.PreparedBatch(groups, names)
-    rb = batch.ResidentBatch(pb)                     # H2D happens here, outside the timed region
-    units = float(pb.total_bases)
+    t_gen = time.time()
+    pop = Population(args.seed, args.genomes, args.length)
+    waves = pop.build_waves()
+    if args.leaf_only:
+        waves = waves[:2]
+    units = float(waves_bases(waves))
+    t_gen = time.time() - t_gen
+
+    # the sharding plan of every wave (identical on every rank) and this rank's flat C views of its groups
+    plans, mine = [], []
+    for _, groups, names in waves:
+        plan = shard_groups_balanced([sum(len(s) for s in g) for g in groups], world)
+        plans.append(plan)
+        ids = plan[rank]
+        mine.append(batch.PreparedBatch([groups[i] for i in ids], [names[i] for i in ids]) if ids else None)
 
     # host threads of this rank: the ranks of a node share one CPU quota
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     n_threads = max(2, usable_cpus() // max(1, local_world))
 
-    def step(want_raw):
-        res = rb.align(sensitivity=10, want_raw=want_raw, n_threads=n_threads)
-        if world > 1:
-            # the match list (records, then the CIGAR pool) goes to the rank that owns the graph
-            gather_blobs(res.raw_matches, cdev, dst=0, as_bytes=False)
-            gather_blobs(res.raw_cigars, cdev, dst=0, as_bytes=False)
-        res.close()
-        return res
+    def step():
+        agg = {"create_s": 0.0, "align_s": 0.0, "gather_s": 0.0, "n_matches": 0, "stats": None, "per_wave": []}
+        for w, pb in enumerate(mine):
+            t0 = time.perf_counter()
+            res = None
+            if pb is not None:
+                rb = batch.ResidentBatch(pb)                      # hand-over: inside the timed region
+                t1 = time.perf_counter()
+                res = rb.align(sensitivity=10, want_raw=world > 1, n_threads=n_threads)
+                t2 = time.perf_counter()
+                rb.close()
+            else:
+                t1 = t2 = t0
+            if world > 1:
+                z = np.zeros(0, np.uint8)
+                got = gather_matches(res.raw_matches if res is not None else z, res.raw_cigars if res is not None else z, plans[w][rank], plans[w], cdev, dst=0)
+                if got is not None:
+                    agg["n_matches"] += len(got[0])
+            t3 = time.perf_counter()
+            agg["create_s"] += t1 - t0; agg["align_s"] += t2 - t1; agg["gather_s"] += t3 - t2
+            if res is not None:
+                st = res.stats
+                if world == 1:
+                    agg["n_matches"] += int(st["n_matches"])
+                agg["per_wave"].append((waves[w][0], pb.total_bases, t1 - t0, t2 - t1, st["n_matches"]))
+                if agg["stats"] is None:
+                    agg["stats"] = {k: (list(v) if isinstance(v, list) else v) for k, v in st.items()}
+                else:
+                    for k, v in st.items():
+                        if isinstance(v, list):
+                            agg["stats"][k] = [a + b for a, b in zip(agg["stats"][k], v)]
+                        else:
+                            agg["stats"][k] += v
+                res.close()
+        return agg
 
     for _ in range(args.warmup):
-        step(world > 1)
+        step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        last = step(world > 1)
+        last = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         dt = max_over_ranks(dt, cdev)
-        total_units = sum_over_ranks(units, cdev)
-    else:
-        total_units = units
 
-    st = last.stats
-    kern = [(st["kern_ms"][i], batch.KERNELS[i], st["kern_launches"][i], st["kern_alg_bytes"][i]) for i in range(len(batch.KERNELS)) if st["kern_launches"][i] > 0]
-    kms, kname, klaunch, kbytes = max(kern)
+    st = last["stats"]
+    K = batch.KERNELS
+    table = {}
+    for i, name in enumerate(K):
+        if name == "-" or st["kern_launches"][i] <= 0:
+            continue
+        ms, n, by, cells = st["kern_ms"][i], st["kern_launches"][i], st["kern_alg_bytes"][i], st["kern_cells"][i]
+        e = {"device_ms_per_step": ms, "launches_per_step": n, "avg_launch_ms": ms / n}
+        if batch.KERNEL_BOUND[i] == "hbm":
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            e.update({"bound": "hbm", "alg_bytes_per_launch": by / n, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+        else:
+            e.update({"bound": "valu+lds (integer DP; no MFMA)", "alg_bytes_per_launch": by / n, "cells_evaluated": cells,
+                      "gcups": cells / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
+        table[name] = e
+    kname = max(table, key=lambda k: table[k]["device_ms_per_step"])
+    ki = K.index(kname)
+    kms, klaunch, kbytes = st["kern_ms"][ki], st["kern_launches"][ki], st["kern_alg_bytes"][ki]
     achieved = (kbytes / klaunch) / (kms / klaunch * 1e-3) / 1e9 if klaunch and kms > 0 else 0.0
+    dp_cells = sum(st["kern_cells"])
+    dp_ms = sum(st["kern_ms"][i] for i in range(len(K)) if batch.KERNEL_BOUND[i] == "dp")
+    ms_step = dt / args.steps * 1e3
     out = {
-        "metric": "aligned Gbp/s in the pangraph-build alignment backend (bases handed to the aligner per second)",
-        "value": total_units * args.steps / dt / 1e9,
+        "metric": "aligned Gbp/s in `pangraph build` (bases handed to the aligner per second, all merges, all self-merge rounds)",
+        "value": units * args.steps / dt / 1e9,
         "unit": "Gbp/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": ms_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"leaf level of pangraph build: {args.genomes // 2} sibling-genome pairs per GPU x {args.length} bp "
-                               f"(asm10, -c -X -s 90, ~{args.divergence * 100:.1f}% divergence + inversions/HGT/deletions), one batch per step",
-                   "genomes_per_gpu": args.genomes, "genome_length": args.length, "groups_per_gpu": args.genomes // 2,
-                   "parallelism": f"groups sharded over {world} rank(s), match-list gather to rank 0"},
+        "config": {"workload": f"{args.genomes} x {args.length} bp genomes, all levels: whole guide-tree build, {len(waves)} waves "
+                               f"(tree heights 1..{len(waves) // 2} x self-merge rounds 0,1), {sum(len(g) for _, g, _ in waves)} find_matches calls, "
+                               f"U = {units / 1e9:.2f} Gbp per step (asm10, -c -X -s 90)" + (" [LEAF LEVEL ONLY]" if args.leaf_only else ""),
+                   "genomes": args.genomes, "genome_length": args.length, "seed": args.seed, "waves": len(waves),
+                   "timed_region": "per wave: pga_batch_create (H2D + encoding) + pga_batch_align + match-list gather",
+                   "parallelism": f"groups of every wave sharded over {world} rank(s) by base count, match-list gather to rank 0 per wave"},
+        "resident_gbp_s": units / max(last["align_s"], 1e-9) / 1e9 if world == 1 else None,
+        "rank0_seconds_per_step": {"hand_over": last["create_s"], "align": last["align_s"], "gather": last["gather_s"]},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(kname, args.genomes), "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
-                     "alg_bytes_per_launch": kbytes / klaunch if klaunch else None},
-        "stages_s": {k: st[k] for k in ("sketch", "index", "seed", "chain", "align", "total")},
-        "kernels_ms": {batch.KERNELS[i]: st["kern_ms"][i] for i in range(len(batch.KERNELS)) if st["kern_launches"][i] > 0},
-        "counts": {k: st[k] for k in ("n_bases", "n_minimizers", "n_anchors", "n_dp_jobs", "n_dp_cells", "n_matches")},
-        "aligned_span_gbp_s_per_gpu": st["aligned_span"] * args.steps / dt / 1e9,      # secondary: sum of (qe - qs) of this rank's matches per second
+                     "traffic": pmc_traffic(kname), "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run)",
+                     "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
+                     "alg_bytes_per_launch": kbytes / klaunch if klaunch else None,
+                     "note": "device_ms_per_step are HIP-event times on each kernel's own stream; streams overlap, so they do not add up to ms_per_step",
+                     "kernels": table},
+        "dp": {"cells_evaluated": dp_cells, "gcups_over_dp_kernel_time": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
+               "gcups_over_step": dp_cells / (ms_step * 1e-3) / 1e9, "nominal_cells_qlen_x_tlen": st["n_dp_cells"], "jobs": st["n_dp_jobs"]},
+        "stages_s": {k: st[k] for k in ("upload", "sketch", "index", "seed", "chain", "align", "total")},
+        "counts": {k: st[k] for k in ("n_bases", "n_minimizers", "n_anchors", "n_dp_jobs", "n_matches")},
+        "n_matches_gathered": last["n_matches"],
+        "aligned_span_gbp_s_rank0": st["aligned_span"] * args.steps / dt / 1e9,      # secondary: sum of (qe - qs) of rank 0's matches per second
+        "waves_rank0": [{"wave": w, "Mbp": b / 1e6, "hand_over_s": round(c, 4), "align_s": round(a, 4), "matches": int(m)} for w, b, c, a, m in last["per_wave"]],
+        "workload_generation_s": t_gen,
     }
     if rank == 0:
         if args.cpu_budget > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(groups, names, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(waves, args.cpu_budget)
         elif world > 1:
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "reference", "sample": "measured at N=1 only"}
         print(json.dumps(out))
-    rb.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -45,10 +45,12 @@ typedef struct pga_result_s pga_result_t;
 typedef struct {                 /* stage wall times (s) and work counters of a call */
 	double upload, sketch, index, seed, chain, align, total;
 	double n_bases, n_minimizers, n_anchors, n_dp_jobs, n_dp_cells, n_matches, n_dp_bases;
-	/* the path's own kernels, device time from HIP events on the launch stream:
+	/* the path's own kernels, device time from HIP events on the launch stream (streams overlap: the times do not add up to `total`):
 	 * [0] k_sketch_tiles  [1] k_chain_fast (+k_chain_segments)  [2] k_bt_list + k_bt_walk  [3] k_extd2_fast (register tiles)
-	 * [4] k_extd2_wide  [5] k_ll_i16  [6] k_rs_init + k_rs_pass (sort replay)  [7] k_gapfill_band (corridor gap fills)  [8], [9] unused */
-	double kern_ms[10], kern_launches[10], kern_alg_bytes[10];
+	 * [4] k_extd2_wide<256>  [5] k_ll_i16  [6] k_rs_init + k_rs_pass + k_rs_small (sort replay)  [7] k_gapfill_band (corridor gap fills)
+	 * [8] k_extd2_wide<512>  [9] k_extd2_wide<1024>  [10] index build (device sorts + CSR kernels)  [11] seeding kernels + anchor sort
+	 * [12..15] unused.  kern_cells: DP cells evaluated by the DP kernels ([3] [4] [5] [7] [8] [9]), 0 elsewhere */
+	double kern_ms[16], kern_launches[16], kern_alg_bytes[16], kern_cells[16];
 	double aligned_span;         /* sum of (qry_end - qry_start) over the emitted matches (secondary metric) */
 } pga_stats_t;
 
@@ -84,6 +86,9 @@ int pga_stage_chain(const pga_params_t *params, int32_t n, const char *const *se
 int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const int32_t *qlen, const uint8_t *const *t, const int32_t *tlen,
                     int a, int b, int sc_ambi, int gapo, int gape, int gapo2, int gape2, const int32_t *w, const int32_t *zdrop, const int32_t *end_bonus, const int32_t *flag,
                     int32_t *ez, uint32_t **cigars, uint64_t *cigar_off);
+/* radix_sort_128x (ksort.h:101-151, misc.c:155-159), the exact replay incl. the arrangement of equal keys: sorts every array
+ * [seg_off[s], seg_off[s+1]) of the n_seg arrays in xy (two uint64 per record: x = key, y = payload) in place */
+int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy);
 void pga_free(void *p);
 #ifdef __cplusplus
 }

@@ -30,10 +30,14 @@ class pga_match_t(C.Structure):
 class pga_stats_t(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("upload", "sketch", "index", "seed", "chain", "align", "total", "n_bases", "n_minimizers", "n_anchors",
                                           "n_dp_jobs", "n_dp_cells", "n_matches", "n_dp_bases")] + \
-               [("kern_ms", C.c_double * 10), ("kern_launches", C.c_double * 10), ("kern_alg_bytes", C.c_double * 10), ("aligned_span", C.c_double)]
+               [("kern_ms", C.c_double * 16), ("kern_launches", C.c_double * 16), ("kern_alg_bytes", C.c_double * 16), ("kern_cells", C.c_double * 16),
+                ("aligned_span", C.c_double)]
 
 
-KERNELS = ("k_sketch_tiles", "k_chain_fast", "k_bt_list+k_bt_walk", "k_extd2_fast", "k_extd2_wide", "k_ll_i16", "k_rs_pass", "k_gapfill_band", "-", "-")
+KERNELS = ("k_sketch_tiles", "k_chain_fast", "k_bt_list+k_bt_walk", "k_extd2_fast", "k_extd2_wide<256>", "k_ll_i16", "k_rs_init+k_rs_pass+k_rs_small",
+           "k_gapfill_band", "k_extd2_wide<512>", "k_extd2_wide<1024>", "index build (sorts + CSR kernels)", "seeding kernels + anchor sort", "-", "-", "-", "-")
+# what bounds each slot: HBM traffic (scan / sort / hash work) or the integer DP recurrences (VALU + LDS issue; no MFMA)
+KERNEL_BOUND = ("hbm", "hbm", "hbm", "dp", "dp", "dp", "hbm", "dp", "dp", "dp", "hbm", "hbm", "-", "-", "-", "-")
 
 
 class PgaError(RuntimeError):
@@ -83,10 +87,15 @@ def set_device(dev: int) -> None:
 
 
 class PreparedBatch:
-    """Flat C arrays of a list of groups, built once (so a benchmark can time only the library call)."""
+    """Flat C arrays of a list of groups, built once (so a benchmark can time only the library call).
+    Sequences may be str, bytes or 1-D uint8 numpy arrays; arrays are passed by address (no copy: they must stay alive and
+    contiguous, which slices of a contiguous 1-D array are)."""
 
     def __init__(self, groups: Sequence[Sequence[str]], names: Optional[Sequence[Sequence[str]]] = None):
         self.n_groups = len(groups)
+        if self.n_groups and len(groups[0]) and hasattr(groups[0][0], "ctypes"):
+            self._init_arrays(groups, names)
+            return
         flat, flat_names, off = [], [], [0]
         for gi, g in enumerate(groups):
             nm = names[gi] if names is not None else [str(i) for i in range(len(g))]
@@ -104,6 +113,31 @@ class PreparedBatch:
         self.lens = (C.c_uint32 * n)(*[len(b) for b in flat])
         self.off = (C.c_int64 * (self.n_groups + 1))(*off)
         self.total_bases = sum(len(b) for b in flat)
+
+
+def _init_arrays(self, groups, names):
+    flat, flat_names, off = [], [], [0]
+    for gi, g in enumerate(groups):
+        nm = names[gi] if names is not None else [str(i) for i in range(len(g))]
+        if len(nm) != len(g):
+            raise ValueError("Number of sequences and number of sequence names is expected to be the same")
+        flat.extend(g)
+        flat_names.extend(n.encode() for n in nm)
+        off.append(len(flat))
+    n = len(flat)
+    for a in flat:
+        if a.dtype.itemsize != 1 or (a.ndim != 1) or (n and a.strides[0] != 1):
+            raise ValueError("sequence arrays must be contiguous 1-D uint8")
+    self.names = [x.decode() for x in flat_names]
+    self._keep = (flat, flat_names)
+    self.seqs = C.cast((C.c_void_p * n)(*[a.ctypes.data for a in flat]), C.POINTER(C.c_char_p))
+    self.cnames = (C.c_char_p * n)(*flat_names)
+    self.lens = (C.c_uint32 * n)(*[len(a) for a in flat])
+    self.off = (C.c_int64 * (self.n_groups + 1))(*off)
+    self.total_bases = sum(len(a) for a in flat)
+
+
+PreparedBatch._init_arrays = _init_arrays
 
 
 @dataclass

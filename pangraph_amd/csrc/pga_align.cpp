@@ -631,6 +631,7 @@ struct Driver {
 	bool gap_fill_by_identity(QueryCtx &Q, int rev, int rid, int32_t qs, int32_t ts, int32_t n, int &id_out)
 	{
 		if (n <= 0) return false;
+		if (opt.max_sw_mat > 0 && (int64_t)n * n > opt.max_sw_mat) return false;   // align.c:326: the reference never aligns such a window (request() answers z-dropped)
 		const int a_ = mat[0], b_ = -mat[1];
 		const int g1 = std::min(opt.q + opt.e, opt.q2 + opt.e2);
 		const int64_t lim = (int64_t)a_ + 2 * g1;                  // (a+b)*m < lim
@@ -1140,26 +1141,28 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 		if (n_sets == 1) run_rounds(sets[0], 0, n_threads, st, tm);
 		else {
 			int dev = 0; PGA_HIP(hipGetDevice(&dev));
-			const int arena0 = dev_get_arena();
 			std::vector<Timers> tms((size_t)n_sets);
 			std::vector<std::string> errs((size_t)n_sets);
 			std::vector<std::thread> th;
 			for (int k = 0; k < n_sets; ++k) th.emplace_back([&, k] {
 				hipStream_t ss = nullptr;
+				const int arena = dev_lease_arena();      // the set's own stream gets its own arena
+				ArenaScope arena_scope(arena);
 				try {
 					PGA_HIP(hipSetDevice(dev));
-					dev_set_arena(arena0 * 16 + 1000 + k);
 					set_thread_budget(std::max(1, n_threads / n_sets));
 					PGA_HIP(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
 					run_rounds(sets[(size_t)k], k, std::max(1, n_threads / n_sets), ss, tm ? &tms[(size_t)k] : nullptr);
 				} catch (std::exception &e) { errs[(size_t)k] = e.what(); if (errs[(size_t)k].empty()) errs[(size_t)k] = "unknown error"; }
 				if (ss) { (void)hipStreamSynchronize(ss); (void)hipStreamDestroy(ss); }
+				(void)hipDeviceSynchronize();            // the DP lane streams of the set have drained too: the arena's blocks are reusable
+				dev_release_arena(arena);
 			});
 			for (auto &t : th) t.join();
 			for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
 			if (tm) for (const Timers &t : tms) {
 				tm->dp_jobs += t.dp_jobs; tm->dp_cells += t.dp_cells; tm->dp_bases += t.dp_bases; tm->dp_cigar_ops += t.dp_cigar_ops;
-				for (int i = 0; i < K_COUNT; ++i) { tm->kern[i].ms += t.kern[i].ms; tm->kern[i].launches += t.kern[i].launches; tm->kern[i].alg_bytes += t.kern[i].alg_bytes; }
+				for (int i = 0; i < K_COUNT; ++i) { tm->kern[i].ms += t.kern[i].ms; tm->kern[i].launches += t.kern[i].launches; tm->kern[i].alg_bytes += t.kern[i].alg_bytes; tm->kern[i].cells += t.kern[i].cells; }
 			}
 		}
 

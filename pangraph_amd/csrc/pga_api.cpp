@@ -82,11 +82,15 @@ struct PgaIdx {
 	std::map<std::string, int> by_name;
 	std::mutex mtx;
 	bool have_results = false, indexed = false; mm_mapopt_t res_opt;
+	std::string failure;             // first error of the batch behind this index: sticky, the batch is attempted once
 	std::vector<std::vector<Reg>> results;
 	Timers tm;
 	hipStream_t st = 0;              // the part's own (non-blocking) stream
-	int arena = 0;                   // device-memory arena of the part (pga_mem.cpp)
-	~PgaIdx() { if (st) (void)hipStreamDestroy(st); }
+	int arena = 0;                   // device-memory arena of the index, leased for its lifetime (pga_mem.cpp)
+	PgaIdx() : arena(dev_lease_arena()) {}
+	~PgaIdx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } release_buffers(); dev_release_arena(arena); }
+	void release_buffers() { S.d_nt4.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
+		I.key.release(); I.occ_off.release(); I.occ.release(); I.key_grp.release(); grp.release(); d_name_rank.release(); d_mid_occ.release(); }
 };
 
 static void require_device()
@@ -115,7 +119,12 @@ static void idx_sketch_index(PgaIdx &ix)
 	double t1 = now_s();
 	sketch_all(ix.S, w, k, ix.M, ix.st, &ix.tm);
 	double t2 = now_s();
-	build_index_ex(ix.S, ix.M, w, k, ix.I, ix.grp, ix.st);
+	{
+		EventTimer et(ix.st);
+		build_index_ex(ix.S, ix.M, w, k, ix.I, ix.grp, ix.st);
+		KernelStat &ks = ix.tm.kern[K_INDEX];        // 16 B minimizer read for the sort + sorted write + table write
+		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 48.0 * (double)ix.M.n;
+	}
 	double t3 = now_s();
 	ix.tm.sketch = t2 - t1, ix.tm.index = t3 - t2; ix.tm.n_mz = (double)ix.M.n;
 	ix.indexed = true;
@@ -125,6 +134,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 {
 	require_device();
 	std::unique_ptr<PgaIdx> ix(new PgaIdx());
+	ArenaScope arena_scope(ix->arena);
 	memset(&ix->hdr, 0, sizeof(ix->hdr));
 	PGA_HIP(hipStreamCreateWithFlags(&ix->st, hipStreamNonBlocking));
 	if (w < 1) w = 1;
@@ -177,11 +187,17 @@ static std::vector<int32_t> group_mid_occ(PgaIdx &ix, const mm_mapopt_t &opt)
 
 static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 {
+	ArenaScope arena_scope(ix.arena);
 	check_supported(opt, ix.I.k, ix.I.w);
 	double t0 = now_s();
 	ix.d_mid_occ.upload(group_mid_occ(ix, opt), ix.st);
 	SeedResult SR;
-	seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm);
+	{
+		EventTimer et(ix.st);
+		seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm);
+		KernelStat &ks = ix.tm.kern[K_SEED];         // query minimizers probe the table, anchors written, read and written by the sort
+		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
+	}
 	double t1 = now_s();
 	ChainResult CR;
 	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st, &ix.tm);
@@ -215,6 +231,7 @@ extern "C" void mm_mapopt_update(mm_mapopt_t *opt, const mm_idx_t *mi) // option
 {
 	PgaIdx *ix = reinterpret_cast<PgaIdx*>(const_cast<mm_idx_t*>(mi));
 	if (opt->mid_occ <= 0) {
+		ArenaScope arena_scope(ix->arena);
 		try { opt->mid_occ = group_mid_occ(*ix, *opt)[0]; }
 		catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_mapopt_update: %s\n", e.what()); return; }
 	}
@@ -248,34 +265,55 @@ static mm_reg1_t *regs_to_c(const std::vector<Reg> &regs, int *n_regs)
 	return out;
 }
 
+// cheap identity check of a query against the indexed sequence of the same name (64 probes)
+static bool seqs_same_bases(const SeqSet &S, int qid, const char *seq, int l_seq)
+{
+	const uint8_t *h = S.h_nt4.data() + S.off[qid];
+	for (int i = 0; i < l_seq; i += (l_seq > 64 ? l_seq / 64 : 1)) {
+		const char c = seq[i] & 0xdf; uint8_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
+		if ((uint8_t)seq[i] < 0x40) code = 4;
+		if (code != h[i]) return false;
+	}
+	return true;
+}
+
 static bool same_opt(const mm_mapopt_t &a, const mm_mapopt_t &b) { return memcmp(&a, &b, offsetof(mm_mapopt_t, split_prefix)) == 0; }
+
+// The minimap2 ABI has no error channel: NULL with *n_regs = 0 means "no alignments", and the unchanged Rust crate would build
+// an unmerged graph from it.  So a failure of the batch (device out of memory, an option check_supported rejects, a query that is
+// not one of the indexed sequences) is fatal: the message goes to stderr and the process aborts -- unless PGA_MM_MAP_SOFT_ERRORS=1,
+// in which case mm_map returns NULL and pga_last_error() holds the message (tests).  The failure is recorded on the index, so the N
+// rayon callers do not re-run a failing batch N times.
+static mm_reg1_t *mm_map_fail(PgaIdx *ix, const std::string &msg, int *n_regs)
+{
+	set_err(msg);
+	fprintf(stderr, "[pga] mm_map: %s\n", msg.c_str());
+	const char *soft = getenv("PGA_MM_MAP_SOFT_ERRORS");
+	if (!(soft && soft[0] == '1')) { fprintf(stderr, "[pga] mm_map cannot report errors through the minimap2 ABI: aborting (PGA_MM_MAP_SOFT_ERRORS=1 returns NULL instead)\n"); abort(); }
+	(void)ix; *n_regs = 0; return 0;
+}
 
 extern "C" mm_reg1_t *mm_map(const mm_idx_t *mi, int l_seq, const char *seq, int *n_regs, mm_tbuf_t *b, const mm_mapopt_t *opt, const char *name) // map.c:376-381
 {
 	(void)b;
 	*n_regs = 0;
 	PgaIdx *ix = reinterpret_cast<PgaIdx*>(const_cast<mm_idx_t*>(mi));
+	if (l_seq == 0) return 0;
 	try {
-		if (l_seq == 0) return 0;
 		auto it = name ? ix->by_name.find(name) : ix->by_name.end();
 		if (it == ix->by_name.end() || (int)ix->S.len[it->second] != l_seq)
 			throw std::runtime_error(std::string("pga: mm_map() query '") + (name ? name : "(null)") + "' is not one of the indexed sequences; this backend aligns a group all-vs-all "
 			                         "(what pangraph's find_matches does); mapping foreign queries is not implemented");
 		const int qid = it->second;
-		{   // cheap identity check of the bases
-			const uint8_t *h = ix->S.h_nt4.data() + ix->S.off[qid];
-			static const char tbl[] = "ACGT";
-			for (int i = 0; i < l_seq; i += (l_seq > 64 ? l_seq / 64 : 1)) {
-				char c = seq[i] & 0xdf; uint8_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
-				if ((uint8_t)seq[i] < 0x40) code = 4;
-				if (code != h[i]) throw std::runtime_error("pga: mm_map() query bases differ from the indexed sequence of the same name");
-			}
-			(void)tbl;
-		}
+		if (!seqs_same_bases(ix->S, qid, seq, l_seq)) throw std::runtime_error("pga: mm_map() query bases differ from the indexed sequence of the same name");
 		std::lock_guard<std::mutex> lk(ix->mtx);
-		if (!ix->have_results || !same_opt(ix->res_opt, *opt)) run_batch(*ix, *opt, 0);
+		if (!ix->failure.empty()) return mm_map_fail(ix, ix->failure, n_regs);
+		if (!ix->have_results || !same_opt(ix->res_opt, *opt)) {
+			try { run_batch(*ix, *opt, 0); }
+			catch (std::exception &e) { ix->failure = e.what(); if (ix->failure.empty()) ix->failure = "unknown error"; return mm_map_fail(ix, ix->failure, n_regs); }
+		}
 		return regs_to_c(ix->results[qid], n_regs);
-	} catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_map: %s\n", e.what()); *n_regs = 0; return 0; }
+	} catch (std::exception &e) { return mm_map_fail(ix, e.what(), n_regs); }
 }
 
 extern "C" double mm_event_identity(const mm_reg1_t *r) // align.c:897-917
@@ -316,7 +354,7 @@ static void collect_results(PgaIdx &ixr, int g0, const std::vector<int64_t> &gof
 	R.st.upload += t.upload, R.st.sketch += t.sketch, R.st.index += t.index, R.st.seed += t.seed, R.st.chain += t.chain, R.st.align += t.align;
 	R.st.n_bases += (double)ix->S.total, R.st.n_minimizers += t.n_mz, R.st.n_anchors += t.n_anchor, R.st.n_dp_jobs += t.dp_jobs, R.st.n_dp_cells += t.dp_cells;
 	R.st.n_dp_bases += t.dp_bases;
-	for (int i = 0; i < K_COUNT; ++i) R.st.kern_ms[i] += t.kern[i].ms, R.st.kern_launches[i] += t.kern[i].launches, R.st.kern_alg_bytes[i] += t.kern[i].alg_bytes;
+	for (int i = 0; i < K_COUNT; ++i) R.st.kern_ms[i] += t.kern[i].ms, R.st.kern_launches[i] += t.kern[i].launches, R.st.kern_alg_bytes[i] += t.kern[i].alg_bytes, R.st.kern_cells[i] += t.kern[i].cells;
 }
 
 static void params_to_opts(const pga_params_t &p, mm_idxopt_t &io, mm_mapopt_t &mo) // align_with_minimap2_lib.rs:35-57 + options_args.rs:273-325
@@ -428,8 +466,8 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 		auto work = [&](int p) {
 			try {
 				PGA_HIP(hipSetDevice(dev));
-				dev_set_arena(p + 1);
 				PgaIdx &ix = *B->parts[p];
+				ArenaScope arena_scope(ix.arena);
 				if (!ix.indexed || ix.hdr.w != io.w || ix.hdr.k != io.k) {
 					ix.hdr.w = io.w, ix.hdr.k = io.k, ix.hdr.b = 14 < 2 * io.k ? 14 : 2 * io.k;
 					ix.mid_occ_frac = -1.0f; ix.have_results = false;
@@ -440,7 +478,6 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 				if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
 				run_batch(ix, mo, threads_each);
 			} catch (std::exception &e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "unknown error"; }
-			dev_set_arena(0);
 		};
 		if (n_parts == 1) work(0);
 		else {
@@ -548,6 +585,24 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 			all.insert(all.end(), cg.begin() + R.cigar_off, cg.begin() + R.cigar_off + R.n_cigar);
 		}
 		*cigars = dup_out(all);
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy)
+{
+	try {
+		require_device();
+		if (n_seg <= 0) return 0;
+		const uint64_t n = seg_off[n_seg];
+		std::vector<int64_t> len((size_t)n_seg); std::vector<uint32_t> flag((size_t)n_seg, 1u);
+		for (int s = 0; s < n_seg; ++s) len[s] = (int64_t)(seg_off[s + 1] - seg_off[s]);
+		DBuf<u128> a; a.upload(reinterpret_cast<const u128*>(xy), (size_t)n, 0);
+		DBuf<uint64_t> off; off.upload(seg_off, (size_t)n_seg + 1, 0);
+		DBuf<int64_t> dl; dl.upload(len, 0);
+		DBuf<uint32_t> df; df.upload(flag, 0);
+		replay_sort_segments(a.p, n, off.p, dl.p, n_seg, df.p, 0);
+		if (n) { PGA_HIP(hipMemcpyAsync(xy, a.p, n * sizeof(u128), hipMemcpyDeviceToHost, 0)); PGA_HIP(hipStreamSynchronize(0)); }
 		return 0;
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }

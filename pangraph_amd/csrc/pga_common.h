@@ -26,6 +26,12 @@ void dev_free(void *p);
 void dev_trim();        // release every idle block
 void dev_set_arena(int arena);
 int dev_get_arena();   // calling thread: recycle device blocks only within this arena (one per concurrent sub-batch)
+int dev_lease_arena();                // a globally unique arena id until dev_release_arena(): one worker (one stream) at a time
+void dev_release_arena(int arena);    // call after the worker's stream has been synchronised
+struct ArenaScope {                   // the calling thread allocates in `arena` while the scope lives
+	int prev; explicit ArenaScope(int arena) : prev(dev_get_arena()) { dev_set_arena(arena); } ~ArenaScope() { dev_set_arena(prev); }
+	ArenaScope(const ArenaScope&) = delete; ArenaScope &operator=(const ArenaScope&) = delete;
+};
 
 // ---- device buffer ----
 template <class T> struct DBuf {
@@ -116,8 +122,9 @@ struct Index {
 };
 
 // device kernels timed with HIP events (order is part of pga_stats_t, include/pga_align.h)
-enum { K_SKETCH = 0, K_CHAIN = 1, K_BACKTRACK = 2, K_EXTD2 = 3, K_EXTD2_WIDE = 4, K_LL = 5, K_SORT = 6, K_BAND = 7, K_COUNT = 10 };
-struct KernelStat { double ms = 0, launches = 0, alg_bytes = 0; };
+enum { K_SKETCH = 0, K_CHAIN = 1, K_BACKTRACK = 2, K_EXTD2 = 3, K_EXTD2_WIDE = 4 /* <256> */, K_LL = 5, K_SORT = 6, K_BAND = 7, K_WIDE512 = 8, K_WIDE1024 = 9,
+       K_INDEX = 10 /* index build: device sorts + CSR kernels */, K_SEED = 11 /* seeding kernels + anchor sort */, K_COUNT = 16 };
+struct KernelStat { double ms = 0, launches = 0, alg_bytes = 0, cells = 0; };   // cells: DP cells the kernel's loops evaluated
 struct Timers {
 	double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0, dp_bases = 0, dp_cigar_ops = 0;
 	KernelStat kern[K_COUNT];   // device time of the path's own kernels, measured with HIP events on the launch stream

@@ -17,6 +17,7 @@
 // Persistent launch: a fixed grid of waves pulls problems from an atomic queue (problem sizes are ragged).
 #include "pga_common.h"
 #include "pga_dp.h"
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -394,6 +395,36 @@ template <class F> static void host_parallel(size_t n, F f)
 
 static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band);
 
+// Launch lanes: four priority streams (lane 0, the million-tile classes, at the lower priority) and four grow-only scratch slabs per SET.
+// Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
+// the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
+// used on the set's streams); a set returns to the pool with its streams drained.
+struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };
+static std::mutex g_lane_mu;
+static std::vector<LaneSet*> g_lane_idle;
+struct LaneLease {
+	LaneSet *set = nullptr;
+	explicit LaneLease(int dev)
+	{
+		{
+			std::lock_guard<std::mutex> lk(g_lane_mu);
+			for (size_t i = 0; i < g_lane_idle.size(); ++i) if (g_lane_idle[i]->dev == dev) { set = g_lane_idle[i]; g_lane_idle.erase(g_lane_idle.begin() + (long)i); break; }
+		}
+		if (set) return;
+		set = new LaneSet(); set->dev = dev; set->arena = dev_lease_arena();
+		int prio_lo = 0, prio_hi = 0;
+		PGA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // numerically lower = higher priority
+		for (int l = 0; l < 4; ++l) PGA_HIP(hipStreamCreateWithPriority(&set->stream[l], hipStreamNonBlocking, l == 0 ? prio_lo : prio_hi));
+	}
+	~LaneLease()
+	{
+		for (int l = 0; l < 4; ++l) (void)hipStreamSynchronize(set->stream[l]);
+		std::lock_guard<std::mutex> lk(g_lane_mu);
+		g_lane_idle.push_back(set);
+	}
+	LaneLease(const LaneLease&) = delete; LaneLease &operator=(const LaneLease&) = delete;
+};
+
 void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
 	dp_run_impl(d_nt4, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr);
@@ -470,11 +501,11 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static thread_local hipStream_t lane_stream_dev[16][4] = {};   // per host thread: concurrent query sets do not queue behind each other
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
-	hipStream_t *lane_stream = lane_stream_dev[dev_id & 15];
-	struct Launch { int c; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
+	LaneLease lanes(dev_id);                                // four streams + four scratch slabs of this device, exclusive for the call: concurrent query sets do not queue behind each other
+	hipStream_t *lane_stream = lanes.set->stream;
+	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
 	size_t budget = (size_t)64 << 30;                       // per class; the four lane slabs together stay well inside HBM
@@ -498,8 +529,8 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		waves_of[c] = n_waves;
 		lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], n_waves * slab_max[c]);
 	}
-	static thread_local DBuf<uint8_t> lane_slab[4];
-	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) { PGA_HIP(hipDeviceSynchronize()); lane_slab[l].alloc(lane_need[l]); }
+	DBuf<uint8_t> *lane_slab = lanes.set->slab;
+	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) { ArenaScope own(lanes.set->arena); lane_slab[l].alloc(lane_need[l]); }   // (the set is idle: its last user drained the streams)
 	// every class is prepared and launched in turn, the classes with few, long problems first: they are already running
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
@@ -524,15 +555,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
-		hipStream_t &ls = lane_stream[serial ? 0 : lane_of_class[c]];
-		static std::mutex lane_mu;
-		std::lock_guard<std::mutex> lane_lk(lane_mu);
-		if (!ls) {
-			int prio_lo = 0, prio_hi = 0;
-			PGA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // numerically lower = higher priority
-			PGA_HIP(hipStreamCreateWithPriority(&ls, hipStreamNonBlocking, lane_of_class[c] == 0 ? prio_lo : prio_hi));
-		}
-		hipStream_t cs = ls;
+		hipStream_t cs = lane_stream[serial ? 0 : lane_of_class[c]];
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
 		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
@@ -559,6 +582,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			if (c == 4 || c == 7 || ids.size() <= 512) nt = r_cap >= 3000 ? 1024 : r_cap >= 1200 ? 512 : 256;
 			if (getenv("PGA_WIDE_NT")) nt = atoi(getenv("PGA_WIDE_NT"));
 			else if (c == 3) nt = 512;
+			X.nt = nt;
 			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
@@ -574,15 +598,43 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		float msf = 0, ms_off = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1)); (void)hipEventElapsedTime(&ms_off, ready, X.e0);
 		const double ms = msf;
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
-		if (tm) {
-			double bases = 0; for (uint32_t id : ids) bases += (double)jobs[id].qlen + jobs[id].tlen;
-			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below
-			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c <= 1 ? K_EXTD2 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7)
-			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->dp_bases += bases;
-		}
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
 		download_to(r, X.d_r.p, ids.size(), lane_stream[getenv("PGA_DP_SERIAL") ? 0 : lane_of_class[c]]);
+		if (tm) {
+			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below.
+			// cells: what the kernel's loops evaluated -- the corridor kernel 32 columns on every diagonal, the register tiles the whole
+			// matrix (none when the identity proof answers), the workgroup kernel the band on the diagonals it ran (DpRes.pad = diagonals
+			// done: z-drop ends an extension early), the local-alignment kernel the padded matrix
+			std::vector<double> part_b((size_t)thread_budget() + 1, 0.0), part_c((size_t)thread_budget() + 1, 0.0);
+			std::atomic<int> slot(0);
+			host_parallel(ids.size(), [&](size_t lo, size_t hi) {
+				double bases = 0, cells = 0;
+				for (size_t i = lo; i < hi; ++i) {
+					const DpJob &j = jobs[ids[i]];
+					bases += (double)j.qlen + j.tlen;
+					if (c == 8) cells += 32.0 * (double)(j.qlen + j.tlen - 1);
+					else if (c == 6) cells += (double)((j.qlen + 7) / 8 * 8) * j.tlen;
+					else if (c <= 1) cells += r[i].pad == 0x5A ? 0.0 : (double)j.qlen * j.tlen;
+					else {
+						const int nd = r[i].pad > 0 ? r[i].pad : j.qlen + j.tlen - 1, w = j.w < 0 ? (j.qlen > j.tlen ? j.qlen : j.tlen) : j.w;
+						for (int d = 0; d < nd; ++d) {     // ksw2_extd2_sse.c:173-181
+							int st = 0, en = j.tlen - 1;
+							if (st < d - j.qlen + 1) st = d - j.qlen + 1;
+							if (en > d) en = d;
+							if (st < (d - w + 1) >> 1) st = (d - w + 1) >> 1;
+							if (en > (d + w) >> 1) en = (d + w) >> 1;
+							if (en >= st) cells += (double)(en - st + 1);
+						}
+					}
+				}
+				const int s = slot.fetch_add(1) % (int)part_b.size();
+				part_b[(size_t)s] += bases; part_c[(size_t)s] += cells;
+			});
+			double bases = 0, cells = 0; for (double x : part_b) bases += x; for (double x : part_c) cells += x;
+			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
+			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->kern[kk].cells += cells; tm->dp_bases += bases;
+		}
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
 		if (((c >= 2 && c <= 4) || c == 7) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;

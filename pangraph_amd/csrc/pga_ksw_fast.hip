@@ -116,7 +116,7 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					if (base + 1 <= pool_cap) cigar_pool[base] = (uint32_t)tlen << 4;
 					DpRes R;
 					R.max = 0, R.max_q = -1, R.max_t = -1, R.mqe = KSW_NEG_INF, R.mqe_t = -1, R.mte = KSW_NEG_INF, R.mte_q = -1;
-					R.score = sc_mch * (tlen - m_tot) + sc_mis * m_tot, R.zdropped = 0, R.reach_end = 0, R.n_cigar = 1, R.pad = 0, R.cigar_off = base;
+					R.score = sc_mch * (tlen - m_tot) + sc_mis * m_tot, R.zdropped = 0, R.reach_end = 0, R.n_cigar = 1, R.pad = 0x5A /* answered without the matrix */, R.cigar_off = base;
 					res[jid] = R;
 				}
 				continue;

@@ -44,6 +44,24 @@ size_t cache_limit()
 void dev_set_arena(int arena) { t_arena = arena; }
 int dev_get_arena() { return t_arena; }
 
+// Arena ids are LEASED: an id belongs to one worker (one stream) at a time, and it goes back to the free list only after that
+// worker has synchronised its stream (ArenaLease's owner does), so whoever leases it next may reuse its idle blocks on any
+// stream.  Ids are recycled, so the number of pools is bounded by the peak number of concurrent workers.  Arena 0 is the
+// default of threads that never leased one (stage taps, single-threaded tests): not safe for concurrent use on several streams.
+namespace { std::vector<int> g_arena_free; int g_arena_next = 1; }
+int dev_lease_arena()
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_arena_free.empty()) { const int a = g_arena_free.back(); g_arena_free.pop_back(); return a; }
+	return g_arena_next++;
+}
+void dev_release_arena(int arena)
+{
+	if (arena <= 0) return;
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_arena_free.push_back(arena);
+}
+
 void *dev_alloc(size_t bytes)
 {
 	int dev = 0;

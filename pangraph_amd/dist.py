@@ -1,16 +1,28 @@
-"""Multi-GPU plumbing for the one exchange step of the path: the final match-list gather.
+"""Multi-GPU plumbing for the one exchange step of the path: the match-list gather.
 
-Queries are independent given their group, so a level's groups are sharded across ranks with no data-path
-collective; each rank then owns a variable-length byte blob (packed pga_match_t records + CIGAR pool) and rank 0
-collects them: an all_gather of the blob sizes followed by one send per rank to the owner.  With the `nccl`
-backend this is RCCL over xGMI (point-to-point sends to the owning rank; the CIGAR pool dominates the payload).  The same code runs on CPU tensors under `gloo` (tests/test_dist_cpu.py, world_size 2).
+Queries are independent given their group, so the groups of a wave (one tree level, one self-merge round) are sharded across
+ranks with no data-path collective -- balanced by their base counts (`shard_groups_balanced`) -- and each rank ends up with a
+variable-length list of packed `pga_match_t` records plus a CIGAR pool.  Rank 0 (the owner of the graph) collects them:
+an all_gather of the two blob sizes, then one point-to-point send per rank to the owner (`gather_blobs`; with the `nccl`
+backend this is RCCL over xGMI; the CIGAR pool dominates the payload and nobody but the owner needs it).  `gather_matches`
+puts the pieces together: group ids become global again and CIGAR offsets point into the concatenated pool, records ordered by
+(group, query, the aligner's own order inside a query) -- the order a single rank would have produced.
+The same code runs on CPU tensors under `gloo` (tests/test_dist_cpu.py, world_size 2).
 """
 from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
+
+# include/pga_align.h: pga_match_t (88 bytes)
+MATCH_DTYPE = np.dtype([("group", "<i4"), ("qry", "<i4"), ("ref", "<i4"), ("qry_len", "<i4"), ("qry_start", "<i4"), ("qry_end", "<i4"),
+                        ("ref_len", "<i4"), ("ref_start", "<i4"), ("ref_end", "<i4"), ("matches", "<i4"), ("length", "<i4"), ("quality", "<i4"),
+                        ("reverse", "<i4"), ("align", "<i4"), ("n_ambi", "<i4"), ("inv", "<i4"), ("divergence", "<f8"), ("cigar_off", "<u8"),
+                        ("n_cigar", "<u4"), ("pad", "<u4")])
+assert MATCH_DTYPE.itemsize == 88
 
 
 def shard_groups(n_groups: int, rank: int, world: int) -> List[int]:
@@ -20,11 +32,25 @@ def shard_groups(n_groups: int, rank: int, world: int) -> List[int]:
     return list(range(lo, hi))
 
 
+def shard_groups_balanced(weights: Sequence[float], world: int) -> List[List[int]]:
+    """Groups dealt to `world` ranks, heaviest first, each to the currently lightest rank (LPT); every rank's list is in
+    ascending group order.  Deterministic, so every rank computes the same plan without talking."""
+    order = sorted(range(len(weights)), key=lambda g: (-weights[g], g))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for g in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        out[r].append(g)
+        load[r] += weights[g]
+    for v in out:
+        v.sort()
+    return out
+
+
 def gather_blobs(blob, device: torch.device, dst: int = 0, as_bytes: bool = True):
     """Variable-length gather of one byte blob per rank (bytes, or a uint8 numpy array / torch tensor, which is not copied on
     the host); returns the list on `dst` (bytes, or host uint8 tensors with as_bytes=False), None elsewhere.
-    Sizes travel by all_gather; the payload goes point to point to `dst` only -- a level's CIGAR pool is hundreds of MB per
-    rank, and nobody but the owner of the graph needs it."""
+    Sizes travel by all_gather; the payload goes point to point to `dst` only."""
     world = dist.get_world_size()
     rank = dist.get_rank()
     if isinstance(blob, (bytes, bytearray)):
@@ -54,6 +80,39 @@ def gather_blobs(blob, device: torch.device, dst: int = 0, as_bytes: bool = True
     if as_bytes:
         return [bytes(o.cpu().numpy().tobytes()) for o in outs]
     return outs
+
+
+def merge_match_lists(parts_m: Sequence[np.ndarray], parts_c: Sequence[np.ndarray], local_to_global: Sequence[Sequence[int]]):
+    """parts_m[r]: the pga_match_t records of rank r (uint8 or structured), parts_c[r]: its CIGAR pool (uint8 or uint32),
+    local_to_global[r][g]: the global index of rank r's local group g.  Returns (records, cigar pool) of the whole wave as one
+    rank would have produced them."""
+    recs, pools, base = [], [], 0
+    for m, c, l2g in zip(parts_m, parts_c, local_to_global):
+        m = np.asarray(m)
+        m = m.view(MATCH_DTYPE).copy() if m.dtype != MATCH_DTYPE else m.copy()
+        c = np.asarray(c)
+        c = c.view(np.uint32) if c.dtype != np.uint32 else c
+        if len(m):
+            m["group"] = np.asarray(l2g, dtype=np.int32)[m["group"]]
+            m["cigar_off"] += np.uint64(base)
+        recs.append(m)
+        pools.append(c)
+        base += len(c)
+    rec = np.concatenate(recs) if recs else np.zeros(0, MATCH_DTYPE)
+    pool = np.concatenate(pools) if pools else np.zeros(0, np.uint32)
+    # a rank's records are already in (group, query, own order) order: a stable sort by group restores the global order
+    rec = rec[np.argsort(rec["group"], kind="stable")]
+    return rec, pool
+
+
+def gather_matches(raw_matches, raw_cigars, my_groups: Sequence[int], plan: Sequence[Sequence[int]], device: torch.device, dst: int = 0):
+    """The exchange step of a wave.  Every rank passes its packed records / CIGAR pool (uint8 views of the native result) and the
+    sharding plan; `dst` gets (records, pool) with global group ids, the others None."""
+    pm = gather_blobs(raw_matches, device, dst=dst, as_bytes=False)
+    pc = gather_blobs(raw_cigars, device, dst=dst, as_bytes=False)
+    if pm is None:
+        return None
+    return merge_match_lists([t.numpy() for t in pm], [t.numpy() for t in pc], plan)
 
 
 def max_over_ranks(x: float, device: torch.device) -> float:

@@ -75,3 +75,18 @@ def evolve_population(seed: int, n: int, length: int, snp: float = 0.005, indel:
             g = np.concatenate([g[p:], g[:p]])
         out.append(g.tobytes().decode())
     return out
+
+
+def sibling_pairs(seed: int, n_genomes: int, length: int, div: float):
+    """n_genomes/2 independent sibling pairs at `div` pairwise divergence with 2 inversions, 6 insertions and 4 deletions each
+    (the round-1 leaf-level workload: far more divergent than sibling leaves of a 1000-genome tree, hence DP-heavy).
+    Returns (groups of two byte strings, decimal names)."""
+    groups, names = [], []
+    for g in range(n_genomes // 2):
+        rng = np.random.default_rng(seed * 1000003 + g)
+        anc = random_seq(rng, length)
+        ev = max(2000, min(50000, length // 40))
+        kids = [mutate(rng, anc, snp=div / 2, indel=div / 20, n_inv=2, n_ins=6, n_del=4, max_event=ev) for _ in range(2)]
+        groups.append([k.tobytes() for k in kids])
+        names.append([str(2 * g), str(2 * g + 1)])
+    return groups, names

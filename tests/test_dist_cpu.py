@@ -53,3 +53,82 @@ def test_shard_groups_covers_everything():
             assert allg == list(range(n))
             sizes = [len(shard_groups(n, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- the match-list exchange proper: records of a sharded wave == records of one rank ----
+def _fake_wave(n_groups, seed=3):
+    """per group a list of (record fields, cigar ops) as one rank would emit them"""
+    import numpy as np
+    from pangraph_amd.dist import MATCH_DTYPE
+    rng = np.random.default_rng(seed)
+    out = []
+    for g in range(n_groups):
+        recs = []
+        for q in range(int(rng.integers(0, 4))):
+            for _ in range(int(rng.integers(0, 3))):
+                recs.append((q, int(rng.integers(0, 9)), rng.integers(1, 1000, size=int(rng.integers(1, 6))).astype(np.uint32)))
+        out.append(recs)
+    return out
+
+
+def _pack(groups, ids):
+    """packed pga_match_t[] + CIGAR pool of the groups `ids` (local group index = position in ids)"""
+    import numpy as np
+    from pangraph_amd.dist import MATCH_DTYPE
+    m, pool = [], []
+    off = 0
+    for lg, g in enumerate(ids):
+        for q, r, cg in groups[g]:
+            rec = np.zeros(1, MATCH_DTYPE)
+            rec["group"], rec["qry"], rec["ref"], rec["cigar_off"], rec["n_cigar"], rec["matches"] = lg, q, r, off, len(cg), 1000 * g + q
+            m.append(rec); pool.append(cg); off += len(cg)
+    return (np.concatenate(m) if m else np.zeros(0, MATCH_DTYPE)), (np.concatenate(pool) if pool else np.zeros(0, np.uint32))
+
+
+def _gather_worker(rank, world, port, q):
+    import numpy as np
+    from pangraph_amd.dist import gather_matches, shard_groups_balanced
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = _fake_wave(11)
+    weights = [1 + sum(len(c) for _, _, c in g) for g in groups]
+    plan = shard_groups_balanced(weights, world)
+    m, c = _pack(groups, plan[rank])
+    got = gather_matches(m.view(np.uint8), c.view(np.uint8), plan[rank], plan, torch.device("cpu"), dst=0)
+    if rank == 0:
+        rec, pool = got
+        want_m, want_c = _pack(groups, list(range(len(groups))))
+        ok = len(rec) == len(want_m)
+        for a, b in zip(rec, want_m):
+            ok &= all(a[f] == b[f] for f in ("group", "qry", "ref", "n_cigar", "matches"))
+            ok &= (pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] == want_c[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["n_cigar"])]).all()
+        q.put(bool(ok) and len(rec) > 5)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_wave_gather_equals_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    assert q.get(timeout=120) is True
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+
+def test_shard_groups_balanced():
+    from pangraph_amd.dist import shard_groups_balanced
+    w = [10, 1, 1, 1, 9, 2, 2, 8, 3, 3]
+    for world in (1, 2, 3, 8):
+        plan = shard_groups_balanced(w, world)
+        assert sorted(g for p in plan for g in p) == list(range(len(w)))
+        assert all(p == sorted(p) for p in plan)
+        loads = [sum(w[g] for g in p) for p in plan]
+        assert max(loads) <= sum(w) / world + max(w)

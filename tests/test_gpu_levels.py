@@ -1,0 +1,152 @@
+"""Parity of the HIP path on the block sets of UPPER guide-tree levels and on the occurrence-driven seeding paths
+(SURVEY.md section 8c fixtures (3), (4); configs C2, C3):
+real block sets of finished builds (the reference's own test data), the sc2-like one-group population, groups whose
+minimizers occur more often than mid_occ / max_max_occ, and every wave (both self-merge rounds of every merge of every tree
+height) of a simulated build -- against golden digests generated from the reference build (tests/golden/make_golden_levels.py)
+and, where oracle/_ref travels with the snapshot, against the reference run live on the box.  Also the run-length sort replay
+through its own stage tap and concurrent mm_map from 16 threads.  Bit-exact."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from levels_util import ref_align_groups, product_align_groups, digest, high_occ_groups
+from pangraph_amd.levels import Population, Rates, c2_population
+from util import load_golden, read_fasta, rows_to_lists, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def exp():
+    return load_golden("levels_expected.json.gz")
+
+
+def test_plasmid_block_set_real_ids(gpu_lib, exp):
+    names, seqs = read_fasta(os.path.join(GOLDEN, "plasmids_blocks.fa.gz"))
+    assert len(names) == 137
+    assert rows_to_lists(gpu_lib.align_all(seqs, names, sensitivity=10)) == exp["plasmids_blocks"]["asm10"]
+    for sens in (5, 20):
+        rows = rows_to_lists(gpu_lib.align_all(seqs, names, sensitivity=sens))
+        assert (len(rows), digest(rows)) == (exp["plasmids_blocks"][f"asm{sens}"]["n"], exp["plasmids_blocks"][f"asm{sens}"]["sha256"])
+
+
+def test_staph_block_set(gpu_lib, exp):
+    names, seqs = read_fasta(os.path.join(GOLDEN, "staph_blocks.fa.gz"))
+    rows = product_align_groups([seqs], [names], sensitivity=10)[0]
+    assert (len(rows), digest(rows)) == (exp["staph_blocks"]["n"], exp["staph_blocks"]["sha256"])
+
+
+def test_russian_doll_plasmids(gpu_lib, exp):
+    names, seqs = read_fasta(os.path.join(GOLDEN, "russian_doll_plasmids.fa.gz"))
+    for sens in (10, 20):
+        assert rows_to_lists(gpu_lib.align_all(seqs, names, sensitivity=sens)) == exp["russian_doll"][f"asm{sens}"]
+
+
+def test_c2_sc2_like_group(gpu_lib, exp):
+    seqs, names = c2_population()
+    rows = product_align_groups([seqs], [names], sensitivity=10)[0]
+    assert len(rows) == exp["c2"]["n"]
+    assert digest(rows) == exp["c2"]["sha256"]
+
+
+def test_high_occurrence_groups(gpu_lib, exp):
+    groups, names = high_occ_groups()
+    got = product_align_groups(groups, names, sensitivity=10)
+    assert [dict(n=len(r), sha256=digest(r)) for r in got] == exp["high_occ"]
+
+
+def test_c3_small_every_wave(gpu_lib, exp):
+    p = exp["c3_small"]["params"]
+    pop = Population(p["seed"], p["n"], p["length"], Rates(**p["rates"]))
+    waves = pop.build_waves()
+    assert len(waves) == len(exp["c3_small"]["waves"])
+    for (label, groups, names), e in zip(waves, exp["c3_small"]["waves"]):
+        assert [len(g) for g in groups] == e["n_blocks"], label
+        got = product_align_groups(groups, names, sensitivity=10)
+        assert [dict(n=len(r), sha256=digest(r)) for r in got] == e["groups"], label
+
+
+def test_c3_full_size_every_wave_vs_reference(gpu_lib, ref_lib):
+    """config C3: 10 genomes x 5 Mbp, the whole build, every wave against the reference run here"""
+    pop = Population(2, 10, 5_000_000)
+    for label, groups, names in pop.build_waves():
+        got = product_align_groups(groups, names, sensitivity=10)
+        want = ref_align_groups(groups, names, sensitivity=10)
+        for g, (a, b) in enumerate(zip(got, want)):
+            assert a == b, (label, g, len(a), len(b))
+
+
+def test_sort_replay_tap_adversarial(gpu_lib, ref_lib):
+    """the run-length walk and the token walk of the sort replay (pga_sort_wave.h) against radix_sort_128x itself"""
+    dll = gpu_lib.dll
+    dll.pga_stage_sort.restype = C.c_int
+    dll.pga_stage_sort.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    arrays = []
+
+    def add(x):
+        arrays.append(np.asarray(x, dtype=np.uint64))
+
+    for n in (1, 2, 63, 64, 65, 66, 1023, 1024, 1025, 4097, 70000, 400000):
+        add(rng.integers(0, 5, size=n))                                          # few keys: long digit runs after the first level
+        add(rng.integers(0, 1 << 40, size=n))                                    # (almost) distinct
+        add(np.arange(n)[::-1] // 3)                                             # descending with ties
+        add(np.roll(np.arange(n) // 7, n // 3))                                  # rotated ascending
+        add((np.arange(n) // 50) << 16)                                          # ascending runs of 50 at byte level 2
+        add(((np.arange(n)[::-1] // 300) << 16) | (rng.integers(0, 3, size=n)))  # descending runs + low-byte ties
+        add(np.repeat(rng.integers(0, 1 << 32, size=max(1, n // 17)), 17)[:n])   # runs of 17 equal keys
+        add(np.where(rng.random(n) < 0.02, rng.integers(0, 1 << 24, size=n), (np.arange(n) // 9) << 8))   # nearly sorted, 2 % foreign
+        add(np.zeros(n))                                                         # one key
+        add((rng.integers(0, 2, size=n) << 63) | (np.arange(n) // 40 << 8))      # two strands, each ascending
+    seg_off = np.zeros(len(arrays) + 1, dtype=np.uint64)
+    seg_off[1:] = np.cumsum([len(a) for a in arrays])
+    xy = np.zeros((int(seg_off[-1]), 2), dtype=np.uint64)
+    xy[:, 0] = np.concatenate(arrays)
+    xy[:, 1] = np.arange(len(xy), dtype=np.uint64)
+    want = xy.copy()
+    for s in range(len(arrays)):
+        b, e = int(seg_off[s]), int(seg_off[s + 1])
+        ref_lib.dll.radix_sort_128x(C.c_void_p(want.ctypes.data + 16 * b), C.c_void_p(want.ctypes.data + 16 * e))
+    assert dll.pga_stage_sort(len(arrays), seg_off.ctypes.data, xy.ctypes.data) == 0
+    for s in range(len(arrays)):
+        b, e = int(seg_off[s]), int(seg_off[s + 1])
+        assert (xy[b:e] == want[b:e]).all(), (s, e - b)
+
+
+def test_concurrent_mm_map_16_threads(gpu_lib, ref_lib):
+    """what rayon does (align_with_minimap2_lib.rs:64-74): one index, mm_map from many threads, one mm_tbuf_t each"""
+    from pangraph_amd.synth import evolve_population
+    seqs = evolve_population(23, 48, 20000, snp=0.01, indel=0.001, n_inv=1, n_ins=1, n_del=1, max_event=3000)
+    names = [str(1000 + 7919 * i) for i in range(len(seqs))]
+    want = ref_lib.align_all(seqs, names, sensitivity=10)
+    by_q = {}
+    for r in want:
+        by_q.setdefault(r.qname, []).append(r.key())
+    io, mo = gpu_lib.make_options("asm10", s=90)
+    idx = gpu_lib.index(seqs, names, io, mo)
+    out, errs = {}, []
+
+    def work(t):
+        try:
+            from pangraph_amd.mm2ffi import Mm2Index
+            mine = Mm2Index(gpu_lib, idx.ptr, idx.io, idx.mo, None)      # own mm_tbuf_t on the shared index
+            for q in range(t, len(seqs), 16):
+                out[names[q]] = [r.key() for r in mine.map(seqs[q], names[q])]
+            gpu_lib.dll.mm_tbuf_destroy(mine._tbuf)
+            mine.ptr = None
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    idx.close()
+    assert not errs, errs
+    assert len(out) == len(seqs)
+    for nm in names:
+        assert out[nm] == by_q.get(nm, []), nm

@@ -63,3 +63,29 @@ def test_stage_ksw(oracle_lib):
             keys += ["max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q"]
         for k in keys:
             assert got[k] == exp[k], (k, v["preset"], v["w"], v["flag"], len(v["q"]), len(v["t"]))
+
+
+# ---- block sets of upper tree levels (tests/golden/make_golden_levels.py) ----
+def test_real_block_sets(oracle_lib):
+    """the reference's own finished builds: 137 plasmid blocks with their real decimal BlockIds, the russian-doll plasmids"""
+    exp = load_golden("levels_expected.json.gz")
+    names, seqs = read_fasta(os.path.join(GOLDEN, "plasmids_blocks.fa.gz"))
+    assert len(names) == 137 and all(n.isdigit() for n in names)
+    assert rows_to_lists(oracle_lib.align_all(seqs, names, sensitivity=10)) == exp["plasmids_blocks"]["asm10"]
+    names, seqs = read_fasta(os.path.join(GOLDEN, "russian_doll_plasmids.fa.gz"))
+    for sens in (10, 20):
+        assert rows_to_lists(oracle_lib.align_all(seqs, names, sensitivity=sens)) == exp["russian_doll"][f"asm{sens}"]
+
+
+def test_c3_small_upper_waves(oracle_lib):
+    """every wave above the leaf merges of the simulated 10-genome build (the leaf wave is left to the GPU suite: 15 s here)"""
+    from levels_util import digest
+    from pangraph_amd.levels import Population, Rates
+    exp = load_golden("levels_expected.json.gz")["c3_small"]
+    p = exp["params"]
+    waves = Population(p["seed"], p["n"], p["length"], Rates(**p["rates"])).build_waves()
+    assert len(waves) == len(exp["waves"])
+    for (label, groups, names), e in list(zip(waves, exp["waves"]))[1:]:
+        assert [len(g) for g in groups] == e["n_blocks"], label
+        got = [rows_to_lists(oracle_lib.align_all([a.tobytes().decode() for a in g], n, sensitivity=10)) for g, n in zip(groups, names)]
+        assert [dict(n=len(r), sha256=digest(r)) for r in got] == e["groups"], label
