@@ -10,6 +10,7 @@
 #include "pga_pipeline.h"
 #include "pga_dp.h"
 #include "../../include/pga_align.h"
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <thread>
@@ -20,6 +21,13 @@ using namespace pga;
 
 static thread_local std::string g_err;
 static void set_err(const std::string &s) { g_err = s; }
+static void mem_log(const char *what)
+{
+	static const bool on = getenv("PGA_MEMLOG") != nullptr;
+	if (!on) return;
+	size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
+	fprintf(stderr, "[pga-mem] %-28s used %.1f GB of %.1f\n", what, (double)(tot - fr) / 1e9, (double)tot / 1e9);
+}
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---------------------------------------------------------------- options (options.c)
@@ -126,6 +134,7 @@ static void idx_sketch_index(PgaIdx &ix)
 		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 48.0 * (double)ix.M.n;
 	}
 	double t3 = now_s();
+	mem_log("after sketch+index");
 	ix.tm.sketch = t2 - t1, ix.tm.index = t3 - t2; ix.tm.n_mz = (double)ix.M.n;
 	ix.indexed = true;
 }
@@ -199,13 +208,16 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
 	}
 	double t1 = now_s();
+	mem_log("after seed");
 	ChainResult CR;
 	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st, &ix.tm);
 	double t2 = now_s();
+	mem_log("after chain");
 	if (n_threads <= 0) { n_threads = usable_cpus(); }
 	set_thread_budget(n_threads);
 	align_batch(ix.S, opt, ix.I.k, SR.h_q_aoff, CR, SR.h_rep_len, ix.results, n_threads, &ix.tm, ix.st);
 	double t3 = now_s();
+	mem_log("after align");
 	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;
 	ix.have_results = true; ix.res_opt = opt;
 	if (getenv("PGA_VERBOSE"))
@@ -423,7 +435,9 @@ extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, cons
 		uint64_t max_bases = getenv("PGA_MAX_BATCH_BASES") ? strtoull(getenv("PGA_MAX_BATCH_BASES"), 0, 10) : 3000000000ULL;
 		{
 			uint64_t total = 0; for (int64_t i = 0; i < group_off[n_groups]; ++i) total += seq_lens[i];
-			const int want = getenv("PGA_PARTS") ? atoi(getenv("PGA_PARTS")) : 1;
+			int want = getenv("PGA_PARTS") ? atoi(getenv("PGA_PARTS")) : 1;
+			const int need = (int)((total + max_bases - 1) / max_bases);      // parts of EQUAL size (3.5 Gbp -> 1.75 + 1.75, not 3.0 + 0.5)
+			if (need > want) want = need;
 			if (want > 1 && n_groups >= want && total >= 200000000ULL) max_bases = std::min<uint64_t>(max_bases, (total + want - 1) / want + 1);
 		}
 		int g0 = 0;
@@ -460,7 +474,7 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 		double t_all = now_s();
 		const int n_parts = (int)B->parts.size();
 		int threads_each = params->n_threads > 0 ? params->n_threads : usable_cpus();
-		threads_each = std::max(1, threads_each / std::max(1, n_parts));
+		threads_each = std::max(1, threads_each / std::max(1, std::min(n_parts, 2)));
 		std::vector<std::string> errs((size_t)n_parts);
 		int dev = 0; PGA_HIP(hipGetDevice(&dev));
 		auto work = [&](int p) {
@@ -477,12 +491,19 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 				mm_mapopt_t mo = mo0;
 				if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;
 				run_batch(ix, mo, threads_each);
+				// minimizers and index are rebuilt by every call: give their memory back before the next part starts
+				ix.M.mz.release(); ix.I.key.release(); ix.I.occ_off.release(); ix.I.occ.release(); ix.I.key_grp.release(); ix.grp.release(); ix.indexed = false;
 			} catch (std::exception &e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "unknown error"; }
 		};
 		if (n_parts == 1) work(0);
 		else {
+			// at most two parts at a time: their dependency-bound phases overlap, and the device memory of two parts (resident
+			// arrays + DP scratch) stays bounded whatever the number of parts
+			std::atomic<int> next(0);
+			auto runner = [&] { for (;;) { const int p = next.fetch_add(1); if (p >= n_parts) break; work(p); } };
 			std::vector<std::thread> th;
-			for (int p = 0; p < n_parts; ++p) th.emplace_back(work, p);
+			const int conc = std::min(n_parts, getenv("PGA_PART_CONCURRENCY") ? std::max(1, atoi(getenv("PGA_PART_CONCURRENCY"))) : 2);
+			for (int t = 0; t < conc; ++t) th.emplace_back(runner);
 			for (auto &t : th) t.join();
 		}
 		for (int p = 0; p < n_parts; ++p) if (!errs[p].empty()) throw std::runtime_error(errs[p]);

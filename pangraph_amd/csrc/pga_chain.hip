@@ -233,8 +233,8 @@ struct Iter { int32_t stack[CMAXD]; int top; };
 // passes the bandwidth test, so "marked" is a set-membership stamp; the n_skip walk itself stays sequential.
 // ring capacity (anchors: live window + the staged block) is a template parameter; 2048 covers the ~800-anchor windows of
 // max_gap = 10 kb with room to spare (1024 was tried: too many segments outgrow it and have to be swept twice)
-#define CF_WI 512          // inner-window ring capacity
-#define CF_MAXIN 256       // inner candidates handled by the fast path
+#define CF_WI 1024         // inner-window ring capacity: the most inner candidates the fast path takes (repeats crowd the window)
+#define CF_MAXIN 256       // inner candidates handled from registers; more than that go through the chunked form of the same scan
 
 // lchain.c:232-248 on unpacked fields (segment-local: x is the 32-bit target position)
 __device__ __forceinline__ int32_t score_pair32(int32_t xi, int32_t yi, int32_t xj, int32_t yj, int32_t span_j, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)
@@ -275,8 +275,8 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 	__shared__ int32_t r_f[CF_W];
 	__shared__ uint8_t s_sp[CF_W];
 	__shared__ int32_t r_p[CF_WI], r_t[CF_WI];
-	__shared__ int32_t s_sc[CF_MAXIN], s_j[CF_MAXIN];
-	__shared__ uint8_t s_fl[CF_MAXIN];
+	__shared__ int32_t s_sc[CF_WI], s_j[CF_WI];
+	__shared__ uint8_t s_fl[CF_WI];
 	const int lane = threadIdx.x;
 	const uint32_t sidx = blockIdx.x;
 	if (sidx >= n_seg) return;
@@ -295,7 +295,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
 	for (int k = lane; k < CF_WI; k += 64) r_t[k] = -1;
 	int32_t st = 0, st_in = 0, i0 = 0;
-	bool bail = false;
+	bool bail = false; int why = 0;   // why: 1 ring overflow, 2 tree-size cap, 3 tied minimum, 4 too many inner candidates
 	double sm_pri = 1e300; int32_t sm_arg = -1, sm_blk = -1, sm_ymin = 0, sm_ymax = 0;   // lane b: summary of ring block b
 	// Shortcut for the co-linear stretch: when the anchor just before i is a candidate (its x differs, it is inside the x and y
 	// ranges) and its priority is STRICTLY below that of every anchor inserted before it (p_floor: a running minimum, refreshed
@@ -338,7 +338,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			fs_floor = wave_max_i32((lane < CF_W / 64 && sm_blk >= 0 && sm_blk + 64 > st) ? sm_fs : FS_NONE);
 		}
 		// the ring must hold [st, blk+128)
-		if (blk + 128 - st > CF_W) { bail = true; break; }
+		if (blk + 128 - st > CF_W) { bail = true; why = 1; break; }
 		const int32_t blk_end = blk + 64 < n ? blk + 64 : n;
 		for (int32_t i = blk; i < blk_end; ++i) {
 			const int il = i - blk;
@@ -436,7 +436,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 					}
 				} else for (int32_t tj = S > st ? S : st; tj < i0; tj += 64) scan64(tj, i0);
 			}
-			if (i0 - st > P.cap) { bail = true; break; }             // size cap of the tree (lchain.c:304): not handled here
+			if (i0 - st > P.cap) { bail = true; why = 2; break; }             // size cap of the tree (lchain.c:304): not handled here
 			k1 = CF_CLK();
 			{
 				// the wave minimum of a double, as two 32-bit DPP reductions over its order-preserving integer image
@@ -449,7 +449,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 				const unsigned long long who = __ballot(best_j >= 0 && is_min);
 				if (who == 0) best_j = -1;
 				else {
-					if (__popcll(who) > 1 || __ballot(tie && is_min)) { bail = true; break; }
+					if (__popcll(who) > 1 || __ballot(tie && is_min)) { bail = true; why = 3; break; }
 					best_j = __builtin_amdgcn_readlane(best_j, __ffsll((long long)who) - 1);
 				}
 			}
@@ -486,7 +486,84 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 				if (!exact && max_dist_inner > 0 && st_in < i0 && yi > 0) {
 					// lchain.c:322-349: candidates of the inner window with y in [y_i - inner, y_i - 1], visited by descending (y, j)
 					const int32_t n_in = i0 - st_in;
-					if (n_in > CF_MAXIN) { bail = true; break; }
+					if (n_in > CF_WI) { bail = true; why = 4; break; }
+					if (n_in > CF_MAXIN) {
+						// ---- crowded inner window (repeats): the same scan, 64 candidates at a time from LDS ----
+						++n_inner; n_incand += n_in;
+						auto cand = [&](int32_t jc, int32_t &sc, bool &ok) -> bool {    // candidate jc: inside the y range? its score, inside the band?
+							const CfEnt ec = r_e[jc & CF_M];
+							if (!(ec.y <= yi - 1 && ec.y >= yi - max_dist_inner)) { sc = 0; ok = false; return false; }
+							int32_t wdt;
+							sc = r_f[jc & CF_M] + score_pair32(xi, yi, ec.x, ec.y, s_sp[jc & CF_M], P.pen_gap, P.pen_skip, nullptr, &wdt);
+							ok = wdt <= P.bw;
+							return true;
+						};
+						bool unsorted = false;
+						for (int32_t c0 = 0; c0 < n_in; c0 += 64) {           // stamps: a candidate inside the band marks its predecessor
+							const int32_t jc = i0 - 1 - (c0 + lane);
+							if (jc >= st_in) {
+								if (jc + 1 < i0 && r_e[(jc + 1) & CF_M].y < r_e[jc & CF_M].y) unsorted = true;
+								int32_t sc; bool ok;
+								if (cand(jc, sc, ok) && ok) { const int32_t pj = r_p[jc & (CF_WI - 1)]; if (pj >= st_in) r_t[pj & (CF_WI - 1)] = i; }
+							}
+						}
+						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+						const bool uns = __ballot(unsorted) != 0;
+						int32_t n_slots = n_in;
+						if (uns) {
+							// rank the valid candidates by descending (y, j) (all-pairs count) and lay them out in scan order
+							++n_slow;
+							n_slots = 0;
+							for (int32_t c0 = 0; c0 < n_in; c0 += 64) {
+								const int32_t jc = i0 - 1 - (c0 + lane);
+								int32_t sc = 0; bool ok = false;
+								const bool val = jc >= st_in && cand(jc, sc, ok);
+								n_slots += __popcll(__ballot(val));
+								if (val) {
+									const int32_t yc = r_e[jc & CF_M].y;
+									int32_t rank = 0;
+									for (int32_t jo = st_in; jo < i0; ++jo) {
+										const int32_t yo = r_e[jo & CF_M].y;
+										const bool vo = yo <= yi - 1 && yo >= yi - max_dist_inner;
+										rank += (vo && (yo > yc || (yo == yc && jo > jc))) ? 1 : 0;
+									}
+									s_sc[rank] = sc; s_j[rank] = jc;
+									s_fl[rank] = (uint8_t)((ok ? 1 : 0) | (r_t[jc & (CF_WI - 1)] == i ? 2 : 0));
+								}
+							}
+							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+						}
+						int32_t n_skip = 0; bool stop = false;
+						for (int32_t c0 = 0; c0 < n_slots && !stop; c0 += 64) {
+							int32_t v_sc = 0, v_j = -1; bool v_ok = false, v_mk = false;
+							if (uns) {
+								const int32_t c = c0 + lane;
+								if (c < n_slots) { const int32_t fl = s_fl[c]; v_ok = fl & 1; v_mk = (fl & 2) != 0; v_sc = s_sc[c]; v_j = s_j[c]; }
+							} else {
+								const int32_t jc = i0 - 1 - (c0 + lane);
+								if (jc >= st_in) { v_j = jc; const bool val = cand(jc, v_sc, v_ok); v_mk = val && r_t[jc & (CF_WI - 1)] == i; }
+							}
+							const int32_t v = v_ok ? v_sc : INT32_MIN;
+							const int32_t incl = wave_prefix_max_incl(v);
+							int32_t excl = __builtin_amdgcn_update_dpp(max_f, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps the running maximum
+							if (excl < max_f) excl = max_f;
+							const bool is_max = v_ok && v_sc > excl;
+							const unsigned long long mx = __ballot(is_max), inc = __ballot(v_ok && !is_max && v_mk);
+							unsigned long long rest = mx; int last = -1, pos = 0;
+							for (;;) {
+								const int c = rest ? __ffsll((long long)rest) - 1 : 64;
+								const unsigned long long range = (c >= 64 ? ~0ULL : ((1ULL << c) - 1)) & ~((1ULL << pos) - 1);
+								n_skip += __popcll(inc & range);
+								if (n_skip > P.max_skip) { stop = true; break; }
+								if (c >= 64) break;
+								rest &= rest - 1;
+								last = c; if (n_skip > 0) --n_skip;
+								pos = c + 1;
+								if (pos >= 64) break;
+							}
+							if (last >= 0) { max_f = __builtin_amdgcn_readlane(v_sc, last); max_j = __builtin_amdgcn_readlane(v_j, last); }
+						}
+					} else {
 					++n_inner; n_incand += n_in;
 					// lane l of group k looks at candidate jc = i0-1-(l+64k): if y does not decrease with the index anywhere in the
 					// window (the co-linear case), descending (y, j) IS descending index, i.e. ascending (k, l)
@@ -568,6 +645,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 						}
 						if (last >= 0) { max_f = __builtin_amdgcn_readlane(c_sc[k], last); max_j = __builtin_amdgcn_readlane(c_j[k], last); }
 					}
+					}
 				}
 			}
 			const long long k4 = CF_CLK();
@@ -597,7 +675,7 @@ void k_chain_fast(const u128 *__restrict__ a, const uint64_t *__restrict__ seg_s
 			}
 		}
 	}
-	if (lane == 0) seg_flag[sg] = bail ? 1u : 0u;
+	if (lane == 0) seg_flag[sg] = bail ? (uint32_t)(why ? why : 1) : 0u;
 	if (PROF && prof && lane == 0) {
 		const unsigned long long dt = wall_clock64() - c0;
 		atomicAdd(&prof[0], dt); atomicMax(&prof[1], dt); atomicMax(&prof[2], (unsigned long long)n);
@@ -955,8 +1033,9 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		PGA_HIP(hipGetLastError());
 		const double ms = et.stop();
 		if (getenv("PGA_VERBOSE") && use_fast) {
-			std::vector<uint32_t> fl = seg_flag.download(st); size_t nf = 0; for (uint32_t v : fl) nf += v;
-			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel, %.3f ms (fast kernel %.3f ms)\n", n_seg, nf, ms, ms_fast);
+			std::vector<uint32_t> fl = seg_flag.download(st); size_t nf = 0, why[5] = {0, 0, 0, 0, 0}; for (uint32_t v : fl) { nf += v != 0; ++why[v < 5 ? v : 1]; }
+			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel (ring overflow %zu, size cap %zu, tied minimum %zu, inner candidates %zu), %.3f ms (fast kernel %.3f ms)\n", n_seg, nf, why[1], why[2], why[3], why[4], ms, ms_fast);
+			if (nf) { std::vector<uint64_t> ss = seg_start.download(st); for (uint32_t s = 0; s < n_seg; ++s) if (fl[s]) fprintf(stderr, "[pga]     segment %u: %llu anchors, reason %u\n", s, (unsigned long long)((s + 1 < n_seg ? ss[s + 1] : n_a) - ss[s]), fl[s]); }
 			std::vector<unsigned long long> pr = cprof.download(st);
 			if (prof_on) fprintf(stderr, "[pga]   chain fast: longest segment %llu anchors, slowest %.2f ms, sum %.1f ms; scan iterations %.2f/anchor, inner scans %.3f/anchor with %.1f candidates, %llu unsorted\n",
 			        pr[2], pr[1] * 1e-5, pr[0] * 1e-5, (double)pr[3] / (double)n_a, (double)pr[4] / (double)n_a, pr[4] ? (double)pr[5] / (double)pr[4] : 0.0, pr[6]);

@@ -399,7 +399,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
 // the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
 // used on the set's streams); a set returns to the pool with its streams drained.
-struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };
+struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };   // slabs live for one call: they go back to the block cache (same arena, so the next call of this set gets them again; the cache may also drop them)
 static std::mutex g_lane_mu;
 static std::vector<LaneSet*> g_lane_idle;
 struct LaneLease {
@@ -419,6 +419,7 @@ struct LaneLease {
 	~LaneLease()
 	{
 		for (int l = 0; l < 4; ++l) (void)hipStreamSynchronize(set->stream[l]);
+		for (int l = 0; l < 4; ++l) set->slab[l].release();
 		std::lock_guard<std::mutex> lk(g_lane_mu);
 		g_lane_idle.push_back(set);
 	}
@@ -508,8 +509,10 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
-	size_t budget = (size_t)64 << 30;                       // per class; the four lane slabs together stay well inside HBM
-	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 5 < budget) budget = tot / 5; }
+	// scratch budget per class: a slab is n_waves x the largest problem of the class, and n_waves is halved until it fits.  24 GB keeps
+	// ~100 concurrent 10 kb x 10 kb direction matrices; concurrent parts and query sets each hold a lane set, so four of them stay inside HBM
+	size_t budget = (size_t)(getenv("PGA_SLAB_GB") ? atof(getenv("PGA_SLAB_GB")) : 24.0) << 30;
+	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 8 < budget) budget = tot / 8; }
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_begin = now();

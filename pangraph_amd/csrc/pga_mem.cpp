@@ -3,7 +3,7 @@
 // A batch allocates a few dozen device arrays per stage and the DP stage a scratch slab of tens of GB; hipMalloc and
 // hipFree cost from 0.1 ms to tens of ms each and hipFree synchronises the device, so freed blocks are kept in
 // per-device, size-rounded free lists and handed out again (a level of `pangraph build` repeats the same sizes call
-// after call).  The cache is bounded: beyond PGA_CACHE_GB (default 200) of idle blocks the largest are released.
+// after call).  The cache is bounded: beyond PGA_CACHE_GB (default 96) of idle blocks the largest idle blocks (of any pool) are released.
 #include "pga_common.h"
 #include <map>
 #include <mutex>
@@ -33,7 +33,7 @@ size_t round_size(size_t b)
 }
 size_t cache_limit()
 {
-	static size_t lim = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 200.0; return (size_t)(g * (double)(1ull << 30)); }();
+	static size_t lim = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 96.0; return (size_t)(g * (double)(1ull << 30)); }();
 	return lim;
 }
 }
@@ -83,6 +83,7 @@ void *dev_alloc(size_t bytes)
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
 		dev_trim();                                   // give the idle blocks back and retry once
+		(void)hipDeviceSynchronize();
 		e = hipMalloc(&p, r);
 		if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " allocating " + std::to_string(r) + " bytes of device memory");
 	}
@@ -104,10 +105,13 @@ void dev_free(void *p)
 			g_live.erase(it);
 			Pool &P = g_pools[{lv.dev, lv.arena}];
 			P.idle.emplace(lv.size, p); P.idle_bytes += lv.size; g_idle_total += lv.size;
-			// over the limit: release the largest idle blocks of this pool (they are the DP slabs)
-			while (g_idle_total > cache_limit() && !P.idle.empty()) {
-				auto big = std::prev(P.idle.end());
-				drop.push_back(big->second); P.idle_bytes -= big->first; g_idle_total -= big->first; P.idle.erase(big);
+			// over the limit: release the largest idle blocks, whichever pool holds them (they are the DP slabs of past calls)
+			while (g_idle_total > cache_limit()) {
+				Pool *best = nullptr;
+				for (auto &kv : g_pools) if (!kv.second.idle.empty() && (!best || std::prev(kv.second.idle.end())->first > std::prev(best->idle.end())->first)) best = &kv.second;
+				if (!best) break;
+				auto big = std::prev(best->idle.end());
+				drop.push_back(big->second); best->idle_bytes -= big->first; g_idle_total -= big->first; best->idle.erase(big);
 			}
 		}
 	}

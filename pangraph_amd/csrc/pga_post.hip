@@ -1,0 +1,330 @@
+// pga_post.hip -- everything of the base-level alignment stage that READS BASES outside the DP kernels, as batched device kernels:
+// the host driver (pga_align.cpp) keeps control flow over compact records and never touches a base.
+//
+//   k_seg_identity   first-pass gap fills whose windows are equally long: mismatch count with early exit, deciding whether the main
+//                    diagonal is provably the unique optimum (proof: pga_ksw_fast.hip) -- replaces the per-segment DP call
+//                    mm_align_pair (align.c:316-344) for two thirds of the segments (nearly all of them between close relatives)
+//   k_zdrop_walk     mm_test_zdrop's walk along a CIGAR (align.c:32-45,47-77): the worst score drop and its window
+//   k_cigar_finish   mm_fix_cigar + mm_update_extra (align.c:91-167,240-289) of a finished region: one WAVE per region; CIGAR
+//                    operations are consumed in order, the bases under an operation 64 at a time across the lanes
+//
+// Numerics of k_cigar_finish: the reference accumulates s (double) base by base with a clamp at 0 and tracks its maximum.  Inside a
+// match run the increments are integers and every partial sum is an integer plus the fractional bits of earlier gap terms
+// (e * mg_log2: a float times an int) -- far inside a double's mantissa for any sequence length, so double addition is EXACT here and
+// the 64-base block form below (prefix sums and prefix minima in int32, s_i = P_i - min(-s_in, min_j<=i P_j)) returns bit-identical
+// values to the stepwise loop.  Gap terms are evaluated exactly as the reference writes them (float mg_log2, double product, no FMA).
+#include "pga_common.h"
+#include "pga_post.h"
+#include "pga_wave.h"
+
+namespace pga {
+
+__device__ __forceinline__ int post_tbase(const uint8_t *__restrict__ nt4, uint64_t t_off, int i) { return nt4[t_off + (uint64_t)i]; }
+// base j of the aligned query strand, window starting at q_start on that strand (reverse strand = complement read backwards, align.c:970-975)
+__device__ __forceinline__ int post_qbase(const uint8_t *__restrict__ nt4, uint64_t q_off, int qlen_full, int q_start, int q_rev, int j)
+{
+	const int pj = q_start + j;
+	if (!q_rev) return nt4[q_off + (uint64_t)pj];
+	const int c = nt4[q_off + (uint64_t)(qlen_full - 1 - pj)];
+	return c < 4 ? 3 - c : 4;
+}
+
+// ------------------------------------------------------------------------------------------------ identity probes
+__global__ __launch_bounds__(256)
+void k_seg_identity(const PostProbe *__restrict__ pr, uint32_t n, const uint8_t *__restrict__ nt4, int m_max, int32_t *__restrict__ out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const PostProbe P = pr[i];
+	int m = 0;
+	const uint8_t *t = nt4 + P.t_off;
+	if (!P.q_rev) {
+		const uint8_t *q = nt4 + P.q_off + (uint64_t)P.qs;
+		for (int k = 0; k < P.n; ++k) {
+			const int x = t[k], y = q[k];
+			if ((x | y) > 3) { m = -1; break; }
+			if (x != y && ++m > m_max) { m = -1; break; }
+		}
+	} else {
+		const uint8_t *q = nt4 + P.q_off + (uint64_t)(P.qlen_full - 1 - P.qs);
+		for (int k = 0; k < P.n; ++k) {
+			const int x = t[k], y = q[-k];
+			if ((x | y) > 3) { m = -1; break; }
+			if (x != 3 - y && ++m > m_max) { m = -1; break; }
+		}
+	}
+	out[i] = m;
+}
+
+void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_max, PinVec<int32_t> &out, hipStream_t st)
+{
+	const size_t n = probes.size();
+	out.resize(n);
+	if (!n) return;
+	DBuf<PostProbe> d; d.alloc(n);
+	DBuf<int32_t> r; r.alloc(n);
+	PGA_HIP(hipMemcpyAsync(d.p, probes.data(), n * sizeof(PostProbe), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d.p, (uint32_t)n, d_nt4, m_max, r.p);
+	PGA_HIP(hipGetLastError());
+	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	PGA_HIP(hipStreamSynchronize(st));
+}
+
+// ------------------------------------------------------------------------------------------------ z-drop walk
+// One thread per request.  Scores: match run positions add mat[t][q]; a gap of any kind subtracts q + e*len (align.c:64-72); after
+// every step the tracker compares with the best prefix so far, discounting the diagonal offset at e per base (align.c:32-45).
+__global__ __launch_bounds__(64)
+void k_zdrop_walk(const PostWalk *__restrict__ rq, uint32_t n, const uint32_t *__restrict__ cig, const uint8_t *__restrict__ nt4,
+                  int sc_mch, int sc_mis, int sc_ambi, int gap_q, int gap_e, PostWalkRes *__restrict__ out)
+{
+	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= n) return;
+	const PostWalk W = rq[id];
+	const uint32_t *cg = cig + W.cig_off;
+	int score = 0, best = INT32_MIN, best_i = -1, best_j = -1, ti = 0, qj = 0, worst = 0;
+	int w_t0 = -1, w_t1 = -1, w_q0 = -1, w_q1 = -1;
+	auto track = [&](int ci, int cj) {
+		if (score < best) {
+			const int li = ci - best_i, lj = cj - best_j, off = li > lj ? li - lj : lj - li, z = best - score - off * gap_e;
+			if (z > worst) { worst = z; w_t0 = best_i, w_t1 = ci, w_q0 = best_j, w_q1 = cj; }
+		} else best = score, best_i = ci, best_j = cj;
+	};
+	for (uint32_t k = 0; k < W.n_cigar; ++k) {
+		const uint32_t op = cg[k] & 0xf; const int len = (int)(cg[k] >> 4);
+		if (op == 0) {
+			for (int l = 0; l < len; ++l) {
+				const int tb = post_tbase(nt4, W.t_off, ti + l), qb = post_qbase(nt4, W.q_off, W.qlen_full, W.qs, W.q_rev, qj + l);
+				score += (tb > 3 || qb > 3) ? sc_ambi : tb == qb ? sc_mch : sc_mis;
+				track(ti + l, qj + l);
+			}
+			ti += len, qj += len;
+		} else if (op == 1 || op == 2 || op == 3) {
+			score -= gap_q + gap_e * len;
+			if (op == 1) qj += len; else ti += len;
+			track(ti, qj);
+		}
+	}
+	PostWalkRes R; R.max_zdrop = worst; R.t0 = w_t0, R.t1 = w_t1, R.q0 = w_q0, R.q1 = w_q1;
+	out[id] = R;
+}
+
+void post_zdrop_walk(const uint8_t *d_nt4, const std::vector<PostWalk> &reqs, const std::vector<uint32_t> &cig, const DpParams &P, std::vector<PostWalkRes> &out, hipStream_t st)
+{
+	const size_t n = reqs.size();
+	out.resize(n);
+	if (!n) return;
+	DBuf<PostWalk> d; d.upload(reqs, st);
+	DBuf<uint32_t> c; c.upload(cig.data(), cig.size() ? cig.size() : 1, st);
+	DBuf<PostWalkRes> r; r.alloc(n);
+	hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_nt4, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
+	PGA_HIP(hipGetLastError());
+	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostWalkRes), hipMemcpyDeviceToHost, st));
+	PGA_HIP(hipStreamSynchronize(st));
+}
+
+// ------------------------------------------------------------------------------------------------ CIGAR finish
+__device__ __forceinline__ float post_log2(float x) // mmpriv.h:118-126
+{
+	union { float f; uint32_t i; } z = { x };
+	float r = (float)(((z.i >> 23) & 255) - 128);   // unsigned arithmetic as in the reference (x >= 2 here: gaps are at least one base long)
+	z.i &= ~(255u << 23);
+	z.i += 127u << 23;
+	r += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
+	return r;
+}
+
+__device__ __forceinline__ int32_t wave_prefix_min_incl(int32_t v)
+{
+	v = dpp_min_step_i<0x111, 0xf>(v); v = dpp_min_step_i<0x112, 0xf>(v); v = dpp_min_step_i<0x114, 0xf>(v); v = dpp_min_step_i<0x118, 0xf>(v);
+	v = dpp_min_step_i<0x142, 0xa>(v); v = dpp_min_step_i<0x143, 0xc>(v);
+	return v;
+}
+
+#define FIN_LDS_OPS 6144     // regions with up to this many operations are edited in LDS (24 KB), longer ones in place in HBM
+
+// One wave per region.  Stage 1 (mm_fix_cigar): indels between two match runs slide left as far as the bases allow (the lanes test
+// 64 positions at a time), mixed I/D stretches are merged, empty operations dropped, a leading indel is cut off and reported as a
+// shift of the region start.  Stage 2 (mm_update_extra): blen / mlen / n_ambi and the clamped running score.
+__global__ __launch_bounds__(64)
+void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__restrict__ cig_all, const uint8_t *__restrict__ nt4,
+                    int sc_mch, int sc_mis, int sc_ambi, int gap_q, int gap_e, PostFinRes *__restrict__ out)
+{
+	__shared__ uint32_t s_ops[FIN_LDS_OPS];
+	const int lane = threadIdx.x;
+	for (uint32_t id = blockIdx.x; id < n; id += gridDim.x) {
+		const PostFin F = rq[id];
+		uint32_t *g_ops = cig_all + F.cig_off;
+		uint32_t nc = F.n_cigar;
+		const bool in_lds = nc <= FIN_LDS_OPS;
+		uint32_t *cg = in_lds ? s_ops : g_ops;
+		if (in_lds) { for (uint32_t k = lane; k < nc; k += 64) s_ops[k] = g_ops[k]; }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		int qshift = 0, tshift = 0;
+		if (nc > 1) {
+			// ---- left-alignment of indels (align.c:100-117) ----
+			int toff = 0, qoff = 0; bool squeeze = false;
+			for (uint32_t k = 0; k < nc; ++k) {
+				const uint32_t c = cg[k], op = c & 0xf; const int len = (int)(c >> 4);
+				if (len == 0) squeeze = true;
+				if (op == 0) toff += len, qoff += len;
+				else if (op == 1 || op == 2) {
+					if (k > 0 && k + 1 < nc && (cg[k - 1] & 0xf) == 0 && (cg[k + 1] & 0xf) == 0) {
+						const int room = (int)(cg[k - 1] >> 4), o = op == 1 ? qoff : toff;
+						int slid = 0;
+						for (int b = 0; b < room; b += 64) {
+							const int l = b + lane;
+							bool same = false;
+							if (l < room) {
+								const int x = op == 1 ? post_qbase(nt4, F.q_off, F.qlen_full, F.q_start, F.q_rev, o - 1 - l) : post_tbase(nt4, F.t_off, o - 1 - l);
+								const int y = op == 1 ? post_qbase(nt4, F.q_off, F.qlen_full, F.q_start, F.q_rev, o + len - 1 - l) : post_tbase(nt4, F.t_off, o + len - 1 - l);
+								same = x == y;
+							}
+							const unsigned long long eq = __ballot(same);
+							const int run = eq == ~0ULL ? 64 : __builtin_ctzll(~eq);
+							slid += run;
+							if (run < 64) break;
+						}
+						if (slid > room) slid = room;
+						if (slid > 0) {
+							if (lane == 0) { cg[k - 1] -= (uint32_t)slid << 4; cg[k + 1] += (uint32_t)slid << 4; }
+							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+							qoff -= slid, toff -= slid;
+						}
+						if (slid == room) squeeze = true;
+					}
+					if (op == 1) qoff += len; else toff += len;
+				} else if (op == 3) toff += len;
+			}
+			// ---- the remaining passes edit the operation list only: lane 0 ----
+			if (lane == 0) {
+				// mixed insertion/deletion stretches become one I and one D (align.c:118-133)
+				for (uint32_t k = 0; k + 2 < nc; ++k) {
+					const uint32_t a = cg[k] & 0xf;
+					if (a > 0 && a + (cg[k + 1] & 0xf) == 3) {
+						uint32_t sum_i = 0, sum_d = 0, e = k;
+						for (; e < nc; ++e) {
+							const uint32_t op = cg[e] & 0xf, ln = cg[e] >> 4;
+							if (op == 1) sum_i += ln; else if (op == 2) sum_d += ln; else if (ln != 0) break;
+						}
+						if (sum_i > 0 && sum_d > 0 && e - k > 2) {
+							cg[k] = sum_i << 4 | 1; cg[k + 1] = sum_d << 4 | 2;
+							for (uint32_t z = k + 2; z < e; ++z) cg[z] &= 0xf;
+							squeeze = true;
+						}
+						k = e;
+					}
+				}
+				if (squeeze) {                          // drop empty operations, then fuse neighbours of one kind (align.c:134-146)
+					uint32_t w = 0;
+					for (uint32_t k = 0; k < nc; ++k) if (cg[k] >> 4) cg[w++] = cg[k];
+					nc = w; w = 0;
+					for (uint32_t k = 0; k < nc; ++k) {
+						if (k + 1 == nc || (cg[k] & 0xf) != (cg[k + 1] & 0xf)) cg[w++] = cg[k];
+						else cg[k + 1] += cg[k] >> 4 << 4;
+					}
+					nc = w;
+				}
+			}
+			nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)nc);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		uint32_t first = 0;                             // a leading indel leaves the record (align.c:147-166; lists of one operation are left alone, :96)
+		if (F.n_cigar > 1 && nc > 0 && ((cg[0] & 0xf) == 1 || (cg[0] & 0xf) == 2)) {
+			if ((cg[0] & 0xf) == 1) qshift = (int)(cg[0] >> 4); else tshift = (int)(cg[0] >> 4);
+			first = 1;
+		}
+		// ---- blen / mlen / n_ambi / dp_max over the final list (align.c:249-285) ----
+		const int q0 = F.q_start + qshift; const uint64_t t0 = F.t_off + (uint64_t)tshift;
+		int toff = 0, qoff = 0, blen = 0, mlen = 0, n_ambi = 0, n_gapo = 0, n_gap = 0;
+		double s = 0.0, smax = 0.0;
+		for (uint32_t k = first; k < nc; ++k) {
+			const uint32_t c = cg[k], op = c & 0xf; const int len = (int)(c >> 4);
+			if (op == 0) {
+				int ambi = 0, diff = 0;
+				for (int b = 0; b < len; b += 64) {
+					const int l = b + lane; const bool on = l < len;
+					int x = 0; bool is_ambi = false, is_diff = false;
+					if (on) {
+						const int tb = post_tbase(nt4, t0, toff + l), qb = post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l);
+						is_ambi = tb > 3 || qb > 3; is_diff = !is_ambi && tb != qb;
+						x = is_ambi ? sc_ambi : is_diff ? sc_mis : sc_mch;
+					}
+					const unsigned long long m_ambi = __ballot(is_ambi), m_diff = __ballot(is_diff);
+					ambi += __popcll(m_ambi), diff += __popcll(m_diff);
+					const int cnt = len - b < 64 ? len - b : 64;
+					if ((m_ambi | m_diff) == 0 && sc_mch > 0) {     // all matches: s only grows
+						s += (double)sc_mch * (double)cnt; smax = smax > s ? smax : s;
+					} else {
+						const int P = (int)wave_prefix_sum_incl((uint32_t)x);           // lanes beyond the run add 0: their P repeats the last value
+						const int Pm = wave_prefix_min_incl(P);
+						const double neg_in = -s, pm = (double)Pm;
+						const double floor_ = neg_in < pm ? neg_in : pm;
+						const double si = (double)P - floor_;
+						// maximum of s over the block's valid positions
+						double cand = on ? si : 0.0;
+						const double mx = -wave_min_f64_key(-cand);
+						smax = smax > mx ? smax : mx;
+						const long long bits = __double_as_longlong(si);
+						const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+						s = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);   // lane 63 carries P of the last valid base, and its prefix minimum
+					}
+				}
+				blen += len - ambi, mlen += len - (ambi + diff), n_ambi += ambi;
+				toff += len, qoff += len;
+			} else if (op == 1 || op == 2) {
+				int ambi = 0;
+				for (int b = 0; b < len; b += 64) {
+					const int l = b + lane;
+					const bool a = l < len && (op == 1 ? post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l) : post_tbase(nt4, t0, toff + l)) > 3;
+					ambi += __popcll(__ballot(a));
+				}
+				blen += len - ambi, n_ambi += ambi; ++n_gapo, n_gap += len;
+				s -= (double)gap_q + (double)gap_e * (double)post_log2((float)(1.0 + (double)len));
+				if (s < 0) s = 0;
+				if (op == 1) qoff += len; else toff += len;
+			} else if (op == 3) toff += len;
+		}
+		if (in_lds) { for (uint32_t k = first + lane; k < nc; k += 64) g_ops[k - first] = s_ops[k]; }
+		else if (first) {                               // in place in HBM: close the gap left by the leading indel
+			for (uint32_t b = first; b < nc; b += 64) {
+				const uint32_t k = b + lane; const uint32_t v = k < nc ? g_ops[k] : 0;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				if (k < nc) g_ops[k - first] = v;
+			}
+		}
+		if (lane == 0) {
+			PostFinRes R; R.n_cigar = nc - first; R.qshift = qshift; R.tshift = tshift; R.blen = blen; R.mlen = mlen; R.n_ambi = n_ambi;
+			R.dp_max = (int32_t)(smax + .499); R.n_gapo = n_gapo; R.n_gap = n_gap; R.q_span = qoff; R.t_span = toff;
+			out[id] = R;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+
+void post_cigar_finish(const uint8_t *d_nt4, const std::vector<PostFin> &reqs, PinVec<uint32_t> &cig, const DpParams &P, std::vector<PostFinRes> &out, hipStream_t st)
+{
+	const size_t n = reqs.size();
+	out.resize(n);
+	if (!n) return;
+	DBuf<PostFin> d; d.upload(reqs, st);
+	DBuf<uint32_t> c; c.alloc(cig.size() ? cig.size() : 1);
+	if (cig.size()) PGA_HIP(hipMemcpyAsync(c.p, cig.data(), cig.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	DBuf<PostFinRes> r; r.alloc(n);
+	const unsigned grid = (unsigned)std::min<size_t>(n, 256 * 32);
+	hipLaunchKernelGGL(k_cigar_finish, dim3(grid), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_nt4, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
+	PGA_HIP(hipGetLastError());
+	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostFinRes), hipMemcpyDeviceToHost, st));
+	if (cig.size()) PGA_HIP(hipMemcpyAsync(cig.data(), c.p, cig.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	PGA_HIP(hipStreamSynchronize(st));
+}
+
+// bases of one window, back on the host (only the rare local-alignment windows the LL kernel does not take need them)
+void post_fetch(const uint8_t *d_nt4, uint64_t off, size_t n, std::vector<uint8_t> &out, hipStream_t st)
+{
+	out.resize(n);
+	if (!n) return;
+	PGA_HIP(hipMemcpyAsync(out.data(), d_nt4 + off, n, hipMemcpyDeviceToHost, st));
+	PGA_HIP(hipStreamSynchronize(st));
+}
+
+} // namespace pga
