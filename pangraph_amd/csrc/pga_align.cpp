@@ -1026,7 +1026,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	const DpParams P{opt.q, opt.e, opt.q2, opt.e2, D.mat[0], D.mat[1], D.mat[24]};
 	// deal the queries by anchor count (largest first, round robin): balanced sets
 	// (two sets pay from a few hundred queries on; below that the few long problems of a set only get in each other's way)
-	int n_sets = getenv("PGA_ALIGN_SETS") ? atoi(getenv("PGA_ALIGN_SETS")) : (n_seq >= 256 ? 2 : 1);
+	int n_sets = getenv("PGA_ALIGN_SETS") ? atoi(getenv("PGA_ALIGN_SETS")) : (n_seq >= 256 && part_concurrency() < 2 ? 2 : 1);
 	if (n_sets < 1) n_sets = 1;
 	if (n_seq < 8 * n_sets) n_sets = 1;
 	std::vector<int> order((size_t)n_seq);

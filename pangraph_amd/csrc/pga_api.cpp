@@ -277,14 +277,16 @@ static mm_reg1_t *regs_to_c(const std::vector<Reg> &regs, int *n_regs)
 	return out;
 }
 
-// cheap identity check of a query against the indexed sequence of the same name (64 probes)
+// cheap identity check of a query against the indexed sequence of the same name: the 64 probe positions kept at upload
 static bool seqs_same_bases(const SeqSet &S, int qid, const char *seq, int l_seq)
 {
-	const uint8_t *h = S.h_nt4.data() + S.off[qid];
-	for (int i = 0; i < l_seq; i += (l_seq > 64 ? l_seq / 64 : 1)) {
+	const uint8_t *h = S.probe.data() + (size_t)qid * 64;
+	const int step = l_seq > 64 ? l_seq / 64 : 1;
+	int k = 0;
+	for (int i = 0; i < l_seq && k < 64; i += step, ++k) {
 		const char c = seq[i] & 0xdf; uint8_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
 		if ((uint8_t)seq[i] < 0x40) code = 4;
-		if (code != h[i]) return false;
+		if (code != h[k]) return false;
 	}
 	return true;
 }
@@ -482,6 +484,7 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 				PGA_HIP(hipSetDevice(dev));
 				PgaIdx &ix = *B->parts[p];
 				ArenaScope arena_scope(ix.arena);
+				set_part_concurrency(std::min(n_parts, 2));
 				if (!ix.indexed || ix.hdr.w != io.w || ix.hdr.k != io.k) {
 					ix.hdr.w = io.w, ix.hdr.k = io.k, ix.hdr.b = 14 < 2 * io.k ? 14 : 2 * io.k;
 					ix.mid_occ_frac = -1.0f; ix.have_results = false;

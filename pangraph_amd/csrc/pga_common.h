@@ -92,7 +92,7 @@ struct SeqSet {
 	std::vector<uint64_t> off;          // n_seq+1 offsets into nt4
 	std::vector<uint32_t> len;
 	std::vector<std::string> name;
-	std::vector<uint8_t> h_nt4;         // host copy (the align driver's CIGAR post-processing reads it)
+	std::vector<uint8_t> probe;         // 64 base codes per sequence at evenly spaced positions (mm_map's identity check); the host keeps no other copy of the bases
 	DBuf<uint8_t> d_nt4;                // 1 byte per base: 0..3 ACGT, 4 other (sketch.c:9-26 table)
 	DBuf<uint64_t> d_off;
 	DBuf<uint32_t> d_len;
@@ -143,6 +143,9 @@ int usable_cpus();
 // host threads the calling thread's batch may use (pga_params_t.n_threads; 0 = usable_cpus())
 void set_thread_budget(int n);
 int thread_budget();
+// how many batches (parts) the calling thread's batch shares the device with: their rounds already overlap, so each runs one query set
+void set_part_concurrency(int n);
+int part_concurrency();
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st);
 void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm = nullptr);
 std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f, hipStream_t st);

@@ -399,7 +399,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
 // the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
 // used on the set's streams); a set returns to the pool with its streams drained.
-struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };   // slabs live for one call: they go back to the block cache (same arena, so the next call of this set gets them again; the cache may also drop them)
+struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };   // slabs are grow-only and stay with the set: no allocation in the launch path
 static std::mutex g_lane_mu;
 static std::vector<LaneSet*> g_lane_idle;
 struct LaneLease {
@@ -419,7 +419,6 @@ struct LaneLease {
 	~LaneLease()
 	{
 		for (int l = 0; l < 4; ++l) (void)hipStreamSynchronize(set->stream[l]);
-		for (int l = 0; l < 4; ++l) set->slab[l].release();
 		std::lock_guard<std::mutex> lk(g_lane_mu);
 		g_lane_idle.push_back(set);
 	}

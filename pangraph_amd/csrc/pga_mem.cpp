@@ -3,7 +3,9 @@
 // A batch allocates a few dozen device arrays per stage and the DP stage a scratch slab of tens of GB; hipMalloc and
 // hipFree cost from 0.1 ms to tens of ms each and hipFree synchronises the device, so freed blocks are kept in
 // per-device, size-rounded free lists and handed out again (a level of `pangraph build` repeats the same sizes call
-// after call).  The cache is bounded: beyond PGA_CACHE_GB (default 96) of idle blocks the largest idle blocks (of any pool) are released.
+// after call).  The cache is bounded: idle blocks may fill what the live blocks leave of 85 % of the device memory (and at most PGA_CACHE_GB,
+// default 200); beyond that the largest idle blocks (of any pool) are released.  hipFree synchronises the device, so a cache that is too
+// small costs far more than the memory it saves.
 #include "pga_common.h"
 #include <map>
 #include <mutex>
@@ -31,10 +33,14 @@ size_t round_size(size_t b)
 	const size_t step = p >> 4;                      // ... refined to 1/16 steps above 1 MB
 	return (b + step - 1) / step * step;
 }
-size_t cache_limit()
+size_t g_live_total = 0;                            // bytes handed out and not yet freed
+size_t cache_limit()                               // (called with g_mu held)
 {
-	static size_t lim = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 96.0; return (size_t)(g * (double)(1ull << 30)); }();
-	return lim;
+	static size_t cap = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 200.0; return (size_t)(g * (double)(1ull << 30)); }();
+	static size_t dev_total = [] { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = (size_t)256 << 30; return tot; }();
+	const size_t room = dev_total / 100 * 85;
+	const size_t lim = room > g_live_total ? room - g_live_total : 0;
+	return lim < cap ? lim : cap;
 }
 }
 
@@ -74,7 +80,7 @@ void *dev_alloc(size_t bytes)
 		auto it = P.idle.lower_bound(r);
 		if (it != P.idle.end() && it->first <= r + r / 4) {
 			void *p = it->second; const size_t sz = it->first;
-			P.idle.erase(it); P.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena};
+			P.idle.erase(it); P.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz;
 			return p;
 		}
 	}
@@ -88,7 +94,7 @@ void *dev_alloc(size_t bytes)
 		if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " allocating " + std::to_string(r) + " bytes of device memory");
 	}
 	std::lock_guard<std::mutex> lk(g_mu);
-	g_live[p] = Live{r, dev, arena};
+	g_live[p] = Live{r, dev, arena}; g_live_total += r;
 	return p;
 }
 
@@ -102,7 +108,7 @@ void dev_free(void *p)
 		if (it == g_live.end()) { drop.push_back(p); }
 		else {
 			const Live lv = it->second;
-			g_live.erase(it);
+			g_live.erase(it); g_live_total -= lv.size;
 			Pool &P = g_pools[{lv.dev, lv.arena}];
 			P.idle.emplace(lv.size, p); P.idle_bytes += lv.size; g_idle_total += lv.size;
 			// over the limit: release the largest idle blocks, whichever pool holds them (they are the DP slabs of past calls)

@@ -241,33 +241,42 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 			const uint32_t c = cg[k], op = c & 0xf; const int len = (int)(c >> 4);
 			if (op == 0) {
 				int ambi = 0, diff = 0;
-				for (int b = 0; b < len; b += 64) {
-					const int l = b + lane; const bool on = l < len;
-					int x = 0; bool is_ambi = false, is_diff = false;
-					if (on) {
-						const int tb = post_tbase(nt4, t0, toff + l), qb = post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l);
-						is_ambi = tb > 3 || qb > 3; is_diff = !is_ambi && tb != qb;
-						x = is_ambi ? sc_ambi : is_diff ? sc_mis : sc_mch;
-					}
+				// one 64-base block: counts, and the clamped running score in its block form (see the header)
+				auto block = [&](int tb, int qb, bool on, int cnt) {
+					const bool is_ambi = on && (tb > 3 || qb > 3), is_diff = on && !is_ambi && tb != qb;
+					const int x = !on ? 0 : is_ambi ? sc_ambi : is_diff ? sc_mis : sc_mch;
 					const unsigned long long m_ambi = __ballot(is_ambi), m_diff = __ballot(is_diff);
 					ambi += __popcll(m_ambi), diff += __popcll(m_diff);
-					const int cnt = len - b < 64 ? len - b : 64;
-					if ((m_ambi | m_diff) == 0 && sc_mch > 0) {     // all matches: s only grows
-						s += (double)sc_mch * (double)cnt; smax = smax > s ? smax : s;
-					} else {
-						const int P = (int)wave_prefix_sum_incl((uint32_t)x);           // lanes beyond the run add 0: their P repeats the last value
-						const int Pm = wave_prefix_min_incl(P);
-						const double neg_in = -s, pm = (double)Pm;
-						const double floor_ = neg_in < pm ? neg_in : pm;
-						const double si = (double)P - floor_;
-						// maximum of s over the block's valid positions
-						double cand = on ? si : 0.0;
-						const double mx = -wave_min_f64_key(-cand);
-						smax = smax > mx ? smax : mx;
-						const long long bits = __double_as_longlong(si);
-						const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
-						s = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);   // lane 63 carries P of the last valid base, and its prefix minimum
-					}
+					if ((m_ambi | m_diff) == 0 && sc_mch > 0) { s += (double)sc_mch * (double)cnt; smax = smax > s ? smax : s; return; }   // all matches: s only grows
+					const int P = (int)wave_prefix_sum_incl((uint32_t)x);           // lanes beyond the run add 0: their P repeats the last value
+					const int Pm = wave_prefix_min_incl(P);
+					const double neg_in = -s, pm = (double)Pm;
+					const double floor_ = neg_in < pm ? neg_in : pm;
+					const double si = (double)P - floor_;
+					const double mx = -wave_min_f64_key(-(on ? si : 0.0));          // maximum of s over the block's valid positions
+					smax = smax > mx ? smax : mx;
+					const long long bits = __double_as_longlong(si);
+					const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+					s = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);   // lane 63 carries P of the last valid base, and its prefix minimum
+				};
+				int b = 0;
+				// eight blocks per trip: sixteen loads in flight per lane (a single block per trip would pay the full memory latency every 64 bases)
+				for (; b + 512 <= len; b += 512) {
+					int tb[8], qb[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u) { tb[u] = post_tbase(nt4, t0, toff + b + 64 * u + lane); qb[u] = post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + b + 64 * u + lane); }
+					bool clean = true;
+#pragma unroll
+					for (int u = 0; u < 8; ++u) clean &= tb[u] == qb[u] && tb[u] <= 3;
+					if (__ballot(!clean) == 0 && sc_mch > 0) { s += (double)sc_mch * 512.0; smax = smax > s ? smax : s; continue; }
+#pragma unroll
+					for (int u = 0; u < 8; ++u) block(tb[u], qb[u], true, 64);
+				}
+				for (; b < len; b += 64) {
+					const int l = b + lane; const bool on = l < len;
+					int tb = 0, qb = 0;
+					if (on) { tb = post_tbase(nt4, t0, toff + l); qb = post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l); }
+					block(tb, qb, on, len - b < 64 ? len - b : 64);
 				}
 				blen += len - ambi, mlen += len - (ambi + diff), n_ambi += ambi;
 				toff += len, qoff += len;

@@ -63,6 +63,9 @@ int usable_cpus()
 static thread_local int t_thread_budget = 0;
 void set_thread_budget(int n) { t_thread_budget = n; }
 int thread_budget() { return t_thread_budget > 0 ? t_thread_budget : usable_cpus(); }
+static thread_local int t_part_conc = 1;
+void set_part_concurrency(int n) { t_part_conc = n > 0 ? n : 1; }
+int part_concurrency() { return t_part_conc; }
 
 static inline uint8_t nt4_host(uint8_t r)
 {
@@ -72,45 +75,84 @@ static inline uint8_t nt4_host(uint8_t r)
 	return code;
 }
 
+// ASCII -> nt4 (sketch.c:9-26 table: A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 4), sixteen bases per thread
+__device__ __forceinline__ uint32_t nt4_of(uint32_t r)
+{
+	const uint32_t c = r & 0xdf;
+	uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
+	if (r < 0x40) code = 4u;
+	return code;
+}
+__global__ __launch_bounds__(256)
+void k_encode_nt4(const uint4 *__restrict__ raw, uint4 *__restrict__ nt4, uint64_t n16)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n16) return;
+	const uint4 v = raw[i];
+	auto word = [](uint32_t w) { return nt4_of(w & 0xff) | nt4_of(w >> 8 & 0xff) << 8 | nt4_of(w >> 16 & 0xff) << 16 | nt4_of(w >> 24) << 24; };
+	uint4 o; o.x = word(v.x), o.y = word(v.y), o.z = word(v.z), o.w = word(v.w);
+	nt4[i] = o;
+}
+
+// The hand-over of a batch: the caller's ASCII sequences go to the device as they are -- host threads gather them into pinned
+// staging buffers, chunk by chunk, while the previous chunk is on its way over PCIe -- and are encoded THERE (k_encode_nt4).  The
+// host keeps no copy of the bases: nothing on the host reads them (pga_align.cpp), except 64 probe positions per sequence that let
+// mm_map() check that a query really is the indexed sequence of that name.
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st)
 {
 	S.n_seq = n;
 	S.off.assign((size_t)n + 1, 0); S.len.assign(len, len + n); S.name.resize(n);
 	for (int i = 0; i < n; ++i) { S.off[i + 1] = S.off[i] + len[i]; S.name[i] = name && name[i] ? name[i] : ""; }
 	S.total = S.off[n];
-	// sequences are padded to a 16-byte multiple so the packing loads never straddle the allocation
-	S.h_nt4.resize(S.total + 64);
-	memset(S.h_nt4.data() + S.total, 4, 64);
-	{
-		uint8_t lut[256];
-		for (int c = 0; c < 256; ++c) lut[c] = nt4_host((uint8_t)c);
-		// byte ranges of ~4 MB over the concatenation, converted by the usable host cores
-		const uint64_t chunk = 4u << 20;
-		const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
-		std::atomic<uint64_t> next{0};
-		auto work = [&]() {
-			for (;;) {
-				const uint64_t c = next.fetch_add(1);
-				if (c >= n_chunks) break;
-				const uint64_t b = c * chunk, e = std::min<uint64_t>(S.total, b + chunk);
-				int i = (int)(std::upper_bound(S.off.begin(), S.off.end(), b) - S.off.begin()) - 1;
-				for (uint64_t p = b; p < e; ) {
-					while (S.off[i + 1] <= p) ++i;
-					const uint64_t stop = std::min<uint64_t>(e, S.off[i + 1]);
-					const uint8_t *src = reinterpret_cast<const uint8_t*>(seq[i]) + (p - S.off[i]);
-					uint8_t *d = S.h_nt4.data() + p;
-					for (uint64_t j = 0; j < stop - p; ++j) d[j] = lut[src[j]];
+	S.probe.assign((size_t)n * 64, 4);
+	for (int i = 0; i < n; ++i) {
+		const uint32_t L = len[i]; const uint32_t step = L > 64 ? L / 64 : 1;
+		int k = 0;
+		for (uint32_t p = 0; p < L && k < 64; p += step, ++k) S.probe[(size_t)i * 64 + k] = nt4_host((uint8_t)seq[i][p]);
+	}
+	// sequences are padded to a 16-byte multiple (and 64 more) so that wide loads never straddle the allocation
+	const uint64_t padded = (S.total + 15) / 16 * 16;
+	S.d_nt4.alloc(padded + 64);
+	const uint64_t chunk = (uint64_t)64 << 20;
+	const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
+	if (n_chunks) {
+		struct Stage { uint8_t *pin = nullptr; uint8_t *dev = nullptr; hipEvent_t sent; };
+		Stage sg[2];
+		for (Stage &x : sg) { x.pin = (uint8_t*)pin_alloc(chunk); x.dev = (uint8_t*)dev_alloc(chunk); PGA_HIP(hipEventCreateWithFlags(&x.sent, hipEventDisableTiming)); }
+		const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)thread_budget(), 16));
+		for (uint64_t c = 0; c < n_chunks; ++c) {
+			Stage &x = sg[c & 1];
+			const uint64_t b = c * chunk, e = std::min<uint64_t>(S.total, b + chunk);
+			if (c >= 2) PGA_HIP(hipEventSynchronize(x.sent));          // the staging buffer's previous chunk has left the host
+			// gather [b, e) of the concatenation: every thread copies a contiguous slice
+			auto gather = [&](uint64_t lo, uint64_t hi) {
+				int i = (int)(std::upper_bound(S.off.begin(), S.off.end(), lo) - S.off.begin()) - 1;
+				for (uint64_t p = lo; p < hi;) {
+					while (S.off[(size_t)i + 1] <= p) ++i;
+					const uint64_t stop = std::min<uint64_t>(hi, S.off[(size_t)i + 1]);
+					memcpy(x.pin + (p - b), seq[i] + (p - S.off[(size_t)i]), (size_t)(stop - p));
 					p = stop;
 				}
+			};
+			const uint64_t per = ((e - b) + nt - 1) / nt;
+			if (nt == 1 || e - b < (1u << 20)) gather(b, e);
+			else {
+				std::vector<std::thread> th;
+				for (int t = 1; t < nt; ++t) { const uint64_t lo = std::min(e, b + (uint64_t)t * per), hi = std::min(e, lo + per); if (lo < hi) th.emplace_back(gather, lo, hi); }
+				gather(b, std::min(e, b + per));
+				for (auto &t : th) t.join();
 			}
-		};
-		const int nt = (int)std::min<uint64_t>(n_chunks, (uint64_t)usable_cpus());
-		std::vector<std::thread> th;
-		for (int t = 1; t < nt; ++t) th.emplace_back(work);
-		work();
-		for (auto &t : th) t.join();
+			const uint64_t nb = (e - b + 15) / 16 * 16;
+			if (nb > e - b) memset(x.pin + (e - b), 'N', (size_t)(nb - (e - b)));
+			PGA_HIP(hipMemcpyAsync(x.dev, x.pin, (size_t)nb, hipMemcpyHostToDevice, st));
+			PGA_HIP(hipEventRecord(x.sent, st));
+			hipLaunchKernelGGL(k_encode_nt4, dim3((unsigned)((nb / 16 + 255) / 256)), dim3(256), 0, st, (const uint4*)x.dev, (uint4*)(S.d_nt4.p + b), nb / 16);
+		}
+		PGA_HIP(hipGetLastError());
+		PGA_HIP(hipStreamSynchronize(st));
+		for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
 	}
-	S.d_nt4.upload(S.h_nt4, st);
+	PGA_HIP(hipMemsetAsync(S.d_nt4.p + padded, 4, 64, st));
 	S.d_off.upload(S.off, st);
 	S.d_len.upload(S.len, st);
 	S.n_grp = n_grp;
