@@ -97,7 +97,7 @@ struct PgaIdx {
 	int arena = 0;                   // device-memory arena of the index, leased for its lifetime (pga_mem.cpp)
 	PgaIdx() : arena(dev_lease_arena()) {}
 	~PgaIdx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } release_buffers(); dev_release_arena(arena); }
-	void release_buffers() { S.d_nt4.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
+	void release_buffers() { S.d_nt4.release(); S.d_pk2.release(); S.d_nmask.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
 		I.key.release(); I.occ_off.release(); I.occ.release(); I.key_grp.release(); grp.release(); d_name_rank.release(); d_mid_occ.release(); }
 };
 

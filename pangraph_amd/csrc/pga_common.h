@@ -94,6 +94,8 @@ struct SeqSet {
 	std::vector<std::string> name;
 	std::vector<uint8_t> probe;         // 64 base codes per sequence at evenly spaced positions (mm_map's identity check); the host keeps no other copy of the bases
 	DBuf<uint8_t> d_nt4;                // 1 byte per base: 0..3 ACGT, 4 other (sketch.c:9-26 table)
+	DBuf<uint32_t> d_pk2;               // the packed store: 2 bits per base, sixteen bases per word (word i = bases 16i .. 16i+15 of the concatenation)
+	DBuf<uint16_t> d_nmask;             // ... and one bit per base: 1 = not ACGT
 	DBuf<uint64_t> d_off;
 	DBuf<uint32_t> d_len;
 	// groups: independent all-vs-all problems sharing the batch (one group == one find_matches call)

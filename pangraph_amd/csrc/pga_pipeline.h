@@ -36,6 +36,10 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
                  std::vector<std::vector<Reg>> &out, int n_threads, Timers *tm, hipStream_t st);
 
 // exact replay of minimap2's unstable radix_sort_128x on the flagged arrays [off[s], off[s+1]) of a (pga_sort_replay.hip)
-void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st, Timers *tm = nullptr);
+// Optional hint: the same records STABLY sorted (sx, sy: keys and payloads at the same global positions) and dupc[i] = number of
+// positions j <= i with sx[j] == sx[j-1].  A bucket of the replay occupies the rank range of its records; if that range holds no two
+// equal keys, its final content is the sorted range itself, whatever the walk would have done: it is copied and never queued.
+struct RsHint { const uint64_t *sx, *sy; const uint32_t *dupc; };
+void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st, Timers *tm = nullptr, const RsHint *hint = nullptr);
 
 } // namespace pga

@@ -114,7 +114,8 @@ void post_zdrop_walk(const uint8_t *d_nt4, const std::vector<PostWalk> &reqs, co
 	out.resize(n);
 	if (!n) return;
 	DBuf<PostWalk> d; d.upload(reqs, st);
-	DBuf<uint32_t> c; c.upload(cig.data(), cig.size() ? cig.size() : 1, st);
+	DBuf<uint32_t> c; c.alloc(cig.size() ? cig.size() : 1);
+	if (!cig.empty()) PGA_HIP(hipMemcpyAsync(c.p, cig.data(), cig.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 	DBuf<PostWalkRes> r; r.alloc(n);
 	hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_nt4, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
 	PGA_HIP(hipGetLastError());

@@ -383,7 +383,19 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
 	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, a_raw.p, q_tie.p);
 	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
-	replay_sort_segments(O.a.p, n_a, O.q_aoff.p, nullptr, n_seq, q_tie.p, st, tm);
+	// the stable sort above doubles as a hint for the replay: buckets without equal keys are copied from it instead of being walked
+	DBuf<uint32_t> dupc(n_a);
+	{
+		struct Dp { const uint64_t *x; };
+		Dp dp{x1.p};
+		auto flag_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), [dp] __device__ (uint64_t i) { return (uint32_t)(i > 0 && dp.x[i] == dp.x[i - 1]); });
+		size_t tb = 0;
+		PGA_HIP(rocprim::inclusive_scan(nullptr, tb, flag_it, dupc.p, n_a, rocprim::plus<uint32_t>(), st));
+		DBuf<uint8_t> tmp(tb ? tb : 1);
+		PGA_HIP(rocprim::inclusive_scan(tmp.p, tb, flag_it, dupc.p, n_a, rocprim::plus<uint32_t>(), st));
+	}
+	const RsHint hint{x1.p, y1.p, dupc.p};
+	replay_sort_segments(O.a.p, n_a, O.q_aoff.p, nullptr, n_seq, q_tie.p, st, tm, getenv("PGA_NO_SORT_HINT") ? nullptr : &hint);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipStreamSynchronize(st));
 	if (getenv("PGA_VERBOSE")) {

@@ -83,8 +83,11 @@ __device__ __forceinline__ uint32_t nt4_of(uint32_t r)
 	if (r < 0x40) code = 4u;
 	return code;
 }
+// Two stores come out of one pass: nt4 (1 B/base: the DP kernels index single bases of arbitrary windows and strands) and the PACKED
+// store the sketch kernel streams -- 2 bits per base, sixteen bases per 32-bit word, plus one "not ACGT" bit per base (the reference
+// packs its index sequences the same way at index time, index.c:438-446, mmpriv.h:30-31, four bits per base there).
 __global__ __launch_bounds__(256)
-void k_encode_nt4(const uint4 *__restrict__ raw, uint4 *__restrict__ nt4, uint64_t n16)
+void k_encode_nt4(const uint4 *__restrict__ raw, uint4 *__restrict__ nt4, uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmask, uint64_t n16)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n16) return;
@@ -92,6 +95,11 @@ void k_encode_nt4(const uint4 *__restrict__ raw, uint4 *__restrict__ nt4, uint64
 	auto word = [](uint32_t w) { return nt4_of(w & 0xff) | nt4_of(w >> 8 & 0xff) << 8 | nt4_of(w >> 16 & 0xff) << 16 | nt4_of(w >> 24) << 24; };
 	uint4 o; o.x = word(v.x), o.y = word(v.y), o.z = word(v.z), o.w = word(v.w);
 	nt4[i] = o;
+	const uint32_t in[4] = {o.x, o.y, o.z, o.w};
+	uint32_t bits = 0, nm = 0;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) { const uint32_t c = (in[j >> 2] >> (8 * (j & 3))) & 0xff; bits |= (c & 3u) << (2 * j); nm |= (c > 3 ? 1u : 0u) << j; }
+	pk2[i] = bits; nmask[i] = (uint16_t)nm;
 }
 
 // The hand-over of a batch: the caller's ASCII sequences go to the device as they are -- host threads gather them into pinned
@@ -113,6 +121,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	// sequences are padded to a 16-byte multiple (and 64 more) so that wide loads never straddle the allocation
 	const uint64_t padded = (S.total + 15) / 16 * 16;
 	S.d_nt4.alloc(padded + 64);
+	S.d_pk2.alloc((size_t)(padded / 16) + 8); S.d_nmask.alloc((size_t)(padded / 16) + 8);
 	const uint64_t chunk = (uint64_t)64 << 20;
 	const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
 	if (n_chunks) {
@@ -146,13 +155,15 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			if (nb > e - b) memset(x.pin + (e - b), 'N', (size_t)(nb - (e - b)));
 			PGA_HIP(hipMemcpyAsync(x.dev, x.pin, (size_t)nb, hipMemcpyHostToDevice, st));
 			PGA_HIP(hipEventRecord(x.sent, st));
-			hipLaunchKernelGGL(k_encode_nt4, dim3((unsigned)((nb / 16 + 255) / 256)), dim3(256), 0, st, (const uint4*)x.dev, (uint4*)(S.d_nt4.p + b), nb / 16);
+			hipLaunchKernelGGL(k_encode_nt4, dim3((unsigned)((nb / 16 + 255) / 256)), dim3(256), 0, st, (const uint4*)x.dev, (uint4*)(S.d_nt4.p + b), S.d_pk2.p + b / 16, S.d_nmask.p + b / 16, nb / 16);
 		}
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipStreamSynchronize(st));
 		for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
 	}
 	PGA_HIP(hipMemsetAsync(S.d_nt4.p + padded, 4, 64, st));
+	PGA_HIP(hipMemsetAsync(S.d_pk2.p + padded / 16, 0, 8 * sizeof(uint32_t), st));
+	PGA_HIP(hipMemsetAsync(S.d_nmask.p + padded / 16, 0xff, 8 * sizeof(uint16_t), st));
 	S.d_off.upload(S.off, st);
 	S.d_len.upload(S.len, st);
 	S.n_grp = n_grp;
@@ -191,7 +202,7 @@ __device__ __forceinline__ uint64_t rev2(uint64_t x) // reverse the order of the
 
 template <int W_MAX>
 __global__ __launch_bounds__(SK_THREADS)
-void k_sketch_tiles(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
+void k_sketch_tiles(const uint32_t *__restrict__ pk2, const uint16_t *__restrict__ nmask, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
                     const SkTile *__restrict__ tiles, int w, int k, u128 *__restrict__ stage, uint32_t stage_cap,
                     uint32_t *__restrict__ tile_cnt, int *__restrict__ overflow)
 {
@@ -211,24 +222,25 @@ void k_sketch_tiles(const uint8_t *__restrict__ nt4, const uint64_t *__restrict_
 	const int tid = threadIdx.x;
 	const uint64_t mask = (1ULL << 2 * k) - 1;
 
-	// ---- 1. pack [t0-HALO, t0+TILE) to 2 bits + N bit.  Global loads are 16 B per lane and 16-B aligned in the
-	//         concatenated array, so the LDS image starts at the aligned address `ga` <= goff+t0-HALO.
+	// ---- 1. the 2-bit + N-bit image of [t0-HALO, t0+TILE) comes straight from the packed store (6 bytes per sixteen bases): words are
+	//         aligned to sixteen bases of the concatenated array, so the LDS image starts at the aligned position `ga` <= goff+t0-HALO;
+	//         positions outside the sequence (the previous / next sequence, the padding) count as "not ACGT".
 	const int64_t g_lo = (int64_t)goff + t0 - SK_HALO;      // may be negative or belong to the previous sequence
 	const int64_t ga = g_lo >= 0 ? (g_lo & ~15LL) : -(((-g_lo) + 15) & ~15LL);
 	const int pad = (int)(g_lo - ga);                        // 0..15: LDS position of g_lo
 	for (int c = tid; c < NPOS / 16 + 4; c += SK_THREADS) {
 		int64_t g = ga + (int64_t)c * 16;
-		uint32_t bits = 0, nm = 0;
-		uint4 v = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
-		if (g >= 0 && (uint64_t)g < goff + len + 16) v = *reinterpret_cast<const uint4*>(nt4 + g); // array is padded by 64 B
-		uint32_t in[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			uint32_t code = (in[j >> 2] >> (8 * (j & 3))) & 0xff;
-			int64_t p = g + j - (int64_t)goff;               // sequence coordinate
-			bool bad = code > 3 || p < 0 || p >= (int64_t)len;
-			bits |= (bad ? 0u : code) << (2 * j);
-			nm |= (bad ? 1u : 0u) << j;
+		uint32_t bits = 0, nm = 0xffffu;
+		if (g >= 0 && (uint64_t)g < goff + len + 16) { bits = pk2[g >> 4]; nm = nmask[g >> 4]; }      // (the stores are padded)
+		// bases of this word inside the sequence: [lo, hi)
+		const int64_t lo64 = (int64_t)goff - g, hi64 = (int64_t)goff + (int64_t)len - g;
+		const int lo = lo64 < 0 ? 0 : lo64 > 16 ? 16 : (int)lo64, hi = hi64 < 0 ? 0 : hi64 > 16 ? 16 : (int)hi64;
+		const uint32_t inside = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+		nm |= ~inside & 0xffffu;
+		{   // a base that does not count contributes 00 (what the byte form did): spread the 16-bit mask to 2 bits per base
+			uint32_t m = ~nm & 0xffffu;
+			m = (m | m << 8) & 0x00ff00ffu; m = (m | m << 4) & 0x0f0f0f0fu; m = (m | m << 2) & 0x33333333u; m = (m | m << 1) & 0x55555555u;
+			bits &= m | m << 1;
 		}
 		s_bits[c] = bits;
 		reinterpret_cast<uint16_t*>(s_nmask)[c] = (uint16_t)nm;
@@ -431,7 +443,7 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 			DBuf<u128> stage(nt * (size_t)cap);
 			EventTimer et(st);
 			hipLaunchKernelGGL((k_sketch_tiles<63>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st,
-			                   S.d_nt4.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
+			                   S.d_pk2.p, S.d_nmask.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
 			PGA_HIP(hipGetLastError());
 			const double k_ms = et.stop();
 			int ovf = d_ovf.download(st)[0];
@@ -441,7 +453,7 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 			PGA_HIP(hipMemcpyAsync(&total, d_toff.p + nt, 8, hipMemcpyDeviceToHost, st));
 			PGA_HIP(hipStreamSynchronize(st));
 			M.n = total;
-			if (tm) { tm->kern[K_SKETCH].ms += k_ms; tm->kern[K_SKETCH].launches += 1; tm->kern[K_SKETCH].alg_bytes += (double)S.total + 16.0 * (double)total; }
+			if (tm) { tm->kern[K_SKETCH].ms += k_ms; tm->kern[K_SKETCH].launches += 1; tm->kern[K_SKETCH].alg_bytes += 0.375 * (double)S.total + 16.0 * (double)total; }   // packed bases in (2 bits + the N bit), minimizers out
 			M.mz.alloc(total ? total : 1);
 			hipLaunchKernelGGL(k_compact, dim3((unsigned)nt), dim3(256), 0, st, stage.p, cap, d_cnt.p, d_toff.p, M.mz.p);
 			// sequences of length 0 have no tile: give them the offset of the next tile (or the total)

@@ -52,7 +52,7 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 // persistent waves over the run queue of this pass
 __global__ __launch_bounds__(64)
 void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
-               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all)
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint)
 {
 	__shared__ RsLds L;
 	const int lane = threadIdx.x;
@@ -77,7 +77,16 @@ void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_
 		const int next = rs_next_level(R.vary, shift - 8);
 		// buckets of this level: <= 64 records are insertion-sorted now (ksort.h:142), larger ones queue for the next level that can split them
 		if (next < 0) continue;                                  // the keys of a bucket agree in every lower byte: nothing left to order
-		rs_split_buckets(beg, n, shift, cnt, off, L, lane, [&](int64_t rb, int64_t len) { rs_push2(out, n_out, out_s, n_out_s, cap, R.start + (uint64_t)rb, (uint32_t)len, next, R.vary, lane); });
+		rs_split_buckets(beg, n, shift, cnt, off, L, lane, [&](int64_t rb, int64_t len) {
+			const uint64_t g0 = R.start + (uint64_t)rb;
+			if (hint.dupc && hint.dupc[g0 + (uint64_t)len - 1] == hint.dupc[g0]) {
+				// no two equal keys in this bucket: its final order is the sorted order
+				for (int64_t i = lane; i < len; i += 64) { u128 v; v.x = hint.sx[g0 + (uint64_t)i]; v.y = hint.sy[g0 + (uint64_t)i]; a[g0 + (uint64_t)i] = v; }
+				rs_fence_wg();
+				return;
+			}
+			rs_push2(out, n_out, out_s, n_out_s, cap, g0, (uint32_t)len, next, R.vary, lane);
+		});
 		if (prof && lane == 0) { const unsigned long long tk2 = wall_clock64(); atomicAdd(&prof[2], tk2 - tk1); atomicMax(&prof[3], tk2 - tk1); }
 	}
 }
@@ -202,7 +211,7 @@ void k_rs_small(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32
 
 // sorts every flagged array [off[s], off[s] + len[s]) of `a` by x exactly as radix_sort_128x would (flag == nullptr: all;
 // len == nullptr: the arrays are contiguous, off has n_seg+1 entries)
-void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st, Timers *tm)
+void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, const int64_t *d_len, int n_seg, const uint32_t *d_flag, hipStream_t st, Timers *tm, const RsHint *hint)
 {
 	if (n_seg <= 0 || n_total == 0) return;
 	EventTimer et(st);
@@ -221,7 +230,7 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	if (verbose) { pass_ms[8] = et.stop(); }
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
-		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p);
+		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr});
 		if (verbose) {
 			pass_ms[pass] = ep.stop();
 			uint32_t nr = 0; PGA_HIP(hipMemcpy(&nr, ctr.p + 2 * (pass + 1), 4, hipMemcpyDeviceToHost));
