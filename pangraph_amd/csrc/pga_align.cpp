@@ -965,8 +965,54 @@ struct RoundRunner {
 		return true;
 	}
 
+	// Rounds are a barrier over the queries of the set: round r+1 starts when the slowest problem of round r is done.  After the bulk
+	// (round 0) only the few queries with split chains are left, each with its own CHAIN of dependent rounds (one per split point,
+	// second pass, inversion test) whose lengths and problem sizes have nothing to do with one another.  From then on every such
+	// query runs its rounds on its own (own host thread, stream, arena and launch lanes), a few at a time.
+	void run_tails(const std::vector<int> &open)
+	{
+		std::atomic<size_t> next(0);
+		std::vector<std::string> errs(open.size());
+		std::vector<Timers> tms(open.size());
+		std::vector<std::vector<int>> one(open.size());
+		int dev = 0; PGA_HIP(hipGetDevice(&dev));
+		auto worker = [&] {
+			for (;;) {
+				const size_t k = next.fetch_add(1);
+				if (k >= open.size()) break;
+				hipStream_t ss = nullptr;
+				const int arena = dev_lease_arena();
+				ArenaScope arena_scope(arena);
+				try {
+					PGA_HIP(hipSetDevice(dev));
+					set_thread_budget(1);
+					PGA_HIP(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+					one[k].assign(1, open[k]);
+					Driver Dq(S, opt, D.k, ss);
+					RoundRunner R{S, opt, Dq, Q, out, one[k], set_id * 1000 + (int)k + 1, 1, ss, tm ? &tms[k] : nullptr, P, verbose, {}};
+					R.tail = true;
+					R.run();
+				} catch (std::exception &e) { errs[k] = e.what(); if (errs[k].empty()) errs[k] = "unknown error"; }
+				if (ss) { (void)hipStreamSynchronize(ss); (void)hipStreamDestroy(ss); }
+				dev_release_arena(arena);
+			}
+		};
+		static const int conc = getenv("PGA_TAIL_THREADS") ? std::max(1, atoi(getenv("PGA_TAIL_THREADS"))) : 6;
+		std::vector<std::thread> th;
+		for (int t = 0; t < std::min<int>(conc, (int)open.size()); ++t) th.emplace_back(worker);
+		for (auto &t : th) t.join();
+		for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+		if (tm) for (const Timers &t : tms) {
+			tm->dp_jobs += t.dp_jobs; tm->dp_cells += t.dp_cells; tm->dp_bases += t.dp_bases; tm->dp_cigar_ops += t.dp_cigar_ops;
+			for (int i = 0; i < K_COUNT; ++i) { tm->kern[i].ms += t.kern[i].ms; tm->kern[i].launches += t.kern[i].launches; tm->kern[i].alg_bytes += t.kern[i].alg_bytes; tm->kern[i].cells += t.kern[i].cells; }
+		}
+	}
+
+	bool tail = false;
+
 	void run()
 	{
+		static const int tail_max = getenv("PGA_TAIL_QUERIES") ? atoi(getenv("PGA_TAIL_QUERIES")) : 0;      // off by default: measured slower (the extra streams and lane sets get in the way of the other parts), see DESIGN.md
 		for (int round = 0; round < 100000; ++round) {
 			run_probes();
 			run_dp(round);
@@ -977,6 +1023,13 @@ struct RoundRunner {
 			if (unfinished == 0) break;
 			bool any_pending = false; for (int qi : qs) any_pending |= !Q[(size_t)qi].pending.empty();
 			if (!any_pending) throw std::runtime_error("pga: alignment driver stalled");
+			if (!tail && unfinished > 1 && unfinished <= tail_max) {
+				std::vector<int> open;
+				for (int qi : qs) if (!Q[(size_t)qi].finished) open.push_back(qi);
+				if (verbose) fprintf(stderr, "[pga]   set %d: %zu queries continue on their own after round %d\n", set_id, open.size(), round);
+				run_tails(open);
+				break;
+			}
 		}
 	}
 };

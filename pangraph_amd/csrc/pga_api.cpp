@@ -220,6 +220,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	mem_log("after align");
 	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;
 	ix.have_results = true; ix.res_opt = opt;
+	if (getenv("PGA_VERBOSE")) { long long ms_[4]; dev_mem_stats(ms_); fprintf(stderr, "[pga] allocator so far: %lld hipMalloc %.3f s, %lld hipFree %.3f s\n", ms_[0], ms_[1] * 1e-9, ms_[2], ms_[3] * 1e-9); }
 	if (getenv("PGA_VERBOSE"))
 		fprintf(stderr, "[pga] n_seq=%d bases=%llu mz=%.0f anchors=%.0f | upload %.3f sketch %.3f index %.3f seed %.3f chain %.3f align %.3f s | dp jobs %.0f cells %.3g\n",
 		        ix.S.n_seq, (unsigned long long)ix.S.total, ix.tm.n_mz, ix.tm.n_anchor, ix.tm.upload, ix.tm.sketch, ix.tm.index, ix.tm.seed, ix.tm.chain, ix.tm.align, ix.tm.dp_jobs, ix.tm.dp_cells);
@@ -437,7 +438,9 @@ extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, cons
 		uint64_t max_bases = getenv("PGA_MAX_BATCH_BASES") ? strtoull(getenv("PGA_MAX_BATCH_BASES"), 0, 10) : 3000000000ULL;
 		{
 			uint64_t total = 0; for (int64_t i = 0; i < group_off[n_groups]; ++i) total += seq_lens[i];
-			int want = getenv("PGA_PARTS") ? atoi(getenv("PGA_PARTS")) : 1;
+			// about a Gbp per part, up to three: the parts run concurrently, and every stage of this path is bound by some dependency chain
+			// (sort replay, chain sweep, DP rounds), so what overlaps is what counts
+			int want = getenv("PGA_PARTS") ? atoi(getenv("PGA_PARTS")) : (int)std::min<uint64_t>(3, std::max<uint64_t>(1, total / 1000000000ULL));
 			const int need = (int)((total + max_bases - 1) / max_bases);      // parts of EQUAL size (3.5 Gbp -> 1.75 + 1.75, not 3.0 + 0.5)
 			if (need > want) want = need;
 			if (want > 1 && n_groups >= want && total >= 200000000ULL) max_bases = std::min<uint64_t>(max_bases, (total + want - 1) / want + 1);
@@ -476,7 +479,7 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 		double t_all = now_s();
 		const int n_parts = (int)B->parts.size();
 		int threads_each = params->n_threads > 0 ? params->n_threads : usable_cpus();
-		threads_each = std::max(1, threads_each / std::max(1, std::min(n_parts, 2)));
+		threads_each = std::max(1, threads_each / std::max(1, std::min(n_parts, 3)));
 		std::vector<std::string> errs((size_t)n_parts);
 		int dev = 0; PGA_HIP(hipGetDevice(&dev));
 		auto work = [&](int p) {
@@ -484,7 +487,7 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 				PGA_HIP(hipSetDevice(dev));
 				PgaIdx &ix = *B->parts[p];
 				ArenaScope arena_scope(ix.arena);
-				set_part_concurrency(std::min(n_parts, 2));
+				set_part_concurrency(std::min(n_parts, 3));
 				if (!ix.indexed || ix.hdr.w != io.w || ix.hdr.k != io.k) {
 					ix.hdr.w = io.w, ix.hdr.k = io.k, ix.hdr.b = 14 < 2 * io.k ? 14 : 2 * io.k;
 					ix.mid_occ_frac = -1.0f; ix.have_results = false;
@@ -500,12 +503,12 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 		};
 		if (n_parts == 1) work(0);
 		else {
-			// at most two parts at a time: their dependency-bound phases overlap, and the device memory of two parts (resident
+			// at most three parts at a time: their dependency-bound phases overlap, and the device memory of three parts (resident
 			// arrays + DP scratch) stays bounded whatever the number of parts
 			std::atomic<int> next(0);
 			auto runner = [&] { for (;;) { const int p = next.fetch_add(1); if (p >= n_parts) break; work(p); } };
 			std::vector<std::thread> th;
-			const int conc = std::min(n_parts, getenv("PGA_PART_CONCURRENCY") ? std::max(1, atoi(getenv("PGA_PART_CONCURRENCY"))) : 2);
+			const int conc = std::min(n_parts, getenv("PGA_PART_CONCURRENCY") ? std::max(1, atoi(getenv("PGA_PART_CONCURRENCY"))) : 3);
 			for (int t = 0; t < conc; ++t) th.emplace_back(runner);
 			for (auto &t : th) t.join();
 		}

@@ -402,13 +402,21 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };   // slabs are grow-only and stay with the set: no allocation in the launch path
 static std::mutex g_lane_mu;
 static std::vector<LaneSet*> g_lane_idle;
+static std::atomic<size_t> g_slab_total(0);                  // bytes held by the slabs of all sets of all devices
 struct LaneLease {
 	LaneSet *set = nullptr;
-	explicit LaneLease(int dev)
+	LaneLease(int dev, const size_t (&need)[4])
 	{
 		{
+			// best fit: the idle set that has to grow least; among those, the one that wastes least
 			std::lock_guard<std::mutex> lk(g_lane_mu);
-			for (size_t i = 0; i < g_lane_idle.size(); ++i) if (g_lane_idle[i]->dev == dev) { set = g_lane_idle[i]; g_lane_idle.erase(g_lane_idle.begin() + (long)i); break; }
+			long best = -1; size_t best_grow = 0, best_waste = 0;
+			for (size_t i = 0; i < g_lane_idle.size(); ++i) if (g_lane_idle[i]->dev == dev) {
+				size_t grow = 0, waste = 0;
+				for (int l = 0; l < 4; ++l) { const size_t c = g_lane_idle[i]->slab[l].cap; if (need[l] > c) grow += need[l] - c; else waste += c - need[l]; }
+				if (best < 0 || grow < best_grow || (grow == best_grow && waste < best_waste)) best = (long)i, best_grow = grow, best_waste = waste;
+			}
+			if (best >= 0) { set = g_lane_idle[(size_t)best]; g_lane_idle.erase(g_lane_idle.begin() + best); }
 		}
 		if (set) return;
 		set = new LaneSet(); set->dev = dev; set->arena = dev_lease_arena();
@@ -419,6 +427,10 @@ struct LaneLease {
 	~LaneLease()
 	{
 		for (int l = 0; l < 4; ++l) (void)hipStreamSynchronize(set->stream[l]);
+		// the slabs stay with the set as long as all sets together hold a reasonable share of the device; beyond that this set gives its
+		// slabs back (to the block cache, which may drop them)
+		static const size_t keep = (size_t)(getenv("PGA_SLAB_KEEP_GB") ? atof(getenv("PGA_SLAB_KEEP_GB")) : 96.0) << 30;
+		if (g_slab_total.load() > keep) for (int l = 0; l < 4; ++l) { g_slab_total -= set->slab[l].cap; set->slab[l].release(); }
 		std::lock_guard<std::mutex> lk(g_lane_mu);
 		g_lane_idle.push_back(set);
 	}
@@ -503,8 +515,6 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// land on the same queue run back to back)
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
-	LaneLease lanes(dev_id);                                // four streams + four scratch slabs of this device, exclusive for the call: concurrent query sets do not queue behind each other
-	hipStream_t *lane_stream = lanes.set->stream;
 	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
@@ -531,8 +541,15 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		waves_of[c] = n_waves;
 		lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], n_waves * slab_max[c]);
 	}
+	// four streams + four scratch slabs of this device, exclusive for the call (concurrent callers do not queue behind each other): the
+	// idle set whose slabs fit the need best
+	LaneLease lanes(dev_id, lane_need);
+	hipStream_t *lane_stream = lanes.set->stream;
 	DBuf<uint8_t> *lane_slab = lanes.set->slab;
-	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) { ArenaScope own(lanes.set->arena); lane_slab[l].alloc(lane_need[l]); }   // (the set is idle: its last user drained the streams)
+	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) {      // (the set is idle: its last user drained the streams)
+		ArenaScope own(lanes.set->arena);
+		g_slab_total -= lane_slab[l].cap; lane_slab[l].alloc(lane_need[l]); g_slab_total += lane_slab[l].cap;
+	}
 	// every class is prepared and launched in turn, the classes with few, long problems first: they are already running
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the

@@ -9,6 +9,8 @@
 #include "pga_common.h"
 #include <map>
 #include <mutex>
+#include <atomic>
+#include <chrono>
 
 namespace pga {
 
@@ -30,10 +32,13 @@ size_t round_size(size_t b)
 	size_t p = 256;
 	while (p < b) p <<= 1;                           // next power of two ...
 	if (b <= (1u << 20)) return p;
-	const size_t step = p >> 4;                      // ... refined to 1/16 steps above 1 MB
-	return (b + step - 1) / step * step;
+	const size_t step = b <= ((size_t)64 << 20) ? p >> 4 : p >> 2;   // ... refined to 1/16 steps above 1 MB, 1/4 steps above 64 MB (batch sizes drift from
+	return (b + step - 1) / step * step;                                // call to call: coarse classes keep the large blocks reusable)
 }
 size_t g_live_total = 0;                            // bytes handed out and not yet freed
+std::atomic<long long> g_n_malloc(0), g_ns_malloc(0), g_n_free(0), g_ns_free(0);   // driver calls behind the cache (diagnostics)
+struct NsScope { std::atomic<long long> &n, &ns; std::chrono::steady_clock::time_point t0; NsScope(std::atomic<long long> &n_, std::atomic<long long> &ns_) : n(n_), ns(ns_), t0(std::chrono::steady_clock::now()) {}
+	~NsScope() { ++n; ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
 size_t cache_limit()                               // (called with g_mu held)
 {
 	static size_t cap = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 200.0; return (size_t)(g * (double)(1ull << 30)); }();
@@ -54,18 +59,21 @@ int dev_get_arena() { return t_arena; }
 // worker has synchronised its stream (ArenaLease's owner does), so whoever leases it next may reuse its idle blocks on any
 // stream.  Ids are recycled, so the number of pools is bounded by the peak number of concurrent workers.  Arena 0 is the
 // default of threads that never leased one (stage taps, single-threaded tests): not safe for concurrent use on several streams.
-namespace { std::vector<int> g_arena_free; int g_arena_next = 1; }
+namespace { std::vector<int> g_arena_free; int g_arena_next = 1; std::map<int, bool> g_arena_leased; }
 int dev_lease_arena()
 {
 	std::lock_guard<std::mutex> lk(g_mu);
-	if (!g_arena_free.empty()) { const int a = g_arena_free.back(); g_arena_free.pop_back(); return a; }
-	return g_arena_next++;
+	int a;
+	if (!g_arena_free.empty()) { a = g_arena_free.back(); g_arena_free.pop_back(); } else a = g_arena_next++;
+	g_arena_leased[a] = true;
+	return a;
 }
 void dev_release_arena(int arena)
 {
 	if (arena <= 0) return;
 	std::lock_guard<std::mutex> lk(g_mu);
 	g_arena_free.push_back(arena);
+	g_arena_leased[arena] = false;
 }
 
 void *dev_alloc(size_t bytes)
@@ -78,14 +86,29 @@ void *dev_alloc(size_t bytes)
 		std::lock_guard<std::mutex> lk(g_mu);
 		Pool &P = g_pools[{dev, arena}];
 		auto it = P.idle.lower_bound(r);
-		if (it != P.idle.end() && it->first <= r + r / 4) {
+		if (it != P.idle.end() && (it->first <= r + r / 4 || (r >= ((size_t)16 << 20) && it->first <= 2 * r))) {   // large blocks: up to twice the need beats a hipMalloc (and the hipFree it provokes)
 			void *p = it->second; const size_t sz = it->first;
 			P.idle.erase(it); P.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz;
 			return p;
 		}
+		// nothing in this arena: the idle blocks of arenas that are not leased at the moment are free for all (their owners synchronised
+		// their streams before giving the arena back); the block changes its home to this arena
+		if (arena != 0) for (auto &kv : g_pools) {
+			if (kv.first.first != dev || kv.first.second == 0 || kv.first.second == arena) continue;
+			auto ls = g_arena_leased.find(kv.first.second);
+			if (ls == g_arena_leased.end() || ls->second) continue;
+			Pool &O = kv.second;
+			auto jt = O.idle.lower_bound(r);
+			if (jt != O.idle.end() && (jt->first <= r + r / 4 || (r >= ((size_t)16 << 20) && jt->first <= 2 * r))) {
+				void *p = jt->second; const size_t sz = jt->first;
+				O.idle.erase(jt); O.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz;
+				return p;
+			}
+		}
 	}
 	void *p = nullptr;
-	hipError_t e = hipMalloc(&p, r);
+	hipError_t e;
+	{ NsScope sc(g_n_malloc, g_ns_malloc); e = hipMalloc(&p, r); }
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
 		dev_trim();                                   // give the idle blocks back and retry once
@@ -121,8 +144,10 @@ void dev_free(void *p)
 			}
 		}
 	}
-	for (void *q : drop) (void)hipFree(q);
+	for (void *q : drop) { NsScope sc(g_n_free, g_ns_free); (void)hipFree(q); }
 }
+
+void dev_mem_stats(long long out[4]) { out[0] = g_n_malloc; out[1] = g_ns_malloc; out[2] = g_n_free; out[3] = g_ns_free; }
 
 void dev_trim()
 {

@@ -383,6 +383,17 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
 	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, a_raw.p, q_tie.p);
 	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
+	if (const char *dump = getenv("PGA_DUMP_ANCHORS")) {
+		// diagnosis: the raw anchors of the first large query with equal keys, as the replay will see them
+		std::vector<uint32_t> tf = q_tie.download(st);
+		for (int q = 0; q < n_seq; ++q) if (tf[(size_t)q] && O.h_q_aoff[(size_t)q + 1] - O.h_q_aoff[(size_t)q] >= 400000) {
+			const uint64_t b = O.h_q_aoff[(size_t)q], m = O.h_q_aoff[(size_t)q + 1] - b;
+			std::vector<u128> h((size_t)m);
+			PGA_HIP(hipMemcpy(h.data(), a_raw.p + b, (size_t)m * sizeof(u128), hipMemcpyDeviceToHost));
+			if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), sizeof(u128), (size_t)m, f); fclose(f); fprintf(stderr, "[pga] dumped %llu raw anchors of query %d to %s\n", (unsigned long long)m, q, dump); }
+			break;
+		}
+	}
 	// the stable sort above doubles as a hint for the replay: buckets without equal keys are copied from it instead of being walked
 	DBuf<uint32_t> dupc(n_a);
 	{

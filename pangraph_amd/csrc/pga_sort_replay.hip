@@ -52,7 +52,7 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 // persistent waves over the run queue of this pass
 __global__ __launch_bounds__(64)
 void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
-               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint)
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint, u128 *__restrict__ tmp_all)
 {
 	__shared__ RsLds L;
 	const int lane = threadIdx.x;
@@ -70,7 +70,7 @@ void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_
 		int shift = R.shift;
 		uint32_t cnt[4], off[4];
 		uint32_t *rend = rend_all ? rend_all + R.start : nullptr;    // scratch of the run-length walk, one word per record
-		while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
+		while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend, tmp_all ? tmp_all + R.start : nullptr)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
 		const unsigned long long tk1 = wall_clock64();
 		if (prof && lane == 0) { atomicAdd(&prof[0], tk1 - tk0); atomicMax(&prof[1], tk1 - tk0); atomicAdd(&prof[32], L.prof[0]); atomicAdd(&prof[33], L.prof[1]); atomicAdd(&prof[34], L.prof[2]); atomicAdd(&prof[35], L.prof[3]); }
 		if (shift <= 0) continue;                                // nothing below the last byte
@@ -226,11 +226,13 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	DBuf<unsigned long long> dprof(64); dprof.zero(st);
 	DBuf<uint32_t> rend;
 	if (!getenv("PGA_NO_RUNWALK")) rend.alloc(n_total);
+	DBuf<u128> tmp2;                        // the out-of-place image of the two-bucket levels
+	if (rend.p && !getenv("PGA_NO_TWOBUCKET")) tmp2.alloc(n_total);
 	double pass_ms[9] = {0};
 	if (verbose) { pass_ms[8] = et.stop(); }
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
-		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr});
+		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p);
 		if (verbose) {
 			pass_ms[pass] = ep.stop();
 			uint32_t nr = 0; PGA_HIP(hipMemcpy(&nr, ctr.p + 2 * (pass + 1), 4, hipMemcpyDeviceToHost));

@@ -28,6 +28,7 @@ struct __attribute__((aligned(16))) RsLds {
 	uint32_t head[256], tail[256], wbase[256];
 	uint8_t wslot[256];
 	uint32_t ppos[256]; uint32_t pk[256];   // the cycle being followed by the run-length walk: slot and bucket of every stop
+	uint32_t hpos[256], hrem[256]; uint16_t hdig[256];   // what sits at a bucket's head (digit, remainder of its digit run), valid while head == hpos: following a cycle reads LDS only
 	unsigned long long prof[4];  // ticks (diagnostics)
 };
 
@@ -61,6 +62,31 @@ __device__ __forceinline__ void rs_flush(u128 *beg, RsLds &L, int d, int wlog, i
 __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, RsLds &L, int lane, const unsigned long long (&nonempty)[4])
 {
 	auto digit_at = [&](uint32_t p) -> uint32_t { return (uint32_t)((beg[p].x >> shift) & 255); };
+	// digit and run remainder of the record at the head of bucket k (uniform arguments): from LDS while the head has not moved since
+	// the entry was made, else from memory (and remembered)
+	auto peek = [&](uint32_t k, uint32_t pos, uint32_t tk, uint32_t &dd, uint32_t &rem) {
+		if (L.hpos[k] == pos) { dd = L.hdig[k]; rem = L.hrem[k]; return; }
+		dd = digit_at(pos);
+		uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk;
+		rem = r2 - pos;
+		if (lane == 0) { L.hpos[k] = pos; L.hdig[k] = (uint16_t)dd; L.hrem[k] = rem; }
+		rs_fence_wave();
+	};
+	// the heads of the buckets pk[q0..q1) have moved: one parallel round of loads brings their entries up to date
+	auto refresh = [&](int q0, int q1) {
+		for (int q = q0 + lane; q < q1; q += 64) {
+			const uint32_t k = L.pk[q], pos = L.head[k], tk = L.tail[k];
+			if (pos < tk) { uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk; L.hpos[k] = pos; L.hdig[k] = (uint16_t)digit_at(pos); L.hrem[k] = r2 - pos; }
+			else L.hpos[k] = RS_NONE;
+		}
+		rs_fence_wave();
+	};
+	for (int k = lane; k < 256; k += 64) {
+		const uint32_t pos = L.head[k], tk = L.tail[k];
+		if (pos < tk) { uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk; L.hpos[k] = pos; L.hdig[k] = (uint16_t)digit_at(pos); L.hrem[k] = r2 - pos; }
+		else L.hpos[k] = RS_NONE;
+	}
+	rs_fence_wave();
 #pragma unroll 1
 	for (int kk = 0; kk < 4; ++kk) {
 		unsigned long long todo = nonempty[kk];
@@ -80,9 +106,9 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 					for (int c = 0; c < 4; ++c) hit |= lane + 64 * c < Lc && L.pk[lane + 64 * c] == k;
 					if (__ballot(hit) || Lc == 256) { simple = false; break; }
 					const uint32_t pos = L.head[k], tk = L.tail[k];
-					const uint32_t dd = digit_at(pos);
+					uint32_t dd, r2;
+					peek(k, pos, tk, dd, r2);
 					if (dd == k) { simple = false; break; }               // the record at the head is home: the token would push it along
-					uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk; r2 -= pos;
 					if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; }
 					rs_fence_wave();
 					++Lc;
@@ -94,13 +120,21 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 					if (lane == 0) { L.prof[0] += 1; L.prof[1] += M; }
 					// M rotations, one per lane: the record of the leader's slot goes to the first stop, every stop's record to the next
 					// stop, the last one (digit i) into the leader's slot
+					// (eight stops per trip: their loads are independent of one another, so they are in flight together)
 					for (uint32_t m = (uint32_t)lane; m < M; m += 64) {
 						u128 t = ld128(&beg[h + m]);
-						for (int q = 0; q < Lc; ++q) { u128 *slot = &beg[L.ppos[q] + m]; const u128 o = ld128(slot); *slot = t; t = o; }
+						for (int q0 = 0; q0 < Lc; q0 += 8) {
+							u128 v[8];
+#pragma unroll
+							for (int c = 0; c < 8; ++c) if (q0 + c < Lc) v[c] = ld128(&beg[L.ppos[q0 + c] + m]);
+#pragma unroll
+							for (int c = 0; c < 8; ++c) if (q0 + c < Lc) { beg[L.ppos[q0 + c] + m] = t; t = v[c]; }
+						}
 						beg[h + m] = t;
 					}
 					for (int q = lane; q < Lc; q += 64) L.head[L.pk[q]] += M;   // (distinct buckets: the cycle is simple)
 					rs_fence_wave();
+					refresh(0, Lc);
 					h += M;
 					continue;
 				}
@@ -122,7 +156,8 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 						if (hitq != 0x7fffffff) { q0 = hitq; break; }
 						if (Lc == 256) break;
 						const uint32_t pos = L.head[k], tk = L.tail[k];
-						const uint32_t dd = digit_at(pos);
+						uint32_t dd, r2u;
+						peek(k, pos, tk, dd, r2u);
 						if (dd == k) { home = true; break; }
 						if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; }
 						rs_fence_wave();
@@ -164,6 +199,7 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 						}
 						for (int q = q0 + lane; q < Lc; q += 64) L.head[L.pk[q]] = L.ppos[q] + T;
 						rs_fence_wg();
+						refresh(q0, Lc);
 					}
 					dst = (uint32_t)((carry.x >> shift) & 255);
 					if (!home || dst == i) continue;
@@ -205,7 +241,76 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 }
 
 // one level (ksort.h:118-146) on [beg, beg+n); false if every record has the same digit (the walk is the identity)
-__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4], uint32_t *rend = nullptr)
+// ---- a level with exactly TWO non-empty buckets (the strand bit, the target id of a two-sequence group): closed form ----
+// With buckets A < B, region A = [0, cA) and region B = [cA, n), the walk of ksort.h:128-141 does nothing but this: it scans region A;
+// a record of bucket A stays; the t-th record of bucket B found there (at i_t) is carried to the head of region B, where it pushes the
+// B records one slot to the right until the t-th A record of region B (at q_t) falls out, which lands at i_t.  Heads only move
+// forward, so with h_0 = cA, h_t = q_(t-1) + 1:
+//     new[i_t] = old[q_t]      new[h_t] = old[i_t]      new[p + 1] = old[p] for the B records p in [h_t, q_t)      everything else stays
+// -- three coalesced passes with two running counts instead of one dependent step per record.  `tmp` receives the new arrangement
+// (same length as the run), idx holds the 2m positions i_t, q_t (one word per record is enough: m <= n/2).
+__device__ inline void rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA, uint32_t cA, u128 *tmp, uint32_t *idx, int lane)
+{
+	const unsigned long long lt = (1ULL << lane) - 1;
+	// pass 1: positions of the misplaced records: I[t] = idx[t], Q[t] = idx[m + t]; m is not known yet, so Q is written from the back
+	uint32_t mA = 0, mB = 0;
+	for (int64_t c0 = 0; c0 < n; c0 += 256) {
+		bool mis[4]; int64_t p[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { p[k] = c0 + lane + 64 * k; const bool isA = p[k] < n && (uint32_t)((beg[p[k]].x >> shift) & 255) == dA; mis[k] = p[k] < n && (p[k] < (int64_t)cA ? !isA : isA); }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const unsigned long long bm = __ballot(mis[k]);
+			const int64_t blk = c0 + 64 * k;                      // a 64-block lies in one region or straddles cA: count per side
+			const unsigned long long inA = blk + 64 <= (int64_t)cA ? ~0ULL : blk >= (int64_t)cA ? 0ULL : ((1ULL << (cA - blk)) - 1);
+			if (mis[k]) { if (p[k] < (int64_t)cA) idx[mA + (uint32_t)__popcll(bm & inA & lt)] = (uint32_t)p[k]; else idx[(uint32_t)n - 1 - (mB + (uint32_t)__popcll(bm & ~inA & lt))] = (uint32_t)p[k]; }
+			mA += (uint32_t)__popcll(bm & inA); mB += (uint32_t)__popcll(bm & ~inA);
+		}
+	}
+	rs_fence_wg();
+	const uint32_t m = mA;                                        // == mB
+	auto Qat = [&](uint32_t t) { return idx[(uint32_t)n - 1 - t]; };
+	// pass 2: the new arrangement, out of place
+	uint32_t tA = 0, tB = 0;
+	for (int64_t c0 = 0; c0 < n; c0 += 256) {
+		u128 v[4]; int64_t p[4]; bool isA[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { p[k] = c0 + lane + 64 * k; if (p[k] < n) v[k] = ld128(&beg[p[k]]); isA[k] = p[k] < n && (uint32_t)((v[k].x >> shift) & 255) == dA; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool on = p[k] < n, inA = p[k] < (int64_t)cA;
+			const bool mis = on && (inA ? !isA[k] : isA[k]);
+			const unsigned long long bm = __ballot(mis);
+			const int64_t blk = c0 + 64 * k;
+			const unsigned long long sideA = blk + 64 <= (int64_t)cA ? ~0ULL : blk >= (int64_t)cA ? 0ULL : ((1ULL << (cA - blk)) - 1);
+			if (on) {
+				uint32_t dst;
+				if (inA) {
+					if (isA[k]) dst = (uint32_t)p[k];
+					else { const uint32_t t = tA + (uint32_t)__popcll(bm & sideA & lt); dst = t == 0 ? cA : Qat(t - 1) + 1; }
+				} else {
+					const uint32_t u = tB + (uint32_t)__popcll(bm & ~sideA & lt);      // A records of region B in front of p
+					if (isA[k]) dst = idx[u];                                          // the u-th of them goes to i_u
+					else dst = u < m ? (uint32_t)p[k] + 1 : (uint32_t)p[k];
+				}
+				tmp[dst] = v[k];
+			}
+			tA += (uint32_t)__popcll(bm & sideA); tB += (uint32_t)__popcll(bm & ~sideA);
+		}
+	}
+	rs_fence_wg();
+	// pass 3: back in place
+	for (int64_t c0 = 0; c0 < n; c0 += 256) {
+		u128 v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t p = c0 + lane + 64 * k; if (p < n) v[k] = ld128(&tmp[p]); }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t p = c0 + lane + 64 * k; if (p < n) beg[p] = v[k]; }
+	}
+	rs_fence_wg();
+}
+
+__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4], uint32_t *rend = nullptr, u128 *tmp = nullptr)
 {
 	for (int d = lane; d < 256; d += 64) L.head[d] = 0, L.wbase[d] = RS_NONE;
 	rs_fence_wave();
@@ -231,6 +336,14 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 		n_ne += (uint32_t)__popcll(nonempty[k]);
 	}
 	if (n_ne <= 1) return false;
+	if (n_ne == 2 && tmp && rend && n >= 1024) {
+		// which two buckets, and the size of the lower one (uniform)
+		int dA = -1; uint32_t cA = 0;
+#pragma unroll
+		for (int k = 3; k >= 0; --k) if (nonempty[k]) { const int l = __ffsll((long long)nonempty[k]) - 1; dA = l + 64 * k; cA = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k], l); }
+		rs_level_two(beg, n, shift, (uint32_t)dA, cA, tmp, rend, lane);
+		return true;
+	}
 	if (rend && n >= 4096) {
 		// digit runs of the original order, back to front: rend[p] = first position after p whose digit differs
 		uint32_t nb = 0, carry_end = (uint32_t)n;
