@@ -57,11 +57,14 @@ def pmc_traffic(kernel: str):
     if not files:
         return None
     d = json.load(open(files[-1]))
+    names = [x for x in kernel.replace(" ", "").split("+") if x.startswith("k_")]
+    if not names:
+        return None
     tot, n = 0.0, 0
     for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         disp = 0
         for k, v in d.get(c, {}).items():
-            if kernel in k:
+            if any(nm in k for nm in names):
                 tot += mul * v["sum"] * 1024.0
                 disp += v["dispatches"]
         n = max(n, disp)

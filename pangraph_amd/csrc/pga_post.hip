@@ -30,30 +30,32 @@ __device__ __forceinline__ int post_qbase(const uint8_t *__restrict__ nt4, uint6
 }
 
 // ------------------------------------------------------------------------------------------------ identity probes
+// One WAVE per probe at a time (grid-stride): the lanes read 64 consecutive bases of both windows per step (coalesced; a lane per
+// probe would pull a whole cache line for every byte), the mismatch count is a ballot + popcount, the early exit is uniform.
 __global__ __launch_bounds__(256)
 void k_seg_identity(const PostProbe *__restrict__ pr, uint32_t n, const uint8_t *__restrict__ nt4, int m_max, int32_t *__restrict__ out)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const PostProbe P = pr[i];
-	int m = 0;
-	const uint8_t *t = nt4 + P.t_off;
-	if (!P.q_rev) {
-		const uint8_t *q = nt4 + P.q_off + (uint64_t)P.qs;
-		for (int k = 0; k < P.n; ++k) {
-			const int x = t[k], y = q[k];
-			if ((x | y) > 3) { m = -1; break; }
-			if (x != y && ++m > m_max) { m = -1; break; }
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t i = wave; i < n; i += n_waves) {
+		const PostProbe P = pr[i];
+		const uint8_t *t = nt4 + P.t_off;
+		const uint8_t *q = P.q_rev ? nt4 + P.q_off + (uint64_t)(P.qlen_full - 1 - P.qs) : nt4 + P.q_off + (uint64_t)P.qs;
+		int m = 0;
+		for (int b = 0; b < P.n; b += 64) {
+			const int k = b + lane;
+			bool bad = false, diff = false;
+			if (k < P.n) {
+				const int x = t[k], y = P.q_rev ? q[-k] : q[k];
+				bad = (x | y) > 3;
+				diff = P.q_rev ? x != 3 - y : x != y;
+			}
+			if (__ballot(bad)) { m = -1; break; }
+			m += __popcll(__ballot(diff));
+			if (m > m_max) { m = -1; break; }
 		}
-	} else {
-		const uint8_t *q = nt4 + P.q_off + (uint64_t)(P.qlen_full - 1 - P.qs);
-		for (int k = 0; k < P.n; ++k) {
-			const int x = t[k], y = q[-k];
-			if ((x | y) > 3) { m = -1; break; }
-			if (x != 3 - y && ++m > m_max) { m = -1; break; }
-		}
+		if (lane == 0) out[i] = m;
 	}
-	out[i] = m;
 }
 
 void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_max, PinVec<int32_t> &out, hipStream_t st)
@@ -64,7 +66,7 @@ void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_
 	DBuf<PostProbe> d; d.alloc(n);
 	DBuf<int32_t> r; r.alloc(n);
 	PGA_HIP(hipMemcpyAsync(d.p, probes.data(), n * sizeof(PostProbe), hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d.p, (uint32_t)n, d_nt4, m_max, r.p);
+	hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, st, d.p, (uint32_t)n, d_nt4, m_max, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipStreamSynchronize(st));

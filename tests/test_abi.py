@@ -76,3 +76,19 @@ def test_unknown_preset_is_an_error(oracle_lib, product_so):
             lib.make_options("map-ont-nonsense")
         with pytest.raises(ValueError):
             lib.align_all(["ACGT"], ["1"], sensitivity=7)
+
+
+def test_header_layout_pinned_against_reference_header(tmp_path):
+    """include/pga_mm2_abi.h itself (not the ctypes mirror) against the reference's minimap.h: sizes, offsets of every field the
+    crate or the backend touches, bit positions of the bit-fields, flag constants.  Needs /root/reference (build container)."""
+    import pytest
+    ref_h = "/root/reference/packages/minimap2-sys/minimap2/minimap.h"
+    if not os.path.exists(ref_h):
+        pytest.skip("reference header not present (GPU box)")
+    outs = []
+    for tag, hdr, inc in (("ref", ref_h, os.path.dirname(ref_h)), ("pga", os.path.join(ROOT, "include", "pga_mm2_abi.h"), os.path.join(ROOT, "include"))):
+        exe = str(tmp_path / f"abi_{tag}")
+        subprocess.run(["gcc", "-std=gnu99", "-w", f'-DABI_HEADER="{hdr}"', "-I", inc, os.path.join(ROOT, "tests", "abi_probe.c"), "-o", exe], check=True)
+        outs.append(subprocess.run([exe], check=True, capture_output=True, text=True).stdout)
+    assert outs[0] == outs[1], "\n".join(a + "   |   " + b for a, b in zip(outs[0].splitlines(), outs[1].splitlines()) if a != b)
+    assert outs[0].splitlines()[0] == "sizeof 24 248 80 24 80 24"
