@@ -439,6 +439,7 @@ struct Seg {
 	int32_t i, rs, qs, re, qe, bw1;
 	int job1 = -1, job2 = -1, zcode = -1, ll_job = -1;
 	int walk = 0;                       // z-drop walk: 0 not asked, 1 asked, 2 answered
+	bool ll_deferred = false;           // the inversion query only decides split_inv of a split-off region: nobody waits for it here
 	int32_t max_zdrop = 0, wt0 = -1, wt1 = -1, wq0 = -1, wq1 = -1;
 };
 
@@ -459,6 +460,7 @@ struct RegTask {
 	int inv_state = 0;      // 0 = not evaluated, 1 = waiting for its DP problem, 2 = resolved, 3 = waiting for the local-alignment query
 	int inv_ll_job = -1;
 	int inv_job = -1; int32_t inv_q_off = 0, inv_t_off = 0, inv_ql = 0, inv_tl = 0;
+	int split_inv_ll = -1;  // >= 0: r.split_inv is still to be read off this local-alignment query (mm_test_zdrop's return code 2, align.c:78-86,781)
 };
 
 struct WalkAsk { RegTask *T; size_t seg; };
@@ -481,6 +483,7 @@ struct Driver {
 	const SeqSet &S; const mm_mapopt_t &opt; int k; hipStream_t st;
 	int8_t mat[25];
 	int probe_m_max = -1;             // identity probes: (a+b)*m < a + 2*min(q+e, q2+e2)  <=>  m <= probe_m_max; -1: probes off
+	int spec_len = getenv("PGA_SPEC_LEN") ? atoi(getenv("PGA_SPEC_LEN")) : 1500;   // segments at least this long get their second pass speculatively (0: never)
 	Driver(const SeqSet &S_, const mm_mapopt_t &o, int k_, hipStream_t st_) : S(S_), opt(o), k(k_), st(st_)
 	{
 		const int a = std::abs(o.a), b = -std::abs(o.b), amb = -std::abs(o.sc_ambi);     // align.c:9-22
@@ -599,6 +602,11 @@ struct Driver {
 				if (A.flagged(as1 + i, A_LONG_JOIN)) sg.bw1 = std::max(qe - qs, re - rs);
 				const bool probe = qe - qs == re - rs && sg.bw1 >= qe - qs;
 				sg.job1 = request(Q, T.rev, T.rid, qs, qe - qs, rs, re - rs, 0, sg.bw1, -1, opt.zdrop, DP_APPROX_MAX, probe);
+				// a long segment without seeds is where chains break: its exact second pass (needed whenever the z-drop test fires,
+				// with the same parameters whatever the test's return code when both thresholds agree) is launched WITH the first
+				// pass instead of a round later -- one dependent round less per split, the extra problem runs on idle CUs
+				if (!probe && spec_len > 0 && opt.zdrop == opt.zdrop_inv && std::max(qe - qs, re - rs) >= spec_len && !have(Q, sg.job1))
+					sg.job2 = second_pass(Q, T, sg, opt.zdrop);
 				T.segs.push_back(sg);
 				rs = re, qs = qe;
 			}
@@ -635,8 +643,9 @@ struct Driver {
 	}
 
 	// ---- advance: returns true when the region is complete; r2 receives a split-off region (cnt>0), also on a `false` return ----
-	bool advance(QueryCtx &Q, RegTask &T, Reg &r2)
+	bool advance(QueryCtx &Q, RegTask &T, Reg &r2, int &r2_split_inv_ll)
 	{
+		r2_split_inv_ll = -1;
 		Reg &r = T.r; const Anchors A{Q.a.data(), Q.n_a}; const int32_t qlen = Q.qlen;
 		r2.cnt = 0;
 		if (T.done) return true;
@@ -673,14 +682,17 @@ struct Driver {
 					else if (ll_on_device(opt, q_len, t_len)) {
 						// the window against its own reverse complement: query = the other strand, [L - (qs+wq1), +q_len)
 						sg.ll_job = request(Q, 1 - T.rev, T.rid, qlen - (sg.qs + sg.wq1), q_len, sg.rs + sg.wt0, t_len, 0, 0, -1, 0, PGA_JOB_LL);
-						// whatever the answer, the second pass runs when both thresholds agree (they do in every asm preset)
-						if (opt.zdrop == opt.zdrop_inv) sg.job2 = second_pass(Q, T, sg, opt.zdrop);
+						// whatever the answer, the second pass runs when both thresholds agree (they do in every asm preset): the return
+						// code is 1 or 2 (max_zdrop > zdrop_inv == zdrop), and 2 only sets split_inv of the piece split off here --
+						// so this region goes on with the second pass and leaves the query's answer to that piece
+						if (opt.zdrop == opt.zdrop_inv) { if (sg.job2 < 0) sg.job2 = second_pass(Q, T, sg, opt.zdrop); sg.zcode = 1; sg.ll_deferred = true; }
 					} else {
 						int q_end, t_end;
 						sg.zcode = zcode_of(sg, ll_on_host(Q, 1 - T.rev, qlen - (sg.qs + sg.wq1), q_len, T.rid, sg.rs + sg.wt0, t_len, false, &q_end, &t_end));
 					}
 				}
 				if (sg.zcode > 0 && sg.job2 < 0) sg.job2 = second_pass(Q, T, sg, sg.zcode == 2 ? opt.zdrop_inv : opt.zdrop);
+				if (sg.ll_deferred && !have(Q, sg.job2)) return false;
 			}
 			if (sg.zcode < 0) {
 				if (!have(Q, sg.ll_job)) return false;
@@ -700,7 +712,7 @@ struct Driver {
 				T.re1 = sg.rs + (ez.max_t + 1), T.qe1 = sg.qs + (ez.max_q + 1);
 				if (T.cnt1 - (j + 1) >= opt.min_cnt) {
 					cut_region(r, r2, T.as1 + j + 1 - r.as, qlen, A);
-					if (r2.cnt > 0 && sg.zcode == 2) r2.split_inv = 1;
+					if (r2.cnt > 0) { if (sg.ll_deferred) r2_split_inv_ll = sg.ll_job; else if (sg.zcode == 2) r2.split_inv = 1; }
 				}
 				break;
 			} else r.dp_score += ez.score;
@@ -883,10 +895,16 @@ struct RoundRunner {
 				if (T.is_inv) { if (!T.done) { if (T.fin == 2) T.done = true; else waiting = true; } continue; }
 				if (!T.planned) D.plan(q, T);
 				if (!T.done) {
-					Reg r2;
-					const bool complete = D.advance(q, T, r2);
-					if (r2.cnt > 0) { q.pool.emplace_back(new RegTask()); q.pool.back()->r = r2; q.list.insert(q.list.begin() + (long)i + 1, q.pool.back().get()); }
+					Reg r2; int r2_ll = -1;
+					const bool complete = D.advance(q, T, r2, r2_ll);
+					if (r2.cnt > 0) { q.pool.emplace_back(new RegTask()); q.pool.back()->r = r2; q.pool.back()->split_inv_ll = r2_ll; q.list.insert(q.list.begin() + (long)i + 1, q.pool.back().get()); }
 					if (!complete) { waiting = true; continue; }
+				}
+				if (T.split_inv_ll >= 0) {             // the inversion query of the split that made this piece: its answer is split_inv
+					if (!Driver::have(q, T.split_inv_ll)) { waiting = true; continue; }
+					const int sc = q.res[(size_t)T.split_inv_ll].score;
+					T.r.split_inv = (sc >= opt.min_chain_score * opt.a && sc >= opt.min_dp_max) ? 1 : 0;
+					T.split_inv_ll = -1;
 				}
 				if (i > 0 && T.r.split_inv && !(opt.flag & MM_F_NO_INV) && T.inv_state != 2) {
 					if (waiting) continue;   // an earlier element is still open: decide later

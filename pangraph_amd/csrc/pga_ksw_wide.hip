@@ -44,6 +44,8 @@ __device__ __forceinline__ void diag_range_w(int r, int qlen, int tlen, int w, i
 	st0 = st, en0 = en;
 }
 
+__device__ int g_wide_no_fused = 0;   // PGA_NO_FUSED_APPROX=1 (A/B): the unbanded approximate passes take the general loop
+
 template <int WIDE_NT>
 __global__ __launch_bounds__(WIDE_NT)
 void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
@@ -54,6 +56,7 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 	__shared__ uint32_t s_job;
 	__shared__ long long s_part[WIDE_NT / 64];
 	__shared__ int s_hprev;
+	__shared__ int s_h0v[2], s_h0u[2];   // fused approximate path: v of the tracked column and u of its right neighbour, by diagonal parity
 	__builtin_amdgcn_s_setprio(3);      // few, latency-bound workgroups: win issue arbitration against the tile kernels sharing the CU
 	__shared__ uint8_t s_win[WBT * WBT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,6 +129,84 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 
 		int base = 0;                                       // multiple of R with base <= st-16: slot(t) = t-base (-R)
 		int pend_slot = -1, pend_val = 0;
+		// ---- unbanded approximate first passes (the 10 kb x 10 kb gap fills across rearrangements): ONE barrier per diagonal ----
+		// Same packed two-column cell pass as below, but the score bytes are formed inside it (no separate profile pass), the first-row
+		// values of the column that joins on this diagonal are taken by its owner directly (no store by thread 0 in front of a
+		// barrier), and the two values the running corner score needs (v of the tracked column, u of its right neighbour) travel
+		// through a parity-buffered mailbox.  What is left between two diagonals is the one barrier that orders the row arrays.
+		const bool fused = packed_ok && swar_profile && approx_max && !(flag & EZ_APPROX_DROP) && !g_wide_no_fused;
+		if (fused) {
+			const s2_t ZERO = splat2(0), ONE = splat2(1), MCH = splat2(sc_mch), Q1 = splat2(q), Q2 = splat2(q2), QE = splat2(qe), QE2 = splat2(qe2);
+			const s2_t EIGHT = splat2(8), C16 = splat2(16), C32 = splat2(32), C64 = splat2(64);
+			for (int r = 0; r < n_diag; ++r) {
+				r_done = r + 1;
+				int st0, en0;
+				diag_range_w(r, qlen, tlen, w, st0, en0);
+				const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+				const int8_t *xr = xb[r & 1], *vr = vb[r & 1], *x2r = x2b[r & 1];
+				int8_t *xw = xb[(r + 1) & 1], *vw = vb[(r + 1) & 1], *x2w = x2b[(r + 1) & 1];
+				int x1, x21, v1;
+				if (st > 0) {
+					if (st - 1 >= last_st && st - 1 <= last_en) { x1 = xr[st - 1], x21 = x2r[st - 1], v1 = vr[st - 1]; }
+					else x1 = sx8w(-q - e), x21 = sx8w(-q2 - e2), v1 = sx8w(-q - e);
+				} else {
+					x1 = sx8w(-q - e), x21 = sx8w(-q2 - e2);
+					v1 = r == 0 ? sx8w(-q - e) : r < long_thres ? sx8w(-e) : r == long_thres ? sx8w(long_diff) : sx8w(-e2);
+				}
+				const int u_join = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;   // first-row u of column r
+				const int off_r = 32 + qlen - 1 - r;
+				const int h0t = r == 0 ? 0 : last_H0_t;
+				uint8_t *prow = pmat + (size_t)r * n_col - st;
+				for (int t = st + 2 * tid; t <= en; t += 2 * WIDE_NT) {
+					const int xl = t == st ? x1 : (int)xr[t - 1], vl = t == st ? v1 : (int)vr[t - 1], x2l = t == st ? x21 : (int)x2r[t - 1];
+					const s2_t xt1 = pack2(xl, (int)xr[t]), vt1 = pack2(vl, (int)vr[t]), x2t1 = pack2(x2l, (int)x2r[t]);
+					s2_t ut = unpack_i8x2(*reinterpret_cast<const uint16_t*>(u + t)), yt = unpack_i8x2(*reinterpret_cast<const uint16_t*>(y + t));
+					s2_t y2t = unpack_i8x2(*reinterpret_cast<const uint16_t*>(y2 + t));
+					if (t == r) { ut.x = (short)u_join; yt.x = (short)(-q - e); y2t.x = (short)(-q2 - e2); }
+					else if (t + 1 == r) { ut.y = (short)u_join; yt.y = (short)(-q - e); y2t.y = (short)(-q2 - e2); }
+					s2_t z;
+					{
+						const int a0 = tq[t], a1 = tq[t + 1], b0 = qq[t + off_r], b1 = qq[t + 1 + off_r];
+						z.x = (short)(((a0 | b0) & 4) ? sc_N : a0 == b0 ? sc_mch : sc_mis);
+						z.y = (short)(((a1 | b1) & 4) ? sc_N : a1 == b1 ? sc_mch : sc_mis);
+					}
+					s2_t a = xt1 + vt1, b = yt + ut, a2 = x2t1 + vt1, b2 = y2t + ut;
+					const s2_t zm = pmax(pmax(pmax(z, a), pmax(b, a2)), b2);
+					s2_t d;
+					{
+						const s2_t n0 = pminu(zm - z, ONE), n1 = pminu(zm - a, ONE), n2 = pminu(zm - b, ONE), n3 = pminu(zm - a2, ONE);
+						d = n0 * (ONE + n1 * (ONE + n2 * (ONE + n3)));
+					}
+					z = pmin(zm, MCH);
+					const s2_t un = z - vt1, vn = z - ut;
+					s2_t tmp = z - Q1; a = a - tmp; b = b - tmp;
+					tmp = z - Q2; a2 = a2 - tmp; b2 = b2 - tmp;
+					s2_t xn, yn, x2n, y2n;
+					{ const s2_t m = pmax(a, ZERO);  xn  = m - QE;  d = d + pmin(m, ONE) * EIGHT; }
+					{ const s2_t m = pmax(b, ZERO);  yn  = m - QE;  d = d + pmin(m, ONE) * C16; }
+					{ const s2_t m = pmax(a2, ZERO); x2n = m - QE2; d = d + pmin(m, ONE) * C32; }
+					{ const s2_t m = pmax(b2, ZERO); y2n = m - QE2; d = d + pmin(m, ONE) * C64; }
+					const uint16_t un8 = pack_i8x2(un), vn8 = pack_i8x2(vn);
+					*reinterpret_cast<uint16_t*>(u + t) = un8; *reinterpret_cast<uint16_t*>(vw + t) = vn8;
+					*reinterpret_cast<uint16_t*>(xw + t) = pack_i8x2(xn); *reinterpret_cast<uint16_t*>(y + t) = pack_i8x2(yn);
+					*reinterpret_cast<uint16_t*>(x2w + t) = pack_i8x2(x2n); *reinterpret_cast<uint16_t*>(y2 + t) = pack_i8x2(y2n);
+					*reinterpret_cast<uint16_t*>(prow + t) = pack_i8x2(d);
+					// the stored int8 values (what the corner tracker reads back)
+					if (t == h0t) s_h0v[r & 1] = (int)(int8_t)(vn8 & 0xff); else if (t + 1 == h0t) s_h0v[r & 1] = (int)(int8_t)(vn8 >> 8);
+					if (t == h0t + 1) s_h0u[r & 1] = (int)(int8_t)(un8 & 0xff); else if (t + 1 == h0t + 1) s_h0u[r & 1] = (int)(int8_t)(un8 >> 8);
+				}
+				__syncthreads();
+				if (r > 0) {
+					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+						const int d0 = s_h0v[r & 1], d1 = s_h0u[r & 1];
+						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += s_h0v[r & 1];
+					else ++last_H0_t, H0 += s_h0u[r & 1];
+				} else H0 = s_h0v[0] - qe_h, last_H0_t = 0;
+				if (r == n_diag - 1 && en0 == tlen - 1) ez_score = H0;
+				last_st = st, last_en = en;
+			}
+		} else
 		for (int r = 0; r < n_diag; ++r) {
 			r_done = r + 1;
 			if (pend_slot >= 0) { if (tid == 0) H[pend_slot] = pend_val; pend_slot = -1; }   // last diagonal's H[en0] (nobody reads H before two more barriers)
@@ -417,6 +498,8 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
 	const size_t lds = wide_lds_bytes(r_cap, seq_cap, exact);
+	static const bool no_fused = [] { const bool off = getenv("PGA_NO_FUSED_APPROX") != nullptr; if (off) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_no_fused), &one, sizeof(int)); } return off; }();
+	(void)no_fused;
 	if (n_threads >= 1024) launch_wide_nt<1024>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
 	else if (n_threads >= 512) launch_wide_nt<512>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
 	else launch_wide_nt<256>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);

@@ -249,7 +249,8 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 //     new[i_t] = old[q_t]      new[h_t] = old[i_t]      new[p + 1] = old[p] for the B records p in [h_t, q_t)      everything else stays
 // -- three coalesced passes with two running counts instead of one dependent step per record.  `tmp` receives the new arrangement
 // (same length as the run), idx holds the 2m positions i_t, q_t (one word per record is enough: m <= n/2).
-__device__ inline void rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA, uint32_t cA, u128 *tmp, uint32_t *idx, int lane)
+// Returns false (nothing moved) when only a few records are out of place: the walk skips home records 64 at a time and is faster then.
+__device__ inline bool rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA, uint32_t cA, u128 *tmp, uint32_t *idx, int lane)
 {
 	const unsigned long long lt = (1ULL << lane) - 1;
 	// pass 1: positions of the misplaced records: I[t] = idx[t], Q[t] = idx[m + t]; m is not known yet, so Q is written from the back
@@ -269,6 +270,7 @@ __device__ inline void rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA
 	}
 	rs_fence_wg();
 	const uint32_t m = mA;                                        // == mB
+	if ((uint64_t)m * 16 < (uint64_t)n) return false;
 	auto Qat = [&](uint32_t t) { return idx[(uint32_t)n - 1 - t]; };
 	// pass 2: the new arrangement, out of place
 	uint32_t tA = 0, tB = 0;
@@ -308,6 +310,7 @@ __device__ inline void rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA
 		for (int k = 0; k < 4; ++k) { const int64_t p = c0 + lane + 64 * k; if (p < n) beg[p] = v[k]; }
 	}
 	rs_fence_wg();
+	return true;
 }
 
 __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4], uint32_t *rend = nullptr, u128 *tmp = nullptr)
@@ -341,8 +344,7 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 		int dA = -1; uint32_t cA = 0;
 #pragma unroll
 		for (int k = 3; k >= 0; --k) if (nonempty[k]) { const int l = __ffsll((long long)nonempty[k]) - 1; dA = l + 64 * k; cA = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k], l); }
-		rs_level_two(beg, n, shift, (uint32_t)dA, cA, tmp, rend, lane);
-		return true;
+		if (rs_level_two(beg, n, shift, (uint32_t)dA, cA, tmp, rend, lane)) return true;
 	}
 	if (rend && n >= 4096) {
 		// digit runs of the original order, back to front: rend[p] = first position after p whose digit differs
