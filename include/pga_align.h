@@ -49,7 +49,8 @@ typedef struct {                 /* stage wall times (s) and work counters of a 
 	 * [0] k_sketch_tiles  [1] k_chain_fast (+k_chain_segments)  [2] k_bt_list + k_bt_walk  [3] k_extd2_fast (register tiles)
 	 * [4] k_extd2_wide<256>  [5] k_ll_i16  [6] k_rs_init + k_rs_pass + k_rs_small (sort replay)  [7] k_gapfill_band (corridor gap fills)
 	 * [8] k_extd2_wide<512>  [9] k_extd2_wide<1024>  [10] index build (device sorts + CSR kernels)  [11] seeding kernels + anchor sort
-	 * [12..15] unused.  kern_cells: DP cells evaluated by the DP kernels ([3] [4] [5] [7] [8] [9]), 0 elsewhere */
+	 * [12] k_approx_strips (large unbanded gap fills over several workgroups)  [13..15] unused.
+	 * kern_cells: DP cells evaluated by the DP kernels ([3] [4] [5] [7] [8] [9] [12]), 0 elsewhere */
 	double kern_ms[16], kern_launches[16], kern_alg_bytes[16], kern_cells[16];
 	double aligned_span;         /* sum of (qry_end - qry_start) over the emitted matches (secondary metric) */
 } pga_stats_t;

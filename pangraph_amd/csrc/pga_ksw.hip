@@ -346,9 +346,10 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //   6      local-alignment score queries of the inversion test (pga_ll.hip)
 //   8      first-pass gap fills of nearly equal length: corridor kernel with an exactness proof per problem (pga_ksw_band.hip);
 //          the few it cannot prove come back flagged and take their normal class in a second pass
+//   9      large unbanded first-pass gap fills, one problem spread over several workgroups in column strips (pga_ksw_strips.hip)
 //   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
 //          first passes of class 4 keep room for their sequences in LDS)
-#define DP_NCLASS 9
+#define DP_NCLASS 10
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -367,9 +368,17 @@ size_t band_slab_bytes(int max_diag);
 void launch_gapfill_band(unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                          DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
-static int dp_class(const DpJob &j, bool allow_band)
+bool strips_eligible(const DpJob &j, const DpParams &P);
+size_t strips_slab_bytes(const DpJob &j);
+int strips_count(const DpJob &j);
+size_t strips_bnd_words(const DpJob &j);
+void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, const uint8_t *nt4, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
+                          uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
+
+static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
 {
 	if (j.flag & PGA_JOB_LL) return 6;
+	if (strips_eligible(j, P)) return 9;
 	if (allow_band && j.flag == EZ_APPROX_MAX && j.w >= j.qlen && j.w >= j.tlen && j.qlen >= 1 && j.tlen >= 1 && j.qlen <= BAND_MAXLEN && j.tlen <= BAND_MAXLEN &&
 	    j.tlen - j.qlen <= 12 && j.qlen - j.tlen <= 12) return 8;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
@@ -469,8 +478,8 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	host_parallel(n, [&](size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
 			const bool is_ll = jobs[i].flag & PGA_JOB_LL;
-			cls_of[i] = (uint8_t)dp_class(jobs[i], allow_band);
-			need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : cls_of[i] == 8 ? band_slab_bytes(jobs[i].qlen + jobs[i].tlen) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
+			cls_of[i] = (uint8_t)dp_class(jobs[i], allow_band, P);
+			need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : cls_of[i] == 8 ? band_slab_bytes(jobs[i].qlen + jobs[i].tlen) : cls_of[i] == 9 ? strips_slab_bytes(jobs[i]) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
 		}
 	});
 	{
@@ -513,9 +522,10 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
-	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1; };
+	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
+	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd; DBuf<uint64_t> d_slab_off, d_bnd_off; };   // (class 9: block tables, strip boundaries)
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
 	// scratch budget per class: a slab is n_waves x the largest problem of the class, and n_waves is halved until it fits.  24 GB keeps
@@ -537,6 +547,12 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		size_t n_waves = c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
+		if (c == 9) {                                                                   // every problem of the class is in flight at once, each with its whole matrix
+			size_t tot = 0; for (uint32_t id : cls[c]) tot += need[id];
+			waves_of[c] = cls[c].size();
+			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], tot);
+			continue;
+		}
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
 		waves_of[c] = n_waves;
 		lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], n_waves * slab_max[c]);
@@ -554,7 +570,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
-	static const int launch_order[DP_NCLASS] = {7, 6, 5, 4, 3, 2, 8, 1, 0};
+	static const int launch_order[DP_NCLASS] = {9, 7, 6, 5, 4, 3, 2, 8, 1, 0};
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
 		if (cls[c].empty()) continue;
@@ -570,7 +586,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
 		X.d_jobs.alloc(ids.size());
 		X.d_r.alloc(ids.size());
-		X.d_cnt.alloc(1);
+		X.d_cnt.alloc(c == 9 ? ids.size() : 1);                // (class 9: one completion counter per problem)
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
@@ -578,10 +594,23 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
 		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
-		PGA_HIP(hipMemsetAsync(X.d_cnt.p, 0, sizeof(uint32_t), cs));
+		PGA_HIP(hipMemsetAsync(X.d_cnt.p, 0, sizeof(uint32_t) * X.d_cnt.n, cs));
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
-		if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		if (c == 9) {
+			std::vector<uint32_t> bj, bs; std::vector<uint64_t> so(ids.size()), bo(ids.size());
+			uint64_t s_acc = 0, b_acc = 0;
+			for (size_t i = 0; i < ids.size(); ++i) {
+				const DpJob &j = jobs[ids[i]];
+				so[i] = s_acc; s_acc += need[ids[i]];
+				bo[i] = b_acc; b_acc += strips_bnd_words(j);
+				for (int k2 = 0; k2 < strips_count(j); ++k2) { bj.push_back((uint32_t)i); bs.push_back((uint32_t)k2); }
+			}
+			X.d_blk_job.upload(bj, cs); X.d_blk_strip.upload(bs, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs);
+			X.d_bnd.alloc((size_t)b_acc + 1); X.d_bnd.zero(cs);
+			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
+			launch_approx_strips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_nt4, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
 			int t_cap = 16;
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
@@ -633,6 +662,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 					const DpJob &j = jobs[ids[i]];
 					bases += (double)j.qlen + j.tlen;
 					if (c == 8) cells += 32.0 * (double)(j.qlen + j.tlen - 1);
+					else if (c == 9) cells += (double)j.qlen * j.tlen;
 					else if (c == 6) cells += (double)((j.qlen + 7) / 8 * 8) * j.tlen;
 					else if (c <= 1) cells += r[i].pad == 0x5A ? 0.0 : (double)j.qlen * j.tlen;
 					else {
@@ -651,7 +681,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 				part_b[(size_t)s] += bases; part_c[(size_t)s] += cells;
 			});
 			double bases = 0, cells = 0; for (double x : part_b) bases += x; for (double x : part_c) cells += x;
-			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
+			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c == 9 ? K_STRIPS : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->kern[kk].cells += cells; tm->dp_bases += bases;
 		}
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });

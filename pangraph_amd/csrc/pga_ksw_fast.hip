@@ -377,19 +377,33 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		{
 			int i = bi, j = bj, state = 0;
 			uint32_t last_op = 0xffffffffu;
+			uint32_t run_len = 0;                               // the operation being extended lives in registers: one store per operation, not a
+			auto cg_push = [&](uint32_t op, uint32_t len) {     // read-modify-write of device memory per path step
+				if (op == last_op) { run_len += len; return; }
+				if (last_op != 0xffffffffu) { if (lane == 0) cig_tmp[n_cigar] = run_len << 4 | last_op; ++n_cigar; }
+				last_op = op; run_len = len;
+			};
+			auto cg_flush = [&] { if (last_op != 0xffffffffu && n_cigar >= 0) { if (lane == 0) cig_tmp[n_cigar] = run_len << 4 | last_op; ++n_cigar; last_op = 0xffffffffu; } };
 			uint32_t *cig = cig_tmp;
 			while (i >= 0 && j >= 0) {                                          // wave-uniform loop: every lane tracks (i,j,state)
 				if (++guard > 1000000) { n_cigar = -7; break; }                  // safety net: a stuck wave would take the GPU down
 				// window: rows r_hi-63 .. r_hi, target columns i-63 .. i (the path moves at most one column per step)
 				const int r_hi = i + j, c_lo = i - (BT_COLS - 1);
-				for (int row = 0; row < BT_ROWS; ++row) {
-					const int r = r_hi - row, col = c_lo + lane;
-					uint8_t val = 0;
-					if (r >= 0 && col >= 0) {
-						const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
-						if (col >= st0 && col <= en0) val = pmat[(size_t)r * n_col + (col - (st0 & ~15))];
+				{
+					// all rows of the window are requested before the first one is stored: 64 loads in flight instead of 64 round trips
+					uint8_t wv[BT_ROWS];
+#pragma unroll
+					for (int row = 0; row < BT_ROWS; ++row) {
+						const int r = r_hi - row, col = c_lo + lane;
+						uint8_t val = 0;
+						if (r >= 0 && col >= 0) {
+							const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
+							if (col >= st0 && col <= en0) val = pmat[(size_t)r * n_col + (col - (st0 & ~15))];
+						}
+						wv[row] = val;
 					}
-					s_win[row * BT_COLS + lane] = val;
+#pragma unroll
+					for (int row = 0; row < BT_ROWS; ++row) s_win[row * BT_COLS + lane] = wv[row];
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // single-wave block: LDS is in order, a fence replaces the barrier
 				// walk while the path stays inside the window
@@ -410,15 +424,15 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					if (state == 0) op = 0, --i, --j;
 					else if (state == 1 || state == 3) op = 2, --i;
 					else op = 1, --j;
-					if (op != last_op) { if (lane == 0) cig[n_cigar] = 1u << 4 | op; ++n_cigar; last_op = op; }
-					else if (lane == 0) cig[n_cigar - 1] += 1u << 4;
+					cg_push(op, 1u);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			}
 			if (bi >= 0 && bj >= 0) {
-				if (i >= 0) { if (2u != last_op) { if (lane == 0) cig[n_cigar] = (uint32_t)(i + 1) << 4 | 2u; ++n_cigar; last_op = 2; } else if (lane == 0) cig[n_cigar - 1] += (uint32_t)(i + 1) << 4; }
-				if (j >= 0) { if (1u != last_op) { if (lane == 0) cig[n_cigar] = (uint32_t)(j + 1) << 4 | 1u; ++n_cigar; last_op = 1; } else if (lane == 0) cig[n_cigar - 1] += (uint32_t)(j + 1) << 4; }
+				if (i >= 0) cg_push(2u, (uint32_t)(i + 1));
+				if (j >= 0) cg_push(1u, (uint32_t)(j + 1));
 			}
+			cg_flush();
 		}
 		unsigned long long base = 0;
 		if (lane == 0 && n_cigar > 0) base = atomicAdd(pool_cursor, (unsigned long long)n_cigar);

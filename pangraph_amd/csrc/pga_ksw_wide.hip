@@ -195,7 +195,8 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					if (t == h0t) s_h0v[r & 1] = (int)(int8_t)(vn8 & 0xff); else if (t + 1 == h0t) s_h0v[r & 1] = (int)(int8_t)(vn8 >> 8);
 					if (t == h0t + 1) s_h0u[r & 1] = (int)(int8_t)(un8 & 0xff); else if (t + 1 == h0t + 1) s_h0u[r & 1] = (int)(int8_t)(un8 >> 8);
 				}
-				__syncthreads();
+				// the barrier orders the LDS rows only: the direction bytes are fire-and-forget (fenced before the backtrack)
+				asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 				if (r > 0) {
 					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
 						const int d0 = s_h0v[r & 1], d1 = s_h0u[r & 1];
@@ -425,18 +426,32 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		if (wave == 0) {
 			int i = bi, j = bj, state = 0; long long guard = 0;
 			uint32_t last_op = 0xffffffffu;
+			uint32_t run_len = 0;                               // the operation being extended lives in registers: one store per operation, not a
+			auto cg_push = [&](uint32_t op, uint32_t len) {     // read-modify-write of device memory per path step
+				if (op == last_op) { run_len += len; return; }
+				if (last_op != 0xffffffffu) { if (lane == 0) cig_tmp[n_cigar] = run_len << 4 | last_op; ++n_cigar; }
+				last_op = op; run_len = len;
+			};
+			auto cg_flush = [&] { if (last_op != 0xffffffffu && n_cigar >= 0) { if (lane == 0) cig_tmp[n_cigar] = run_len << 4 | last_op; ++n_cigar; last_op = 0xffffffffu; } };
 			while (i >= 0 && j >= 0) {
 				if (++guard > 4000000) { n_cigar = -7; break; }
 				const int r_hi = i + j, c_lo = i - (WBT - 1);
-				for (int row = 0; row < WBT; ++row) {
-					const int r = r_hi - row, col = c_lo + lane;
-					uint8_t val = 0;
-					if (r >= 0 && col >= 0) {
-						int st0, en0; diag_range_w(r, qlen, tlen, w, st0, en0);
-						const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
-						if (st0 <= en0 && col >= off && col <= off_end) val = pmat[(size_t)r * n_col + (col - off)];
+				{
+					// all 64 rows of the window are requested before the first one is stored: 64 loads in flight instead of 64 round trips
+					uint8_t wv[WBT];
+#pragma unroll
+					for (int row = 0; row < WBT; ++row) {
+						const int r = r_hi - row, col = c_lo + lane;
+						uint8_t val = 0;
+						if (r >= 0 && col >= 0) {
+							int st0, en0; diag_range_w(r, qlen, tlen, w, st0, en0);
+							const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
+							if (st0 <= en0 && col >= off && col <= off_end) val = pmat[(size_t)r * n_col + (col - off)];
+						}
+						wv[row] = val;
 					}
-					s_win[row * WBT + lane] = val;
+#pragma unroll
+					for (int row = 0; row < WBT; ++row) s_win[row * WBT + lane] = wv[row];
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 				while (i >= 0 && j >= 0) {
@@ -456,15 +471,15 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 					if (state == 0) op = 0, --i, --j;
 					else if (state == 1 || state == 3) op = 2, --i;
 					else op = 1, --j;
-					if (op != last_op) { if (lane == 0) cig_tmp[n_cigar] = 1u << 4 | op; ++n_cigar; last_op = op; }
-					else if (lane == 0) cig_tmp[n_cigar - 1] += 1u << 4;
+					cg_push(op, 1u);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			}
 			if (bi >= 0 && bj >= 0 && n_cigar >= 0) {
-				if (i >= 0) { if (2u != last_op) { if (lane == 0) cig_tmp[n_cigar] = (uint32_t)(i + 1) << 4 | 2u; ++n_cigar; last_op = 2; } else if (lane == 0) cig_tmp[n_cigar - 1] += (uint32_t)(i + 1) << 4; }
-				if (j >= 0) { if (1u != last_op) { if (lane == 0) cig_tmp[n_cigar] = (uint32_t)(j + 1) << 4 | 1u; ++n_cigar; last_op = 1; } else if (lane == 0) cig_tmp[n_cigar - 1] += (uint32_t)(j + 1) << 4; }
+				if (i >= 0) cg_push(2u, (uint32_t)(i + 1));
+				if (j >= 0) cg_push(1u, (uint32_t)(j + 1));
 			}
+			cg_flush();
 			unsigned long long base = 0;
 			if (lane == 0 && n_cigar > 0) base = atomicAdd(pool_cursor, (unsigned long long)n_cigar);
 			base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), 0) << 32) | (unsigned)__shfl((int)(base & 0xffffffffULL), 0);
