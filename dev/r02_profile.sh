@@ -5,7 +5,7 @@
 TAG=${1:-x}
 export TMPDIR=/tmp
 R=$PWD
-mkdir -p gpurun_out profiles
+mkdir -p gpurun_out profiles gpurun_out/profiles_out
 ( cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r02 -o r02 -- python $R/bench.py --cpu-budget 0 --steps 1 --warmup 1 > $R/gpurun_out/r02_bench_prof.json 2> $R/gpurun_out/r02_bench_prof.err ); echo "prof rc=$?"
 f=$(find gpurun_out/prof_r02 -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" profiles/r02_${TAG}_c5_kernel_stats.csv
@@ -34,4 +34,6 @@ json.dump(out, open("profiles/r02_${TAG}_pmc_hbm_traffic_c5.json", "w"), indent=
 PY
 find gpurun_out/pmc_* -name "*.csv" -size +20M -delete
 fi
+# profiles/ on the GPU box is not merged back: hand the artifacts over through gpurun_out/
+cp profiles/r02_${TAG}_* gpurun_out/profiles_out/ 2>/dev/null
 head -25 profiles/r02_${TAG}_c5_kernel_stats.csv | cut -c1-200
