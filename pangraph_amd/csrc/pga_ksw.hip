@@ -378,7 +378,9 @@ void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *
                           uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 bool lanes_eligible(const DpJob &j);
-void launch_extd2_lanes(unsigned n_blocks, int q_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+size_t lanes_cig_bytes(int q_cap, int t_cap);
+size_t lanes_chunk_bytes();
+void launch_extd2_lanes(unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
@@ -391,7 +393,7 @@ static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
-	if (!no_lanes && lanes_eligible(j)) return 10;
+	if (!no_lanes && allow_band && lanes_eligible(j)) return 10;      // (allow_band is off in the second pass over problems a kernel handed back)
 	const size_t rows = (size_t)14 * wide_ring(j), l = rows + 2 * (size_t)wide_seqcap(j);
 	if (l <= 48 * 1024) return 2;
 	if (l <= 76 * 1024) return 3;
@@ -461,7 +463,7 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	std::vector<uint32_t> redo;
 	for (size_t i = 0; i < res.size(); ++i) if (res[i].n_cigar == -9) redo.push_back((uint32_t)i);
 	if (redo.empty()) return;
-	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     corridor kernel: %zu of %zu problems not proven, full matrix\n", redo.size(), jobs.size());
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     corridor / lane kernels: %zu of %zu problems handed back, workgroup kernel\n", redo.size(), jobs.size());
 	std::vector<DpJob> jb(redo.size());
 	for (size_t k = 0; k < redo.size(); ++k) jb[k] = jobs[redo[k]];
 	std::vector<DpRes> r2; PinVec<uint32_t> c2;
@@ -549,6 +551,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// scratch slabs: one grow-only buffer per launch lane (classes of a lane run one after the other and share it); sized
 	// before anything is launched so that no buffer moves under a running kernel
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
+	uint32_t lanes_pool_chunks = 0;
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
 		static const int c8w = getenv("PGA_C8_WAVES") ? atoi(getenv("PGA_C8_WAVES")) : 16;
@@ -559,6 +562,19 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			size_t tot = 0; for (uint32_t id : cls[c]) tot += need[id];
 			waves_of[c] = cls[c].size();
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], tot);
+			continue;
+		}
+		if (c == 10) {
+			// one CIGAR buffer per workgroup + a pool of direction-matrix chunks: what the class would need if every problem ran to its
+			// last diagonal, but not more than half of the budget (most extensions z-drop early; a dry pool hands problems back)
+			int q_cap = 16, t_cap = 16; size_t tot = 0;
+			for (uint32_t id : cls[c]) { q_cap = std::max(q_cap, jobs[id].qlen); t_cap = std::max(t_cap, jobs[id].tlen); tot += need[id] + lanes_chunk_bytes(); }
+			const size_t cigb = n_waves * lanes_cig_bytes(q_cap, t_cap);
+			size_t pool = std::min(tot, std::max(budget / 2, 4 * n_waves * lanes_chunk_bytes()));
+			pool = std::max(pool, 2 * n_waves * lanes_chunk_bytes()) / lanes_chunk_bytes() * lanes_chunk_bytes();
+			lanes_pool_chunks = (uint32_t)(pool / lanes_chunk_bytes());
+			waves_of[c] = n_waves;
+			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], cigb + pool + 256);
 			continue;
 		}
 		while (n_waves > 1 && n_waves * slab_max[c] > budget) n_waves /= 2;
@@ -594,7 +610,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
 		X.d_jobs.alloc(ids.size());
 		X.d_r.alloc(ids.size());
-		X.d_cnt.alloc(c == 9 ? ids.size() : 1);                // (class 9: one completion counter per problem)
+		X.d_cnt.alloc(c == 9 ? ids.size() : 2);               // (class 10: [1] is the cursor of its chunk pool)                // (class 9: one completion counter per problem)
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
@@ -625,9 +641,9 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
 		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 10) {
-			int q_cap = 16;
-			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen);
-			launch_extd2_lanes((unsigned)X.n_waves, q_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			int q_cap = 16, t_cap = 16;
+			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
+			launch_extd2_lanes((unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, lanes_pool_chunks, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }

@@ -25,6 +25,7 @@
 #include "pga_wave.h"
 #include "pga_pk16.h"
 #include <cstdio>
+#include <type_traits>
 
 namespace pga {
 
@@ -36,6 +37,8 @@ namespace pga {
 #define EZ_REV_CIGAR  0x80
 #define LBT 64
 #define LANES_C 8
+#define LANES_CHUNK (2u << 20)     // bytes of a direction-matrix chunk
+#define LANES_MAXCHUNK 64
 
 __device__ __forceinline__ void diag_range_l(int r, int qlen, int tlen, int w, int &st0, int &en0)
 {
@@ -47,19 +50,25 @@ __device__ __forceinline__ void diag_range_l(int r, int qlen, int tlen, int w, i
 	st0 = st, en0 = en;
 }
 
-__device__ __forceinline__ s2_t sx8p(s2_t v) { return v << 8 >> 8; }                       // int8 wrap-around of both halves
 __device__ __forceinline__ int sx8l(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
+// Packed 16-bit operations as the instructions themselves: written through the vector extensions, min(x, 1) * c and friends are
+// canonicalised into per-half compares and selects (three to five instructions where one v_pk_* does it).
+__device__ __forceinline__ s2_t k_max(s2_t a, s2_t b) { int r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(as_i(a)), "v"(as_i(b))); return as_s2(r); }
+__device__ __forceinline__ s2_t k_min(s2_t a, s2_t b) { int r; asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(as_i(a)), "v"(as_i(b))); return as_s2(r); }
+__device__ __forceinline__ s2_t k_minu(s2_t a, s2_t b) { int r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(as_i(a)), "v"(as_i(b))); return as_s2(r); }
+__device__ __forceinline__ s2_t k_mad(s2_t a, s2_t b, s2_t c) { int r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(as_i(a)), "v"(as_i(b)), "v"(as_i(c))); return as_s2(r); }
+__device__ __forceinline__ s2_t k_shr(s2_t sh, s2_t a) { int r; asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(as_i(sh)), "v"(as_i(a))); return as_s2(r); }
 
-struct LaneBox {              // cross-wave values of one diagonal (two copies, by diagonal parity)
-	long long part[8];        // per wave: best (H, tie order) key
+struct __attribute__((aligned(16))) LaneBox {              // cross-wave values of one diagonal (two copies, by diagonal parity)
+	uint32_t key[8];          // per wave: best packed (H, tie order, column) key of the diagonal
 	uint32_t nb[8];           // per wave: x, v, x2 of its last column (what lane 0 of the next wave reads on the next diagonal)
-	int hprev, u_en, v_en, h_en_old, h_st, h0v, h0u, pad;
+	int hprev, u_en, v_en, h_en_old, h_st, h0v, h0u, pad;      // (two aligned 16-byte groups: read back with two loads)
 };
 
 template <int NT>
 __global__ __launch_bounds__(NT)
 void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
-                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes, int q_cap,
+                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t cig_bytes, uint32_t n_chunks, int q_cap,
                    DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
 	constexpr int NW = NT / 64, C = LANES_C, RC = NT * C;
@@ -68,7 +77,14 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 	__shared__ LaneBox s_box[2];
 	__shared__ uint8_t s_win[LBT * LBT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint8_t *slab = slab_all + (size_t)blockIdx.x * slab_bytes;
+	// scratch: one CIGAR buffer per workgroup, then the pool of direction-matrix CHUNKS.  A workgroup takes chunks as its diagonals
+	// need them (most extensions z-drop after ~1.5 k diagonals and touch 2 MB of a matrix that would reserve 30 MB) and keeps them
+	// for its next problems; job_counter[1] is the pool's cursor.  An exhausted pool hands the problem back (n_cigar = -9).
+	uint32_t *cig_tmp = (uint32_t*)(slab_all + (size_t)blockIdx.x * cig_bytes);
+	uint8_t *pool_base = slab_all + (size_t)gridDim.x * cig_bytes;
+	__shared__ uint32_t s_chunk[LANES_MAXCHUNK];
+	__shared__ int s_have;
+	if (threadIdx.x == 0) s_have = 0;
 	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
 	const int qe_h = q + e;
 	if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t, t = e, e = e2, e2 = t; }
@@ -78,10 +94,11 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const uint32_t sc_tab = (uint32_t)(uint8_t)sc_mch | (uint32_t)(uint8_t)sc_mis << 8 | (uint32_t)(uint8_t)sc_N << 16 | (uint32_t)(uint8_t)sc_N << 24;
-	const s2_t ZERO = splat2(0), ONE = splat2(1), MCH = splat2(sc_mch), Q1 = splat2(q), Q2 = splat2(q2), QE = splat2(qe), QE2 = splat2(qe2);
-	const s2_t INI1 = splat2(sx8l(-q - e)), INI2 = splat2(sx8l(-q2 - e2));
+	const s2_t ZERO = splat2(0), ONE = splat2(1), FOUR = splat2(4), MCH = splat2(sc_mch << 8), Q1 = splat2(q << 8), Q2 = splat2(q2 << 8), QE = splat2(qe << 8), QE2 = splat2(qe2 << 8);
+	const s2_t C8 = splat2(8), C16 = splat2(16), C32 = splat2(32), C64 = splat2(64), C120 = splat2(120), C15 = splat2(15), CM8 = splat2(-8), CM16 = splat2(-16), CM32 = splat2(-32), CM64 = splat2(-64);
+	const s2_t INI1 = splat2((-q - e) << 8), INI2 = splat2((-q2 - e2) << 8);
 	const uint32_t nb_init = (uint32_t)(uint8_t)(-q - e) | (uint32_t)(uint8_t)(-q - e) << 8 | (uint32_t)(uint8_t)(-q2 - e2) << 16;
-	(void)q_cap;
+	uint8_t *tq = qq + ((q_cap + 15) & ~15);            // the target window: no global load (and so no vmcnt wait behind the direction stores) in the diagonal loop
 
 	for (;;) {
 		__syncthreads();
@@ -106,11 +123,31 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			return c < 4 ? 3 - c : 4;
 		};
 		for (int j = tid; j < qlen; j += NT) qq[j] = (uint8_t)query_at(j);
+		for (int i = tid; i < T + 8; i += NT) tq[i] = (uint8_t)target_at(i);
 		if (tid < NW) { s_box[1].nb[tid] = nb_init; s_box[0].nb[tid] = nb_init; }
-		uint8_t *pmat = slab;
-		uint32_t *cig_tmp = (uint32_t*)(pmat + (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15));
+		const int rpc = LANES_CHUNK / n_col;                   // diagonals per chunk
+		auto want_chunk = [&](int c) {                        // (thread 0) make sure chunk c of this problem exists
+			if (c < LANES_MAXCHUNK && c >= s_have) {
+				// the second half of the pool is reserved progressively for the workgroups with the lower indices (they hold the largest
+				// problems: the queue is sorted): when the pool runs dry the others give up early instead of everybody late
+				const uint32_t limit = n_chunks - (uint32_t)((unsigned long long)(n_chunks / 2) * blockIdx.x / gridDim.x);
+				uint32_t id = 0xffffffffu;
+				if (c < 2 || __hip_atomic_load(job_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < limit) {
+					id = atomicAdd(job_counter + 1, 1u);
+					if (id >= n_chunks) id = 0xffffffffu;
+				}
+				s_chunk[c] = id;
+				if (id != 0xffffffffu) s_have = c + 1;
+			}
+		};
+		if (tid == 0) { want_chunk(0); want_chunk(1); }
+		int row_c = 0, row_o = 0;                               // chunk and offset of the current diagonal
+		uint8_t *prow = nullptr;                                // its row of direction bytes (advanced behind the store)
 
 		// ---- the lane's block: eight columns in registers ----
+		// Every int8 of the reference is held as value << 8 in a 16-bit half (low byte zero): additions and subtractions then wrap
+		// exactly like the reference's epi8 arithmetic, signed maxima and minima order the same way, and no sign extension is ever
+		// needed.
 		s2_t X[4], V[4], X2[4], U[4], Y[4], Y2[4];
 		int H[8];
 		uint32_t S0 = 0, S1 = 0, TB0 = 0, TB1 = 0, W0 = 0, W1 = 0;
@@ -122,8 +159,8 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			for (int i = 0; i < 8; ++i) H[i] = KSW_NEG_INF;
 			S0 = S1 = 0;
 			const int t0 = blk * C;
-			TB0 = target_at(t0) | target_at(t0 + 1) << 8 | target_at(t0 + 2) << 16 | target_at(t0 + 3) << 24;
-			TB1 = target_at(t0 + 4) | target_at(t0 + 5) << 8 | target_at(t0 + 6) << 16 | target_at(t0 + 7) << 24;
+			TB0 = TB1 = 0;
+			if (t0 < T) { const uint2 tb = *reinterpret_cast<const uint2*>(tq + t0); TB0 = tb.x, TB1 = tb.y; }
 			// window bytes k = query[r_prev - k - t0]: what the shift at the top of diagonal r_prev + 1 expects
 			W0 = W1 = 0;
 #pragma unroll
@@ -141,6 +178,19 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
 		const int n_diag = qlen + tlen - 1;
 		int r_done = 0;
+		uint32_t q_next = tid == 0 && qlen > 0 ? (uint32_t)qq[0] : 0u;       // query[r - t0] of the first diagonal
+		auto col8 = [&](const s2_t (&A)[4], int i) -> int { return __builtin_amdgcn_sbfe(as_i(A[i >> 1]), (i & 1) ? 24 : 8, 8); };   // the int8 of column i
+
+		auto sel8 = [&](const int (&A)[8], int i) -> int {             // A[i], i lane-varying: three levels of selects
+			const int a0 = (i & 1) ? A[1] : A[0], a1 = (i & 1) ? A[3] : A[2], a2 = (i & 1) ? A[5] : A[4], a3 = (i & 1) ? A[7] : A[6];
+			const int b0 = (i & 2) ? a1 : a0, b1 = (i & 2) ? a3 : a2;
+			return (i & 4) ? b1 : b0;
+		};
+		auto col8v = [&](const s2_t (&A)[4], int i) -> int {
+			const int a0 = (i & 2) ? as_i(A[1]) : as_i(A[0]), a1 = (i & 2) ? as_i(A[3]) : as_i(A[2]);
+			return __builtin_amdgcn_sbfe((i & 4) ? a1 : a0, (i & 1) ? 24 : 8, 8);
+		};
+		int sat = 0;
 
 		for (int r = 0; r < n_diag; ++r) {
 			r_done = r + 1;
@@ -149,30 +199,34 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			if (st0 > en0) { ez_zdropped = 1; break; }
 			const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
 			const int span = ((en0 - st0) / 16 + 1) * 16;
+			if (row_o == 0) {
+				if (tid == 0) want_chunk(row_c + 1);                 // one chunk ahead: visible behind this diagonal's barrier
+				const uint32_t chunk_id = s_chunk[row_c];
+				if (chunk_id == 0xffffffffu) { sat = 1; break; }
+				prow = pool_base + (size_t)chunk_id * LANES_CHUNK;
+			}
+			if (++row_o == rpc) row_o = 0, ++row_c;
 			int need_hi = en > st0 + span - 1 ? en : st0 + span - 1;
 			if (need_hi > T - 1) need_hi = T - 1;
 			// a lane whose block fell out of the band on the left takes the block one ring further right (fresh rows)
-			if ((blk + NT) * C <= need_hi) { blk += NT; fresh(r - 1); }
+			if ((blk + NT) * C <= need_hi) { blk += NT; fresh(r - 1); const int j = r - blk * C; q_next = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u; }
 			const int t0 = blk * C;
 			LaneBox &bx = s_box[r & 1];
 			const LaneBox &bp = s_box[(r & 1) ^ 1];
-			// query byte of the block's first column
-			{
-				const int j = r - t0;
-				const uint32_t b = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u;
-				W1 = W1 << 8 | W0 >> 24; W0 = W0 << 8 | b;
-			}
-			// left neighbour: x, v, x2 of column t0-1 as the previous diagonal left them
-			const uint32_t mine = ((uint32_t)as_i(X[3]) >> 16 & 0xffu) | ((uint32_t)as_i(V[3]) >> 16 & 0xffu) << 8 | ((uint32_t)as_i(X2[3]) >> 16 & 0xffu) << 16;
+			// query byte of the block's first column (requested one diagonal ahead: its LDS latency hides behind the barrier)
+			W1 = W1 << 8 | W0 >> 24; W0 = W0 << 8 | q_next;
+			{ const int j = r + 1 - t0; q_next = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u; }
+			// left neighbour: x, v, x2 of column t0-1 as the previous diagonal left them (the int8 is the top byte of the block's last half)
+			const uint32_t mine = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
 			uint32_t inc = (uint32_t)wave_shr1((int)mine, 0);
 			if (lane == 0) inc = bp.nb[(wave + NW - 1) % NW];
-			int xin = sx8l((int)inc), vin = sx8l((int)(inc >> 8)), x2in = sx8l((int)(inc >> 16));
 			if (t0 == st) {
+				const uint32_t c1 = (uint32_t)(uint8_t)(-q - e), c2 = (uint32_t)(uint8_t)(-q2 - e2);
 				if (st > 0) {
-					if (!(st - 1 >= last_st && st - 1 <= last_en)) xin = sx8l(-q - e), x2in = sx8l(-q2 - e2), vin = sx8l(-q - e);
+					if (!(st - 1 >= last_st && st - 1 <= last_en)) inc = c1 | c1 << 8 | c2 << 16;
 				} else {
-					xin = sx8l(-q - e), x2in = sx8l(-q2 - e2);
-					vin = r == 0 ? sx8l(-q - e) : r < long_thres ? sx8l(-e) : r == long_thres ? sx8l(long_diff) : sx8l(-e2);
+					const uint32_t v1 = (uint32_t)(uint8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+					inc = c1 | v1 << 8 | c2 << 16;
 				}
 			}
 			// score bytes of the columns in [st0, st0+span) (the others keep what an earlier diagonal left there)
@@ -189,118 +243,137 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 				}
 			}
 			const bool act = t0 >= st && t0 <= en;
-			long long best = (long long)KSW_NEG_INF * 4294967296LL;
 			if (act) {
 				// the column that joins on this diagonal starts from the first-row values
 				if (en >= r && r >= t0 && r < t0 + 8) {
 					const int uj = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
 #pragma unroll
 					for (int p = 0; p < 4; ++p) {
-						if (t0 + 2 * p == r) { U[p].x = (short)sx8l(uj); Y[p].x = (short)sx8l(-q - e); Y2[p].x = (short)sx8l(-q2 - e2); }
-						if (t0 + 2 * p + 1 == r) { U[p].y = (short)sx8l(uj); Y[p].y = (short)sx8l(-q - e); Y2[p].y = (short)sx8l(-q2 - e2); }
+						if (t0 + 2 * p == r) { U[p].x = (short)(uj << 8); Y[p].x = (short)((-q - e) << 8); Y2[p].x = (short)((-q2 - e2) << 8); }
+						if (t0 + 2 * p + 1 == r) { U[p].y = (short)(uj << 8); Y[p].y = (short)((-q - e) << 8); Y2[p].y = (short)((-q2 - e2) << 8); }
 					}
 				}
-				int cx = xin << 16, cv = vin << 16, cx2 = x2in << 16;        // the left neighbour's values ride in the high half
+				// the left neighbour's values ride in the high half of the carry
+				int cx = (int)(inc << 24), cv = (int)(inc << 16 & 0xff000000u), cx2 = (int)(inc << 8 & 0xff000000u);
 				uint32_t dpk[4];
+				auto cells = [&](auto RIGHT) {
 #pragma unroll
-				for (int p = 0; p < 4; ++p) {
-					const int ox = as_i(X[p]), ov = as_i(V[p]), ox2 = as_i(X2[p]);
-					const s2_t xt1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox, (uint32_t)cx, 16));
-					const s2_t vt1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ov, (uint32_t)cv, 16));
-					const s2_t x2t1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox2, (uint32_t)cx2, 16));
-					cx = ox, cv = ov, cx2 = ox2;
-					const s2_t ut = U[p], yt = Y[p], y2t = Y2[p];
-					s2_t z = unpack_i8x2((p < 2 ? S0 >> (16 * p) : S1 >> (16 * (p - 2))) & 0xffffu);
-					s2_t a = sx8p(xt1 + vt1), b = sx8p(yt + ut), a2 = sx8p(x2t1 + vt1), b2 = sx8p(y2t + ut);
-					const s2_t zm = pmax(pmax(pmax(z, a), pmax(b, a2)), b2);
-					s2_t d;
-					{
-						const s2_t n0 = pminu(zm - z, ONE), n1 = pminu(zm - a, ONE), n2 = pminu(zm - b, ONE), n3 = pminu(zm - a2, ONE);
-						if (!right) d = n0 * (ONE + n1 * (ONE + n2 * (ONE + n3)));           // first of z, a, b, a2, b2 that attains the maximum
-						else {
-							const s2_t n4 = pminu(zm - b2, ONE);                                // last one that attains it
-							d = ONE - n1;
-							d = d * n2 + (ONE - n2) * splat2(2);
-							d = d * n3 + (ONE - n3) * splat2(3);
-							d = d * n4 + (ONE - n4) * splat2(4);
+					for (int p = 0; p < 4; ++p) {
+						const int ox = as_i(X[p]), ov = as_i(V[p]), ox2 = as_i(X2[p]);
+						const s2_t xt1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox, (uint32_t)cx, 16));
+						const s2_t vt1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ov, (uint32_t)cv, 16));
+						const s2_t x2t1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox2, (uint32_t)cx2, 16));
+						cx = ox, cv = ov, cx2 = ox2;
+						const s2_t ut = U[p], yt = Y[p], y2t = Y2[p];
+						const s2_t z0 = as_s2((int)__builtin_amdgcn_perm(0u, p < 2 ? S0 : S1, (p & 1) ? 0x030c020cu : 0x010c000cu));
+						s2_t a = xt1 + vt1, b = yt + ut, a2 = x2t1 + vt1, b2 = y2t + ut;
+						s2_t zm, d;
+						if constexpr (!decltype(RIGHT)::value) {
+							// the first of z, a, b, a2, b2 that attains the maximum = how many running maxima stay below it
+							const s2_t p1 = k_max(z0, a), p2 = k_max(p1, b), p3 = k_max(p2, a2);
+							zm = k_max(p3, b2);
+							d = k_minu(zm - z0, ONE) + k_minu(zm - p1, ONE) + k_minu(zm - p2, ONE) + k_minu(zm - p3, ONE);
+						} else {
+							// the last one that attains it = how many maxima over a suffix reach it
+							const s2_t s3 = k_max(a2, b2), s2 = k_max(b, s3), s1 = k_max(a, s2);
+							zm = k_max(z0, s1);
+							d = FOUR - (k_minu(zm - b2, ONE) + k_minu(zm - s3, ONE) + k_minu(zm - s2, ONE) + k_minu(zm - s1, ONE));
 						}
+						const s2_t z = k_min(zm, MCH);
+						const s2_t un = z - vt1, vn = z - ut;
+						s2_t tmp = z - Q1; a = a - tmp; b = b - tmp;
+						tmp = z - Q2; a2 = a2 - tmp; b2 = b2 - tmp;
+						const s2_t ma = k_max(a, ZERO), mb = k_max(b, ZERO), ma2 = k_max(a2, ZERO), mb2 = k_max(b2, ZERO);
+						if constexpr (!decltype(RIGHT)::value) {        // continuation bits: a > 0
+							d = k_mad(k_min(ma, ONE), C8, d); d = k_mad(k_min(mb, ONE), C16, d); d = k_mad(k_min(ma2, ONE), C32, d); d = k_mad(k_min(mb2, ONE), C64, d);
+						} else {                              // a >= 0: all of 0x78 minus the sign bits
+							d = d + C120;
+							d = k_mad(k_shr(C15, a), CM8, d); d = k_mad(k_shr(C15, b), CM16, d); d = k_mad(k_shr(C15, a2), CM32, d); d = k_mad(k_shr(C15, b2), CM64, d);
+						}
+						X[p] = ma - QE; Y[p] = mb - QE; X2[p] = ma2 - QE2; Y2[p] = mb2 - QE2;
+						U[p] = un; V[p] = vn;
+						dpk[p] = (uint32_t)as_i(d);
 					}
-					z = pmin(zm, MCH);
-					const s2_t un = sx8p(z - vt1), vn = sx8p(z - ut);
-					s2_t tmp = sx8p(z - Q1); a = sx8p(a - tmp); b = sx8p(b - tmp);
-					tmp = sx8p(z - Q2); a2 = sx8p(a2 - tmp); b2 = sx8p(b2 - tmp);
-					if (!right) {
-						d = d + pmin(pmax(a, ZERO), ONE) * splat2(8) + pmin(pmax(b, ZERO), ONE) * splat2(16) + pmin(pmax(a2, ZERO), ONE) * splat2(32) + pmin(pmax(b2, ZERO), ONE) * splat2(64);
-					} else {
-						d = d + (ONE - pmin(pmax(ZERO - a, ZERO), ONE)) * splat2(8) + (ONE - pmin(pmax(ZERO - b, ZERO), ONE)) * splat2(16)
-						      + (ONE - pmin(pmax(ZERO - a2, ZERO), ONE)) * splat2(32) + (ONE - pmin(pmax(ZERO - b2, ZERO), ONE)) * splat2(64);
-					}
-					X[p] = sx8p(pmax(a, ZERO) - QE); Y[p] = sx8p(pmax(b, ZERO) - QE);
-					X2[p] = sx8p(pmax(a2, ZERO) - QE2); Y2[p] = sx8p(pmax(b2, ZERO) - QE2);
-					U[p] = un; V[p] = vn;
-					dpk[p] = (uint32_t)as_i(d);
-				}
+				};
+				if (right) cells(std::true_type{}); else cells(std::false_type{});
 				uint2 dd;
 				dd.x = __builtin_amdgcn_perm(dpk[1], dpk[0], 0x06040200u);
 				dd.y = __builtin_amdgcn_perm(dpk[3], dpk[2], 0x06040200u);
-				*reinterpret_cast<uint2*>(pmat + (size_t)r * n_col + (t0 - st)) = dd;
+				*reinterpret_cast<uint2*>(prow + (t0 - st)) = dd;
 			}
+			prow += n_col;
 			// ---- what the workgroup needs from single columns: posted by their owners (updated this diagonal or not) ----
+			// The maximum of H over the diagonal with the reference's tie order (ksw2_extd2_sse.c:325-340: four int32 lanes by
+			// (t - st0) & 3 over [st0, en1), then the tail, first maximum wins) is ONE unsigned key per column:
+			//   (clamp16(H) + 32768) << 15 | (7 - class) << 12 | (4095 - (t - st)),  0 for a column outside [st0, en0).
+			// A maximum that hits the clamp is reported (the problem is redone by the workgroup kernel).
 			if (!approx_max) {
 				if (r > 0) {
-					const int en1 = st0 + (en0 - st0) / 4 * 4;
-					if (t0 + 7 >= st0 - 1 && t0 <= en0)
+					const int lo = st0 - t0, hi = en0 - t0;                  // column i of the block is updated iff lo <= i < hi
+					const int i_p = hi - 1, i_e = hi, i_s = lo;
+					if ((unsigned)i_p < 8u) bx.hprev = sel8(H, i_p);
+					if ((unsigned)i_e < 8u) { bx.u_en = col8v(U, i_e); bx.v_en = col8v(V, i_e); bx.h_en_old = sel8(H, i_e); }
+					uint32_t kbest = 0;
+					if (hi > 0 && lo < 8) {
+						const int e1 = st0 + (en0 - st0) / 4 * 4 - t0;       // class of column i: (i - lo) & 3 below e1, 4 from there on
+						const uint32_t lowbase = (7u << 12) + 4095u - (uint32_t)(t0 - st) + (32768u << 15);
+						const uint32_t span_u = (uint32_t)(hi - lo);
+#pragma unroll
+						for (int i = 0; i < 8; ++i) {
+							const uint32_t rel = (uint32_t)(i - lo);
+							const bool in = rel < span_u;
+							const int h = H[i] + col8(V, i);
+							H[i] = in ? h : H[i];
+							const uint32_t cls = i < e1 ? (rel & 3u) : 4u;
+							const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;        // (v_med3_i32)
+							const uint32_t key = ((uint32_t)hc << 15) + (lowbase - (uint32_t)i - (cls << 12));
+							kbest = in && key > kbest ? key : kbest;
+						}
+					}
+					if ((unsigned)i_s < 8u) bx.h_st = sel8(H, i_s);
+					kbest = wave_max_u32(kbest);
+					if (lane == 0) bx.key[wave] = kbest;
+				} else if (t0 == 0) bx.v_en = col8(V, 0);
+			} else {
+				const int h0t = r == 0 ? 0 : last_H0_t;
+				if (h0t + 1 >= t0 && h0t < t0 + 8) {
+					int hv = 0, hu = 0;
 #pragma unroll
 					for (int i = 0; i < 8; ++i) {
 						const int t = t0 + i;
-						const int vn = (i & 1) ? (int)V[i >> 1].y : (int)V[i >> 1].x;
-						const int hold = H[i];
-						if (t == en0 - 1) bx.hprev = hold;
-						if (t == en0) { bx.u_en = (i & 1) ? (int)U[i >> 1].y : (int)U[i >> 1].x; bx.v_en = vn; bx.h_en_old = hold; }
-						if (t >= st0 && t < en0) {
-							const int h = hold + vn;
-							H[i] = h;
-							const unsigned ord = t < en1 ? 1u + ((unsigned)((t - st0) & 3) << 28) + (unsigned)t : 1u + (4u << 28) + (unsigned)t;
-							const long long key = ((long long)h << 32) | (0xffffffffu - ord);
-							best = key > best ? key : best;
-						}
-						if (t == st0) bx.h_st = H[i];
+						hv = t == h0t ? col8(V, i) : hv;
+						hu = t == h0t + 1 ? col8(U, i) : hu;
 					}
-					best = wave_max_i64(best);
-					if (lane == 0) bx.part[wave] = best;
-				} else if (t0 == 0) bx.v_en = (int)V[0].x;
-			} else {
-				const int h0t = r == 0 ? 0 : last_H0_t;
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					const int t = t0 + i;
-					if (t == h0t) bx.h0v = (i & 1) ? (int)V[i >> 1].y : (int)V[i >> 1].x;
-					if (t == h0t + 1) bx.h0u = (i & 1) ? (int)U[i >> 1].y : (int)U[i >> 1].x;
+					if (h0t >= t0 && h0t < t0 + 8) bx.h0v = hv;
+					if (h0t + 1 >= t0 && h0t + 1 < t0 + 8) bx.h0u = hu;
 				}
 			}
-			if (lane == 63) bx.nb[wave] = ((uint32_t)as_i(X[3]) >> 16 & 0xffu) | ((uint32_t)as_i(V[3]) >> 16 & 0xffu) << 8 | ((uint32_t)as_i(X2[3]) >> 16 & 0xffu) << 16;
+			if (lane == 63) bx.nb[wave] = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 			// ---- uniform bookkeeping of the diagonal (every lane, from the mailboxes) ----
 			bool stop = false;
+			const int4 mb0 = *reinterpret_cast<const int4*>(&bx.hprev), mb1 = *reinterpret_cast<const int4*>(&bx.h_st);   // every mailbox value in one go (unposted ones are never used)
+			const uint4 mkey = *reinterpret_cast<const uint4*>(bx.key);
 			if (!approx_max) {
 				int max_H, max_t, h_en_now, h_st_now;
 				if (r > 0) {
-					const int Hen = en0 > 0 ? bx.hprev + bx.u_en : bx.h_en_old + bx.v_en;
-					long long bb = bx.part[0];
-#pragma unroll
-					for (int k = 1; k < NW; ++k) { const long long o = bx.part[k]; bb = o > bb ? o : bb; }
-					{ const long long hk = ((long long)Hen << 32) | 0xffffffffu; if (hk > bb) bb = hk; }
-					max_H = (int)(bb >> 32);
-					const unsigned ord = 0xffffffffu - (unsigned)(bb & 0xffffffffLL);
-					max_t = ord == 0 ? en0 : (int)((ord - 1) & 0x0fffffffu);
+					const int Hen = en0 > 0 ? mb0.x + mb0.y : mb0.w + mb0.z;
+					uint32_t k = mkey.x > mkey.y ? mkey.x : mkey.y;
+					if (NW > 2) { const uint32_t k2 = mkey.z > mkey.w ? mkey.z : mkey.w; k = k2 > k ? k2 : k; }
+					const uint32_t kh16 = k >> 15;
+					const int kh = (int)kh16 - 32768, kt = st + 4095 - (int)(k & 4095u);
+					sat |= (k != 0 && (kh16 == 0 || kh16 == 65535u)) ? 1 : 0;
+					const bool take_en = k == 0 || Hen >= kh;               // H[en0] is looked at first: it wins ties
+					max_H = take_en ? Hen : kh;
+					max_t = take_en ? en0 : kt;
 					h_en_now = Hen;
-					h_st_now = st0 == en0 ? Hen : bx.h_st;
-					if (en0 >= t0 && en0 < t0 + 8) {
+					h_st_now = st0 == en0 ? Hen : mb1.x;
+					if ((unsigned)(en0 - t0) < 8u) {
 #pragma unroll
-						for (int i = 0; i < 8; ++i) if (t0 + i == en0) H[i] = Hen;
+						for (int i = 0; i < 8; ++i) H[i] = t0 + i == en0 ? Hen : H[i];
 					}
 				} else {
-					const int h0 = bx.v_en - qe_h;
+					const int h0 = mb0.z - qe_h;
 					if (t0 == 0) H[0] = h0;
 					max_H = h0, max_t = 0, h_en_now = h0, h_st_now = h0;
 				}
@@ -315,11 +388,11 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			} else {
 				if (r > 0) {
 					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-						const int d0 = bx.h0v, d1 = bx.h0u;
+						const int d0 = mb1.y, d1 = mb1.z;
 						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
-					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += bx.h0v;
-					else ++last_H0_t, H0 += bx.h0u;
-				} else H0 = bx.h0v - qe_h, last_H0_t = 0;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += mb1.y;
+					else ++last_H0_t, H0 += mb1.z;
+				} else H0 = mb1.y - qe_h, last_H0_t = 0;
 				if (flag & EZ_APPROX_DROP) {
 					if (H0 > ez_max) ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
 					else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
@@ -335,7 +408,8 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 
 		// ---- backtrack by wave 0 (ksw2.h:127-159) through a 64x64 LDS window of the direction matrix ----
 		int n_cigar = 0, bi = -1, bj = -1;
-		if (!ez_zdropped && !(flag & EZ_EXTZ_ONLY)) bi = tlen - 1, bj = qlen - 1;
+		if (sat) {}                                                 // (no traceback: the problem is redone)
+		else if (!ez_zdropped && !(flag & EZ_EXTZ_ONLY)) bi = tlen - 1, bj = qlen - 1;
 		else if (!ez_zdropped && (flag & EZ_EXTZ_ONLY) && ez_mqe + end_bonus > ez_max) ez_reach_end = 1, bi = ez_mqe_t, bj = qlen - 1;
 		else if (ez_max_t >= 0 && ez_max_q >= 0) bi = ez_max_t, bj = ez_max_q;
 		__threadfence_block();
@@ -361,7 +435,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 						if (r >= 0 && col >= 0) {
 							int st0, en0; diag_range_l(r, qlen, tlen, w, st0, en0);
 							const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
-							if (st0 <= en0 && col >= off && col <= off_end) val = pmat[(size_t)r * n_col + (col - off)];
+							if (st0 <= en0 && col >= off && col <= off_end) val = pool_base[(size_t)s_chunk[r / rpc] * LANES_CHUNK + (size_t)(r % rpc) * n_col + (col - off)];
 						}
 						wv[row] = val;
 					}
@@ -405,7 +479,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			if (lane == 0) {
 				DpRes R;
 				R.max = ez_max, R.max_q = ez_max_q, R.max_t = ez_max_t, R.mqe = ez_mqe, R.mqe_t = ez_mqe_t, R.mte = ez_mte, R.mte_q = ez_mte_q;
-				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = n_cigar, R.pad = r_done, R.cigar_off = base;
+				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = sat ? -9 : n_cigar, R.pad = r_done, R.cigar_off = base;
 				res[jid] = R;
 			}
 		}
@@ -416,21 +490,27 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 bool lanes_eligible(const DpJob &j)
 {
 	if (j.flag & PGA_JOB_LL) return false;
-	if (j.qlen < 1 || j.tlen < 1 || j.qlen > 48 * 1024) return false;
+	if (j.qlen < 1 || j.tlen < 1 || j.qlen > 28 * 1024 || j.tlen > 28 * 1024) return false;
 	const int T = (j.tlen + 15) / 16 * 16;
 	const int w = j.w < 0 ? (j.tlen > j.qlen ? j.tlen : j.qlen) : j.w;
 	int R = ((w < j.tlen ? w : j.tlen) + 15) / 16 * 16 + 96;
 	if (R > T) R = T;
-	return R <= 256 * LANES_C;
+	if (R > 256 * LANES_C) return false;
+	int n_col = j.qlen < j.tlen ? j.qlen : j.tlen;
+	n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
+	return ((size_t)j.qlen + j.tlen) / (LANES_CHUNK / (size_t)n_col) + 2 <= LANES_MAXCHUNK;
 }
 
-void launch_extd2_lanes(unsigned n_blocks, int q_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+size_t lanes_cig_bytes(int q_cap, int t_cap) { return (4 * ((size_t)q_cap + t_cap + 8) + 255) & ~(size_t)255; }
+size_t lanes_chunk_bytes() { return LANES_CHUNK; }
+
+void launch_extd2_lanes(unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
 	static bool attr_set = false;
 	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_lanes<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
-	const size_t lds = ((size_t)q_cap + 15) & ~(size_t)15;
-	hipLaunchKernelGGL(k_extd2_lanes<256>, dim3(n_blocks), dim3(256), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, q_cap, res, pool, cursor, pool_cap);
+	const size_t lds = (((size_t)q_cap + 15) & ~(size_t)15) + (((size_t)t_cap + 15) & ~(size_t)15) + 16;
+	hipLaunchKernelGGL(k_extd2_lanes<256>, dim3(n_blocks), dim3(256), lds, st, jobs, n_jobs, nt4, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

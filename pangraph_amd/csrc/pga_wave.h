@@ -51,6 +51,23 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_maxu_step(uint32_t v)
+{
+	const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+	return o > v ? o : v;
+}
+// unsigned maximum over the wave, returned to every lane
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+	v = dpp_maxu_step<0xB1, 0xf>(v);
+	v = dpp_maxu_step<0x4E, 0xf>(v);
+	v = dpp_maxu_step<0x141, 0xf>(v);
+	v = dpp_maxu_step<0x140, 0xf>(v);
+	v = dpp_maxu_step<0x142, 0xa>(v);
+	v = dpp_maxu_step<0x143, 0xc>(v);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // minimum of a double over the wave (no NaNs), to every lane: two 32-bit reductions over the order-preserving integer image
 __device__ __forceinline__ double wave_min_f64_key(double v)
 {
