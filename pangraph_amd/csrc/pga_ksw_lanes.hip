@@ -59,10 +59,11 @@ __device__ __forceinline__ s2_t k_minu(s2_t a, s2_t b) { int r; asm("v_pk_min_u1
 __device__ __forceinline__ s2_t k_mad(s2_t a, s2_t b, s2_t c) { int r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(as_i(a)), "v"(as_i(b)), "v"(as_i(c))); return as_s2(r); }
 __device__ __forceinline__ s2_t k_shr(s2_t sh, s2_t a) { int r; asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(as_i(sh)), "v"(as_i(a))); return as_s2(r); }
 
-struct __attribute__((aligned(16))) LaneBox {              // cross-wave values of one diagonal (two copies, by diagonal parity)
-	uint32_t key[8];          // per wave: best packed (H, tie order, column) key of the diagonal
-	uint32_t nb[8];           // per wave: x, v, x2 of its last column (what lane 0 of the next wave reads on the next diagonal)
-	int hprev, u_en, v_en, h_en_old, h_st, h0v, h0u, pad;      // (two aligned 16-byte groups: read back with two loads)
+struct __attribute__((aligned(16))) LaneRec {      // what a wave publishes per diagonal (two copies, by diagonal parity)
+	uint32_t key;             // best packed (H, tie order, column) key among its columns
+	uint32_t nb;              // x, v, x2 of its last column: what lane 0 of the next wave reads on the next diagonal
+	int32_t h7;               // H of its last column
+	uint32_t pad;
 };
 
 template <int NT>
@@ -74,7 +75,8 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 	constexpr int NW = NT / 64, C = LANES_C, RC = NT * C;
 	extern __shared__ __align__(16) uint8_t qq[];       // the query window, orientation and complement resolved
 	__shared__ uint32_t s_job;
-	__shared__ LaneBox s_box[2];
+	__shared__ LaneRec s_rec[2][NT / 64];
+	__shared__ int s_hen[2], s_hst[2], s_h0v[2], s_h0u[2];
 	__shared__ uint8_t s_win[LBT * LBT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	// scratch: one CIGAR buffer per workgroup, then the pool of direction-matrix CHUNKS.  A workgroup takes chunks as its diagonals
@@ -124,7 +126,6 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 		};
 		for (int j = tid; j < qlen; j += NT) qq[j] = (uint8_t)query_at(j);
 		for (int i = tid; i < T + 8; i += NT) tq[i] = (uint8_t)target_at(i);
-		if (tid < NW) { s_box[1].nb[tid] = nb_init; s_box[0].nb[tid] = nb_init; }
 		const int rpc = LANES_CHUNK / n_col;                   // diagonals per chunk
 		auto want_chunk = [&](int c) {                        // (thread 0) make sure chunk c of this problem exists
 			if (c < LANES_MAXCHUNK && c >= s_have) {
@@ -192,6 +193,9 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 		};
 		int sat = 0;
 
+		uint4 nrec = make_uint4(0u, nb_init, (uint32_t)KSW_NEG_INF, 0u);   // the left neighbour wave's record of the previous diagonal
+		auto diag_loop = [&](auto EXACT_T, auto RIGHT_T) {
+		constexpr bool EXACT = decltype(EXACT_T)::value, RIGHT = decltype(RIGHT_T)::value;
 		for (int r = 0; r < n_diag; ++r) {
 			r_done = r + 1;
 			int st0, en0;
@@ -211,39 +215,34 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			// a lane whose block fell out of the band on the left takes the block one ring further right (fresh rows)
 			if ((blk + NT) * C <= need_hi) { blk += NT; fresh(r - 1); const int j = r - blk * C; q_next = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u; }
 			const int t0 = blk * C;
-			LaneBox &bx = s_box[r & 1];
-			const LaneBox &bp = s_box[(r & 1) ^ 1];
+			LaneRec *recs = s_rec[r & 1];
 			// query byte of the block's first column (requested one diagonal ahead: its LDS latency hides behind the barrier)
 			W1 = W1 << 8 | W0 >> 24; W0 = W0 << 8 | q_next;
-			{ const int j = r + 1 - t0; q_next = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u; }
-			// left neighbour: x, v, x2 of column t0-1 as the previous diagonal left them (the int8 is the top byte of the block's last half)
+			{ const int j = r + 1 - t0; const uint32_t qb = qq[j < 0 ? 0 : j >= qlen ? qlen - 1 : j]; q_next = (unsigned)j < (unsigned)qlen ? qb : 0u; }
+			// left neighbour: x, v, x2 and H of column t0-1 as the previous diagonal left them (an int8 is the top byte of its half)
 			const uint32_t mine = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
-			uint32_t inc = (uint32_t)wave_shr1((int)mine, 0);
-			if (lane == 0) inc = bp.nb[(wave + NW - 1) % NW];
-			if (t0 == st) {
+			uint32_t inc = (uint32_t)wave_shr1((int)mine, (int)nrec.y);
+			const int hp_in = wave_shr1(H[7], (int)nrec.z);
+			{
 				const uint32_t c1 = (uint32_t)(uint8_t)(-q - e), c2 = (uint32_t)(uint8_t)(-q2 - e2);
-				if (st > 0) {
-					if (!(st - 1 >= last_st && st - 1 <= last_en)) inc = c1 | c1 << 8 | c2 << 16;
-				} else {
-					const uint32_t v1 = (uint32_t)(uint8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
-					inc = c1 | v1 << 8 | c2 << 16;
-				}
+				const uint32_t v1 = st > 0 ? c1 : (uint32_t)(uint8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+				const bool fresh_edge = st == 0 || !(st - 1 >= last_st && st - 1 <= last_en);     // (uniform)
+				inc = (t0 == st && fresh_edge) ? (c1 | v1 << 8 | c2 << 16) : inc;
 			}
 			// score bytes of the columns in [st0, st0+span) (the others keep what an earlier diagonal left there)
 			{
 				int lo = st0 - t0, hi = (st0 + span < T ? st0 + span : T) - t0;
-				lo = lo < 0 ? 0 : lo > 8 ? 8 : lo; hi = hi < 0 ? 0 : hi > 8 ? 8 : hi;
-				if (hi > lo) {
-					const unsigned long long m = (hi == 8 ? ~0ull : (1ull << (8 * hi)) - 1) & ~((1ull << (8 * lo)) - 1);
-					const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-					const uint32_t nz0 = ((TB0 ^ W0) + 0x7f7f7f7fu) >> 7 & 0x01010101u, nn0 = (TB0 | W0) >> 2 & 0x01010101u;
-					const uint32_t nz1 = ((TB1 ^ W1) + 0x7f7f7f7fu) >> 7 & 0x01010101u, nn1 = (TB1 | W1) >> 2 & 0x01010101u;
-					S0 = (S0 & ~m0) | (__builtin_amdgcn_perm(0u, sc_tab, nz0 | nn0 << 1) & m0);
-					S1 = (S1 & ~m1) | (__builtin_amdgcn_perm(0u, sc_tab, nz1 | nn1 << 1) & m1);
-				}
+				lo = lo < 0 ? 0 : lo > 8 ? 8 : lo; hi = hi < lo ? lo : hi > 8 ? 8 : hi;
+				// byte masks of [lo, hi) over the two words
+				const int lo0 = lo > 4 ? 4 : lo, hi0 = hi > 4 ? 4 : hi, lo1 = lo - lo0, hi1 = hi - hi0;
+				const uint32_t m0 = (hi0 == 4 ? 0xffffffffu : (1u << (8 * hi0)) - 1u) & ~(lo0 == 4 ? 0xffffffffu : (1u << (8 * lo0)) - 1u);
+				const uint32_t m1 = (hi1 == 4 ? 0xffffffffu : (1u << (8 * hi1)) - 1u) & ~(lo1 == 4 ? 0xffffffffu : (1u << (8 * lo1)) - 1u);
+				const uint32_t nz0 = ((TB0 ^ W0) + 0x7f7f7f7fu) >> 7 & 0x01010101u, nn0 = (TB0 | W0) >> 2 & 0x01010101u;
+				const uint32_t nz1 = ((TB1 ^ W1) + 0x7f7f7f7fu) >> 7 & 0x01010101u, nn1 = (TB1 | W1) >> 2 & 0x01010101u;
+				S0 = (S0 & ~m0) | (__builtin_amdgcn_perm(0u, sc_tab, nz0 | nn0 << 1) & m0);
+				S1 = (S1 & ~m1) | (__builtin_amdgcn_perm(0u, sc_tab, nz1 | nn1 << 1) & m1);
 			}
-			const bool act = t0 >= st && t0 <= en;
-			if (act) {
+			if (t0 >= st && t0 <= en) {
 				// the column that joins on this diagonal starts from the first-row values
 				if (en >= r && r >= t0 && r < t0 + 8) {
 					const int uj = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
@@ -256,84 +255,131 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 				// the left neighbour's values ride in the high half of the carry
 				int cx = (int)(inc << 24), cv = (int)(inc << 16 & 0xff000000u), cx2 = (int)(inc << 8 & 0xff000000u);
 				uint32_t dpk[4];
-				auto cells = [&](auto RIGHT) {
+				// (written column-pair-parallel: the four pairs of a step are independent, and inline asm keeps its program order, so this
+				// is the order that hides the 8-cycle latency of dependent packed operations)
+				s2_t xt1[4], vt1[4], x2t1[4], z0[4], a[4], b[4], a2[4], b2[4], zm[4], d[4], z[4];
 #pragma unroll
-					for (int p = 0; p < 4; ++p) {
-						const int ox = as_i(X[p]), ov = as_i(V[p]), ox2 = as_i(X2[p]);
-						const s2_t xt1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox, (uint32_t)cx, 16));
-						const s2_t vt1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ov, (uint32_t)cv, 16));
-						const s2_t x2t1 = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox2, (uint32_t)cx2, 16));
-						cx = ox, cv = ov, cx2 = ox2;
-						const s2_t ut = U[p], yt = Y[p], y2t = Y2[p];
-						const s2_t z0 = as_s2((int)__builtin_amdgcn_perm(0u, p < 2 ? S0 : S1, (p & 1) ? 0x030c020cu : 0x010c000cu));
-						s2_t a = xt1 + vt1, b = yt + ut, a2 = x2t1 + vt1, b2 = y2t + ut;
-						s2_t zm, d;
-						if constexpr (!decltype(RIGHT)::value) {
-							// the first of z, a, b, a2, b2 that attains the maximum = how many running maxima stay below it
-							const s2_t p1 = k_max(z0, a), p2 = k_max(p1, b), p3 = k_max(p2, a2);
-							zm = k_max(p3, b2);
-							d = k_minu(zm - z0, ONE) + k_minu(zm - p1, ONE) + k_minu(zm - p2, ONE) + k_minu(zm - p3, ONE);
-						} else {
-							// the last one that attains it = how many maxima over a suffix reach it
-							const s2_t s3 = k_max(a2, b2), s2 = k_max(b, s3), s1 = k_max(a, s2);
-							zm = k_max(z0, s1);
-							d = FOUR - (k_minu(zm - b2, ONE) + k_minu(zm - s3, ONE) + k_minu(zm - s2, ONE) + k_minu(zm - s1, ONE));
-						}
-						const s2_t z = k_min(zm, MCH);
-						const s2_t un = z - vt1, vn = z - ut;
-						s2_t tmp = z - Q1; a = a - tmp; b = b - tmp;
-						tmp = z - Q2; a2 = a2 - tmp; b2 = b2 - tmp;
-						const s2_t ma = k_max(a, ZERO), mb = k_max(b, ZERO), ma2 = k_max(a2, ZERO), mb2 = k_max(b2, ZERO);
-						if constexpr (!decltype(RIGHT)::value) {        // continuation bits: a > 0
-							d = k_mad(k_min(ma, ONE), C8, d); d = k_mad(k_min(mb, ONE), C16, d); d = k_mad(k_min(ma2, ONE), C32, d); d = k_mad(k_min(mb2, ONE), C64, d);
-						} else {                              // a >= 0: all of 0x78 minus the sign bits
-							d = d + C120;
-							d = k_mad(k_shr(C15, a), CM8, d); d = k_mad(k_shr(C15, b), CM16, d); d = k_mad(k_shr(C15, a2), CM32, d); d = k_mad(k_shr(C15, b2), CM64, d);
-						}
-						X[p] = ma - QE; Y[p] = mb - QE; X2[p] = ma2 - QE2; Y2[p] = mb2 - QE2;
-						U[p] = un; V[p] = vn;
-						dpk[p] = (uint32_t)as_i(d);
-					}
-				};
-				if (right) cells(std::true_type{}); else cells(std::false_type{});
+				for (int p = 0; p < 4; ++p) {
+					const int ox = as_i(X[p]), ov = as_i(V[p]), ox2 = as_i(X2[p]);
+					xt1[p] = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox, (uint32_t)cx, 16));
+					vt1[p] = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ov, (uint32_t)cv, 16));
+					x2t1[p] = as_s2((int)__builtin_amdgcn_alignbit((uint32_t)ox2, (uint32_t)cx2, 16));
+					cx = ox, cv = ov, cx2 = ox2;
+					z0[p] = as_s2((int)__builtin_amdgcn_perm(0u, p < 2 ? S0 : S1, (p & 1) ? 0x030c020cu : 0x010c000cu));
+				}
+#pragma unroll
+				for (int p = 0; p < 4; ++p) { a[p] = xt1[p] + vt1[p]; b[p] = Y[p] + U[p]; a2[p] = x2t1[p] + vt1[p]; b2[p] = Y2[p] + U[p]; }
+				if constexpr (!RIGHT) {
+					// the first of z, a, b, a2, b2 that attains the maximum = how many running maxima stay below it
+					s2_t p1[4], p2[4], p3[4];
+#pragma unroll
+					for (int p = 0; p < 4; ++p) p1[p] = k_max(z0[p], a[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) p2[p] = k_max(p1[p], b[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) p3[p] = k_max(p2[p], a2[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) zm[p] = k_max(p3[p], b2[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_minu(zm[p] - z0[p], ONE);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = d[p] + k_minu(zm[p] - p1[p], ONE);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = d[p] + k_minu(zm[p] - p2[p], ONE);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = d[p] + k_minu(zm[p] - p3[p], ONE);
+				} else {
+					// the last one that attains it = how many maxima over a suffix reach it
+					s2_t s3[4], s2[4], s1[4];
+#pragma unroll
+					for (int p = 0; p < 4; ++p) s3[p] = k_max(a2[p], b2[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) s2[p] = k_max(b[p], s3[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) s1[p] = k_max(a[p], s2[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) zm[p] = k_max(z0[p], s1[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = FOUR - k_minu(zm[p] - b2[p], ONE);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = d[p] - k_minu(zm[p] - s3[p], ONE);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = d[p] - k_minu(zm[p] - s2[p], ONE);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = d[p] - k_minu(zm[p] - s1[p], ONE);
+				}
+#pragma unroll
+				for (int p = 0; p < 4; ++p) z[p] = k_min(zm[p], MCH);
+#pragma unroll
+				for (int p = 0; p < 4; ++p) { const s2_t un = z[p] - vt1[p], vn = z[p] - U[p]; U[p] = un; V[p] = vn; }
+#pragma unroll
+				for (int p = 0; p < 4; ++p) { const s2_t t1 = z[p] - Q1, t2 = z[p] - Q2; a[p] = a[p] - t1; b[p] = b[p] - t1; a2[p] = a2[p] - t2; b2[p] = b2[p] - t2; }
+				if constexpr (!RIGHT) {                  // continuation bits: a > 0
+#pragma unroll
+					for (int p = 0; p < 4; ++p) { a[p] = k_max(a[p], ZERO); b[p] = k_max(b[p], ZERO); a2[p] = k_max(a2[p], ZERO); b2[p] = k_max(b2[p], ZERO); }
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_min(a[p], ONE), C8, d[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_min(b[p], ONE), C16, d[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_min(a2[p], ONE), C32, d[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_min(b2[p], ONE), C64, d[p]);
+				} else {                                 // a >= 0: all of 0x78 minus the sign bits
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_shr(C15, a[p]), CM8, d[p] + C120);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_shr(C15, b[p]), CM16, d[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_shr(C15, a2[p]), CM32, d[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) d[p] = k_mad(k_shr(C15, b2[p]), CM64, d[p]);
+#pragma unroll
+					for (int p = 0; p < 4; ++p) { a[p] = k_max(a[p], ZERO); b[p] = k_max(b[p], ZERO); a2[p] = k_max(a2[p], ZERO); b2[p] = k_max(b2[p], ZERO); }
+				}
+#pragma unroll
+				for (int p = 0; p < 4; ++p) { X[p] = a[p] - QE; Y[p] = b[p] - QE; X2[p] = a2[p] - QE2; Y2[p] = b2[p] - QE2; dpk[p] = (uint32_t)as_i(d[p]); }
 				uint2 dd;
 				dd.x = __builtin_amdgcn_perm(dpk[1], dpk[0], 0x06040200u);
 				dd.y = __builtin_amdgcn_perm(dpk[3], dpk[2], 0x06040200u);
 				*reinterpret_cast<uint2*>(prow + (t0 - st)) = dd;
 			}
 			prow += n_col;
-			// ---- what the workgroup needs from single columns: posted by their owners (updated this diagonal or not) ----
-			// The maximum of H over the diagonal with the reference's tie order (ksw2_extd2_sse.c:325-340: four int32 lanes by
-			// (t - st0) & 3 over [st0, en1), then the tail, first maximum wins) is ONE unsigned key per column:
-			//   (clamp16(H) + 32768) << 15 | (7 - class) << 12 | (4095 - (t - st)),  0 for a column outside [st0, en0).
+			// ---- H (exact mode): H[t] += v[t] over [st0, en0), H[en0] = H[en0-1](old) + u[en0] (ksw2_extd2_sse.c:325-340), and the
+			// maximum with the reference's tie order (H[en0] first, then four int32 lanes by (t - st0) & 3 over [st0, en1), then the
+			// tail; the first maximum wins) as ONE unsigned key per column:
+			//   (clamp16(H) + 32768) << 16 | field << 12 | (4095 - (t - st)),  field = 8 for en0, 7 - class otherwise.
 			// A maximum that hits the clamp is reported (the problem is redone by the workgroup kernel).
-			if (!approx_max) {
-				if (r > 0) {
-					const int lo = st0 - t0, hi = en0 - t0;                  // column i of the block is updated iff lo <= i < hi
-					const int i_p = hi - 1, i_e = hi, i_s = lo;
-					if ((unsigned)i_p < 8u) bx.hprev = sel8(H, i_p);
-					if ((unsigned)i_e < 8u) { bx.u_en = col8v(U, i_e); bx.v_en = col8v(V, i_e); bx.h_en_old = sel8(H, i_e); }
-					uint32_t kbest = 0;
-					if (hi > 0 && lo < 8) {
-						const int e1 = st0 + (en0 - st0) / 4 * 4 - t0;       // class of column i: (i - lo) & 3 below e1, 4 from there on
-						const uint32_t lowbase = (7u << 12) + 4095u - (uint32_t)(t0 - st) + (32768u << 15);
-						const uint32_t span_u = (uint32_t)(hi - lo);
+			uint32_t kbest = 0;
+			if constexpr (EXACT) {
+				const int lo = st0 - t0, hi = en0 - t0;                      // column i of the block is updated iff lo <= i < hi; i == hi is en0
+				if (hi >= 0 && lo < 8) {
+					const int e1 = st0 + (en0 - st0) / 4 * 4 - t0;           // class of column i: (i - lo) & 3 below e1, 4 from there on
+					const uint32_t lowbase = 4095u - (uint32_t)(t0 - st) + (32768u << 16);
+					const uint32_t span_u = (uint32_t)(hi - lo);
+					const bool r0 = r == 0, e0 = en0 == 0;
+					int prev_old = hp_in;
 #pragma unroll
-						for (int i = 0; i < 8; ++i) {
-							const uint32_t rel = (uint32_t)(i - lo);
-							const bool in = rel < span_u;
-							const int h = H[i] + col8(V, i);
-							H[i] = in ? h : H[i];
-							const uint32_t cls = i < e1 ? (rel & 3u) : 4u;
-							const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;        // (v_med3_i32)
-							const uint32_t key = ((uint32_t)hc << 15) + (lowbase - (uint32_t)i - (cls << 12));
-							kbest = in && key > kbest ? key : kbest;
-						}
+					for (int i = 0; i < 8; ++i) {
+						const uint32_t rel = (uint32_t)(i - lo);
+						const bool in = rel < span_u, is_en = i == hi;
+						const int hold = H[i], vn = col8(V, i);
+						const int hen = r0 ? vn - qe_h : e0 ? hold + vn : prev_old + col8(U, i);
+						const int h = is_en ? hen : in ? hold + vn : hold;
+						H[i] = h;
+						prev_old = hold;
+						const uint32_t field = is_en ? 8u : 7u - (i < e1 ? (rel & 3u) : 4u);
+						const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;        // (v_med3_i32)
+						const uint32_t key = ((uint32_t)hc << 16) + (lowbase - (uint32_t)i + (field << 12));
+						kbest = (in | is_en) && key > kbest ? key : kbest;
 					}
-					if ((unsigned)i_s < 8u) bx.h_st = sel8(H, i_s);
-					kbest = wave_max_u32(kbest);
-					if (lane == 0) bx.key[wave] = kbest;
-				} else if (t0 == 0) bx.v_en = col8(V, 0);
+					// the two values the end-of-sequence scores need, while the diagonal runs along the last target column / query row
+					if (en0 == tlen - 1 || r - st0 == qlen - 1) {          // (uniform: only while the diagonal runs along an edge of the matrix)
+						if ((unsigned)hi < 8u) s_hen[r & 1] = sel8(H, hi);
+						if ((unsigned)lo < 8u) s_hst[r & 1] = sel8(H, lo);
+					}
+				}
+				kbest = wave_max_u32(kbest);
 			} else {
 				const int h0t = r == 0 ? 0 : last_H0_t;
 				if (h0t + 1 >= t0 && h0t < t0 + 8) {
@@ -344,55 +390,49 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 						hv = t == h0t ? col8(V, i) : hv;
 						hu = t == h0t + 1 ? col8(U, i) : hu;
 					}
-					if (h0t >= t0 && h0t < t0 + 8) bx.h0v = hv;
-					if (h0t + 1 >= t0 && h0t + 1 < t0 + 8) bx.h0u = hu;
+					if (h0t >= t0 && h0t < t0 + 8) s_h0v[r & 1] = hv;
+					if (h0t + 1 >= t0 && h0t + 1 < t0 + 8) s_h0u[r & 1] = hu;
 				}
 			}
-			if (lane == 63) bx.nb[wave] = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
+			{
+				// the wave's record: its key, and x, v, x2, H of its last column for lane 0 of the next wave
+				const uint32_t mine_new = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
+				const uint32_t p63 = (uint32_t)__builtin_amdgcn_readlane((int)mine_new, 63), h63 = (uint32_t)__builtin_amdgcn_readlane(H[7], 63);
+				if (lane == 0) *reinterpret_cast<uint4*>(&recs[wave]) = make_uint4(kbest, p63, h63, 0u);
+			}
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			// ---- uniform bookkeeping of the diagonal (every lane, from the mailboxes) ----
+			// ---- uniform bookkeeping of the diagonal (every wave, from the records) ----
 			bool stop = false;
-			const int4 mb0 = *reinterpret_cast<const int4*>(&bx.hprev), mb1 = *reinterpret_cast<const int4*>(&bx.h_st);   // every mailbox value in one go (unposted ones are never used)
-			const uint4 mkey = *reinterpret_cast<const uint4*>(bx.key);
-			if (!approx_max) {
-				int max_H, max_t, h_en_now, h_st_now;
-				if (r > 0) {
-					const int Hen = en0 > 0 ? mb0.x + mb0.y : mb0.w + mb0.z;
-					uint32_t k = mkey.x > mkey.y ? mkey.x : mkey.y;
-					if (NW > 2) { const uint32_t k2 = mkey.z > mkey.w ? mkey.z : mkey.w; k = k2 > k ? k2 : k; }
-					const uint32_t kh16 = k >> 15;
-					const int kh = (int)kh16 - 32768, kt = st + 4095 - (int)(k & 4095u);
-					sat |= (k != 0 && (kh16 == 0 || kh16 == 65535u)) ? 1 : 0;
-					const bool take_en = k == 0 || Hen >= kh;               // H[en0] is looked at first: it wins ties
-					max_H = take_en ? Hen : kh;
-					max_t = take_en ? en0 : kt;
-					h_en_now = Hen;
-					h_st_now = st0 == en0 ? Hen : mb1.x;
-					if ((unsigned)(en0 - t0) < 8u) {
+			uint32_t k = 0;
 #pragma unroll
-						for (int i = 0; i < 8; ++i) H[i] = t0 + i == en0 ? Hen : H[i];
-					}
-				} else {
-					const int h0 = mb0.z - qe_h;
-					if (t0 == 0) H[0] = h0;
-					max_H = h0, max_t = 0, h_en_now = h0, h_st_now = h0;
+			for (int wv = 0; wv < NW; ++wv) {
+				const uint4 rc = *reinterpret_cast<const uint4*>(&recs[wv]);
+				k = rc.x > k ? rc.x : k;
+				if (wv == (wave + NW - 1) % NW) nrec = rc;
+			}
+			if constexpr (EXACT) {
+				const uint32_t kh16 = k >> 16;
+				const int max_H = (int)kh16 - 32768, max_t = st + 4095 - (int)(k & 4095u);
+				sat |= (kh16 == 0 || kh16 == 65535u) ? 1 : 0;
+				if (en0 == tlen - 1 || r - st0 == qlen - 1) {
+					const int he = s_hen[r & 1], hs = s_hst[r & 1];
+					if (en0 == tlen - 1) { if (he > ez_mte) ez_mte = he, ez_mte_q = r - en0; if (r == n_diag - 1) ez_score = he; }
+					if (r - st0 == qlen - 1 && hs > ez_mqe) ez_mqe = hs, ez_mqe_t = st0;
 				}
-				if (en0 == tlen - 1) { const int h = h_en_now; if (h > ez_mte) ez_mte = h, ez_mte_q = r - en0; }
-				if (r - st0 == qlen - 1) { const int h = h_st_now; if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
-				if (max_H > ez_max) ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-				else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-					if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; stop = true; }
-				}
-				if (!stop && r == n_diag - 1 && en0 == tlen - 1) ez_score = h_en_now;
+				// (straight-line: a branch costs more than all of this)
+				const bool upd = max_H > ez_max;
+				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+				stop = !upd & (tl >= 0) & (ql >= 0) & (zdrop >= 0) & (ez_max - max_H > zdrop + l * e2);
+				ez_max_t = upd ? max_t : ez_max_t; ez_max_q = upd ? r - max_t : ez_max_q; ez_max = upd ? max_H : ez_max;
+				if (stop) ez_zdropped = 1, ez_score = KSW_NEG_INF;
 			} else {
+				const int h0v = s_h0v[r & 1], h0u = s_h0u[r & 1];
 				if (r > 0) {
 					if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-						const int d0 = mb1.y, d1 = mb1.z;
-						if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
-					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += mb1.y;
-					else ++last_H0_t, H0 += mb1.z;
-				} else H0 = mb1.y - qe_h, last_H0_t = 0;
+						if (h0v > h0u) H0 += h0v; else H0 += h0u, ++last_H0_t;
+					} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += h0v;
+					else ++last_H0_t, H0 += h0u;
+				} else H0 = h0v - qe_h, last_H0_t = 0;
 				if (flag & EZ_APPROX_DROP) {
 					if (H0 > ez_max) ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
 					else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
@@ -405,6 +445,10 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			if (stop) break;
 			last_st = st, last_en = en;
 		}
+		};
+		if (!approx_max) { if (right) diag_loop(std::true_type{}, std::true_type{}); else diag_loop(std::true_type{}, std::false_type{}); }
+		else { if (right) diag_loop(std::false_type{}, std::true_type{}); else diag_loop(std::false_type{}, std::false_type{}); }
+
 
 		// ---- backtrack by wave 0 (ksw2.h:127-159) through a 64x64 LDS window of the direction matrix ----
 		int n_cigar = 0, bi = -1, bj = -1;
