@@ -90,6 +90,21 @@ int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const int32_t *qlen
 /* radix_sort_128x (ksort.h:101-151, misc.c:155-159), the exact replay incl. the arrangement of equal keys: sorts every array
  * [seg_off[s], seg_off[s+1]) of the n_seg arrays in xy (two uint64 per record: x = key, y = payload) in place */
 int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy);
+
+/* ---- the guide tree (packages/pangraph/src/commands/build/build_run.rs:100 build_tree_using_neighbor_joining) ----
+ * pga_mash_distance replaces distance/mash/mash_distance.rs:9-65 (minimizers_sketch of every sequence, minimizer.rs:49-160, with
+ * MinimizersParams k, w -- the reference uses the defaults 15 and 100 -- then 1 - shared / own distinct minimizer values):
+ * dist is n x n doubles, row major.  pga_guide_tree_nj replaces tree/neighbor_joining.rs:16-103: leaves are nodes 0..n-1 in input
+ * order, join t (0-based) creates node n + t with children merges[2t] and merges[2t+1] (first the node that stood earlier in the
+ * reference's node list); the last join is the root.  pga_guide_tree does both without moving the matrix through the host
+ * (dist may be NULL).  A sequence without any minimizer is an error, as in the reference (it panics, mash_distance.rs:19-20).
+ * Returns 0, or -1 with the message in pga_last_error(). */
+int pga_mash_distance(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist);
+int pga_guide_tree_nj(int32_t n, const double *dist, int32_t *merges);
+int pga_guide_tree(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist, int32_t *merges);
+/* stage tap: the minimizers of every sequence in the reference's order (value = Minimizer.value, position = Minimizer.position with
+ * the sequence's index as id); seq_off has n + 1 entries */
+int pga_stage_mash_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, uint64_t **value, uint64_t **position, uint64_t *seq_off);
 void pga_free(void *p);
 #ifdef __cplusplus
 }

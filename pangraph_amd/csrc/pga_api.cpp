@@ -616,6 +616,43 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 
+// ---------------------------------------------------------------- mash distance + neighbor-joining guide tree (pga_mash.hip)
+namespace pga {
+void mash_stage_sketch(int n, const char *const *seqs, const uint32_t *lens, int k, int w, std::vector<uint64_t> &val, std::vector<uint64_t> &pos, std::vector<uint64_t> &off);
+void mash_distance_host(int n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist, int32_t *merges);
+void nj_host(int n, const double *dist, int32_t *merges);
+}
+
+extern "C" int pga_stage_mash_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, uint64_t **value, uint64_t **position, uint64_t *seq_off)
+{
+	try {
+		require_device();
+		std::vector<uint64_t> v, p, o;
+		mash_stage_sketch(n, seqs, lens, k, w, v, p, o);
+		*value = dup_out(v); *position = dup_out(p);
+		for (int i = 0; i <= n; ++i) seq_off[i] = o[(size_t)i];
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_mash_distance(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist)
+{
+	try { require_device(); mash_distance_host(n, seqs, lens, k, w, dist, nullptr); return 0; }
+	catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_guide_tree_nj(int32_t n, const double *dist, int32_t *merges)
+{
+	try { require_device(); nj_host(n, dist, merges); return 0; }
+	catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_guide_tree(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist, int32_t *merges)
+{
+	try { require_device(); mash_distance_host(n, seqs, lens, k, w, dist, merges); return 0; }
+	catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
 extern "C" int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy)
 {
 	try {
