@@ -91,6 +91,18 @@ int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const int32_t *qlen
  * [seg_off[s], seg_off[s+1]) of the n_seg arrays in xy (two uint64 per record: x = key, y = payload) in place */
 int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy);
 
+/* ---- the step right behind find_matches (packages/pangraph/src/pangraph/graph_merging.rs:95-128 self_merge) ----
+ * flags & 1: drop self matches (qry == ref inside a group, :107) and split every match at indels >= indel_len_threshold, with side
+ * patches (pangraph/split_matches.rs:13-237; the reference's default threshold is 100, align/alignment_args.rs:8-11);
+ * flags & 2: filter_matches per group (:187-216): alignment_energy2 (align/energy.rs:37-54, defaults alpha 100, beta 10) < 0, stable
+ * sort by energy, greedy acceptance of matches whose query and reference intervals overlap no accepted interval of the same block.
+ * Records come back in the same layout, group by group (ascending), accepted matches in energy order; ties keep the order of the
+ * input records (the reference's tie order is that of its parallel aligner: undefined).  A CIGAR operation other than M I D = X
+ * inside a kept stretch is an error, as in the reference (:62-65).  The result is freed with pga_result_free(). */
+typedef struct { int32_t indel_len_threshold; int32_t flags; double alpha, beta; } pga_filter_params_t;
+int pga_filter_matches(int64_t n, const pga_match_t *matches, const uint32_t *cigars, uint64_t n_ops, const pga_filter_params_t *fp, pga_result_t **out);
+int pga_result_filter(const pga_result_t *res, const pga_filter_params_t *fp, pga_result_t **out);
+
 /* ---- the guide tree (packages/pangraph/src/commands/build/build_run.rs:100 build_tree_using_neighbor_joining) ----
  * pga_mash_distance replaces distance/mash/mash_distance.rs:9-65 (minimizers_sketch of every sequence, minimizer.rs:49-160, with
  * MinimizersParams k, w -- the reference uses the defaults 15 and 100 -- then 1 - shared / own distinct minimizer values):

@@ -244,5 +244,25 @@ def _unpack(pb: PreparedBatch, out, want_rows: bool, want_raw: bool) -> BatchRes
             d.pga_result_free(out)
 
 
+class pga_filter_params_t(C.Structure):
+    _fields_ = [("indel_len_threshold", C.c_int32), ("flags", C.c_int32), ("alpha", C.c_double), ("beta", C.c_double)]
+
+
+def filter_result(res: BatchResult, pb: PreparedBatch, indel_len_threshold: int = 100, alpha: float = 100.0, beta: float = 10.0, split: bool = True,
+                  filt: bool = True, want_rows: bool = False) -> BatchResult:
+    """SURVEY 8(f)-2 (graph_merging.rs:95-128): drop self matches + split_matches (`split`), filter_matches (`filt`) of a result obtained with
+    want_raw=True, on the device; returns a raw result (accepted matches only) that can go into dist.gather_matches."""
+    d = lib()
+    if res._handle is None:
+        raise PgaError("filter_result needs a result obtained with want_raw=True")
+    d.pga_result_filter.restype = C.c_int
+    d.pga_result_filter.argtypes = [C.c_void_p, C.POINTER(pga_filter_params_t), C.POINTER(C.c_void_p)]
+    fp = pga_filter_params_t(indel_len_threshold, (1 if split else 0) | (2 if filt else 0), alpha, beta)
+    out = C.c_void_p()
+    if d.pga_result_filter(res._handle, C.byref(fp), C.byref(out)) != 0:
+        raise PgaError(d.pga_last_error().decode())
+    return _unpack(pb, out, want_rows, True)
+
+
 def align_groups(groups, names=None, **kw) -> BatchResult:
     return align_prepared(PreparedBatch(groups, names), **kw)

@@ -616,6 +616,34 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 
+// ---------------------------------------------------------------- split_matches + filter_matches on the device (pga_filter.hip)
+namespace pga {
+struct FilterParams { int32_t thr, flags; double alpha, beta; };
+void filter_matches_dev(int64_t n_in, const pga_match_t *h_m, const uint32_t *h_cig, uint64_t n_ops_in, const FilterParams &fp, std::vector<pga_match_t> &out_m, std::vector<uint32_t> &out_cig);
+}
+
+extern "C" int pga_filter_matches(int64_t n, const pga_match_t *matches, const uint32_t *cigars, uint64_t n_ops, const pga_filter_params_t *fp, pga_result_t **out)
+{
+	try {
+		require_device();
+		if (!fp || !out) throw std::runtime_error("pga_filter_matches: null argument");
+		if (fp->indel_len_threshold < 1) throw std::runtime_error("pga_filter_matches: indel_len_threshold must be positive");
+		std::unique_ptr<pga_result_s> R(new pga_result_s());
+		memset(&R->st, 0, sizeof(R->st));
+		FilterParams p{fp->indel_len_threshold, fp->flags, fp->alpha, fp->beta};
+		filter_matches_dev(n, matches, cigars, n_ops, p, R->m, R->cig);
+		R->st.n_matches = (double)R->m.size();
+		*out = R.release();
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
+extern "C" int pga_result_filter(const pga_result_t *res, const pga_filter_params_t *fp, pga_result_t **out)
+{
+	if (!res) { set_err("pga_result_filter: null result"); return -1; }
+	return pga_filter_matches((int64_t)res->m.size(), res->m.data(), res->cig.data(), (uint64_t)res->cig.size(), fp, out);
+}
+
 // ---------------------------------------------------------------- mash distance + neighbor-joining guide tree (pga_mash.hip)
 namespace pga {
 void mash_stage_sketch(int n, const char *const *seqs, const uint32_t *lens, int k, int w, std::vector<uint64_t> &val, std::vector<uint64_t> &pos, std::vector<uint64_t> &off);
