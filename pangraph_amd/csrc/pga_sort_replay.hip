@@ -65,30 +65,126 @@ void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_
 		const RsRun R = in[r];
 		if (lane == 0) L.prof[0] = L.prof[1] = L.prof[2] = L.prof[3] = 0;
 		const unsigned long long tk0 = wall_clock64();
+		// A level that leaves one DOMINANT bucket (the strand bit, the target id of a pair: nine records out of ten on one side) does not
+		// end the run's turn: the wave goes on with that bucket and queues only the others -- the passes are level-synchronous, and an
+		// array whose expensive level sits behind two such levels would otherwise spend it two passes later than its neighbours.
+		uint64_t cur_start = R.start; int64_t n = R.len;
+		int shift = R.shift;
+		unsigned long long t_walk = 0;
+		for (;;) {
+			u128 *beg = a + cur_start;
+			uint32_t cnt[4], off[4];
+			uint32_t *rend = rend_all ? rend_all + cur_start : nullptr;    // scratch of the run-length walk, one word per record
+			const unsigned long long tl0 = wall_clock64();
+			while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend, tmp_all ? tmp_all + cur_start : nullptr)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
+			t_walk += wall_clock64() - tl0;
+			if (shift <= 0) break;                                // nothing below the last byte
+			const int next = rs_next_level(R.vary, shift - 8);
+			if (next < 0) break;                                  // the keys of a bucket agree in every lower byte: nothing left to order
+			// the largest bucket of the level (uniform)
+			uint32_t big_len = 0, big_off = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t m = wave_max_u32(cnt[k]);
+				if (m > big_len) { const unsigned long long bm = __ballot(cnt[k] == m); const int l = __ffsll((long long)bm) - 1; big_len = m; big_off = (uint32_t)__builtin_amdgcn_readlane((int)off[k], l); }
+			}
+			const bool follow = (uint64_t)big_len * 2 >= (uint64_t)n && big_len > 4096;
+			bool go_on = false;
+			// buckets of this level: <= 64 records are insertion-sorted now (ksort.h:142), larger ones queue for the next level that can split them
+			rs_split_buckets(beg, n, shift, cnt, off, L, lane, [&](int64_t rb, int64_t len) {
+				const uint64_t g0 = cur_start + (uint64_t)rb;
+				if (hint.dupc && hint.dupc[g0 + (uint64_t)len - 1] == hint.dupc[g0]) {
+					// no two equal keys in this bucket: its final order is the sorted order
+					for (int64_t i = lane; i < len; i += 64) { u128 v; v.x = hint.sx[g0 + (uint64_t)i]; v.y = hint.sy[g0 + (uint64_t)i]; a[g0 + (uint64_t)i] = v; }
+					rs_fence_wg();
+					return;
+				}
+				if (follow && (uint32_t)rb == big_off && (uint32_t)len == big_len) { go_on = true; return; }
+				rs_push2(out, n_out, out_s, n_out_s, cap, g0, (uint32_t)len, next, R.vary, lane);
+			});
+			if (!go_on) break;
+			rs_fence_wg();
+			cur_start += big_off; n = big_len; shift = next;
+		}
+		if (prof && lane == 0) { const unsigned long long tk2 = wall_clock64(); atomicAdd(&prof[0], t_walk); atomicMax(&prof[1], t_walk); atomicAdd(&prof[32], L.prof[0]); atomicAdd(&prof[33], L.prof[1]); atomicAdd(&prof[34], L.prof[2]); atomicAdd(&prof[35], L.prof[3]);
+		                          atomicAdd(&prof[2], tk2 - tk0 - t_walk); atomicMax(&prof[3], tk2 - tk0 - t_walk); }
+	}
+}
+
+// ---- the same replay DEPENDENCY-DRIVEN: one launch, one queue.  A level-synchronous pass ends when its longest run ends, and an array
+// whose expensive level is its second waits behind the first levels of all others; here the buckets of a run enter the queue the
+// moment the run is done.  Queue protocol: a producer reserves a slot (atomicAdd on tail), writes the run, then raises the slot's
+// ready flag (release: the records it scattered are visible before the flag); `pending` counts runs that are queued or running.
+// A consumer claims the next slot (atomicAdd on head) and waits for its flag -- or for pending == 0, which ends the kernel.
+struct RsQueue { uint32_t head, tail, pending, overflow; };
+__device__ __forceinline__ void rs_apush(RsRun *q, uint32_t *ready, RsQueue *Q, RsRun *out_s, uint32_t *n_out_s, uint32_t cap, uint64_t start, uint32_t len, int shift, uint64_t vary, int lane)
+{
+	if (len <= 1024) { rs_push(out_s, n_out_s, cap, start, len, shift, vary, lane); return; }
+	if (lane == 0) {
+		__hip_atomic_fetch_add(&Q->pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t k = __hip_atomic_fetch_add(&Q->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k < cap) {
+			q[k].start = start; q[k].len = len; q[k].shift = shift; q[k].vary = vary;
+			__hip_atomic_store(&ready[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		} else { Q->overflow = 1; __hip_atomic_fetch_sub(&Q->pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	}
+}
+
+__global__ __launch_bounds__(64)
+void k_rs_async(u128 *__restrict__ a, RsRun *__restrict__ q, uint32_t *__restrict__ ready, RsQueue *__restrict__ Q, RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap,
+                uint32_t *__restrict__ rend_all, RsHint hint, u128 *__restrict__ tmp_all)
+{
+	__shared__ RsLds L;
+	const int lane = threadIdx.x;
+	for (;;) {
+		uint32_t r = 0;
+		if (lane == 0) r = __hip_atomic_fetch_add(&Q->head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+		if (r >= cap) break;
+		int state = 0;                                           // 1: the slot is filled, 2: nothing is queued or running any more
+		while (state == 0) {
+			if (lane == 0) {
+				if (__hip_atomic_load(&ready[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) state = 1;
+				else if (__hip_atomic_load(&Q->pending, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) state = __hip_atomic_load(&ready[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 2;
+			}
+			state = __builtin_amdgcn_readfirstlane(state);
+			if (state == 0) __builtin_amdgcn_s_sleep(32);
+		}
+		if (state == 2) break;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // every lane sees what the producer scattered
+		const RsRun R = q[r];
 		u128 *beg = a + R.start;
 		const int64_t n = R.len;
 		int shift = R.shift;
 		uint32_t cnt[4], off[4];
-		uint32_t *rend = rend_all ? rend_all + R.start : nullptr;    // scratch of the run-length walk, one word per record
-		while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend, tmp_all ? tmp_all + R.start : nullptr)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
-		const unsigned long long tk1 = wall_clock64();
-		if (prof && lane == 0) { atomicAdd(&prof[0], tk1 - tk0); atomicMax(&prof[1], tk1 - tk0); atomicAdd(&prof[32], L.prof[0]); atomicAdd(&prof[33], L.prof[1]); atomicAdd(&prof[34], L.prof[2]); atomicAdd(&prof[35], L.prof[3]); }
-		if (shift <= 0) continue;                                // nothing below the last byte
-		const int next = rs_next_level(R.vary, shift - 8);
-		// buckets of this level: <= 64 records are insertion-sorted now (ksort.h:142), larger ones queue for the next level that can split them
-		if (next < 0) continue;                                  // the keys of a bucket agree in every lower byte: nothing left to order
-		rs_split_buckets(beg, n, shift, cnt, off, L, lane, [&](int64_t rb, int64_t len) {
-			const uint64_t g0 = R.start + (uint64_t)rb;
-			if (hint.dupc && hint.dupc[g0 + (uint64_t)len - 1] == hint.dupc[g0]) {
-				// no two equal keys in this bucket: its final order is the sorted order
-				for (int64_t i = lane; i < len; i += 64) { u128 v; v.x = hint.sx[g0 + (uint64_t)i]; v.y = hint.sy[g0 + (uint64_t)i]; a[g0 + (uint64_t)i] = v; }
-				rs_fence_wg();
-				return;
-			}
-			rs_push2(out, n_out, out_s, n_out_s, cap, g0, (uint32_t)len, next, R.vary, lane);
-		});
-		if (prof && lane == 0) { const unsigned long long tk2 = wall_clock64(); atomicAdd(&prof[2], tk2 - tk1); atomicMax(&prof[3], tk2 - tk1); }
+		uint32_t *rend = rend_all ? rend_all + R.start : nullptr;
+		while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend, tmp_all ? tmp_all + R.start : nullptr)) shift = rs_next_level(R.vary, shift - 8);
+		const int next = shift > 0 ? rs_next_level(R.vary, shift - 8) : -1;
+		if (next >= 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the scattered records, before any child is announced
+			rs_split_buckets(beg, n, shift, cnt, off, L, lane, [&](int64_t rb, int64_t len) {
+				const uint64_t g0 = R.start + (uint64_t)rb;
+				if (hint.dupc && hint.dupc[g0 + (uint64_t)len - 1] == hint.dupc[g0]) {
+					for (int64_t i = lane; i < len; i += 64) { u128 v; v.x = hint.sx[g0 + (uint64_t)i]; v.y = hint.sy[g0 + (uint64_t)i]; a[g0 + (uint64_t)i] = v; }
+					rs_fence_wg();
+					return;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (buckets insertion-sorted in between wrote records too)
+				rs_apush(q, ready, Q, out_s, n_out_s, cap, g0, (uint32_t)len, next, R.vary, lane);
+			});
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (lane == 0) __hip_atomic_fetch_sub(&Q->pending, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
+}
+
+// k_rs_init's queue entries become the first slots of the asynchronous queue
+__global__ void k_rs_async_seed(const uint32_t *__restrict__ n_in, uint32_t cap, uint32_t *__restrict__ ready, RsQueue *__restrict__ Q)
+{
+	const uint32_t n = *n_in < cap ? *n_in : cap;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) ready[i] = 1u;
+	if (i == 0) { Q->head = 0; Q->tail = n; Q->pending = n; Q->overflow = *n_in > cap ? 1u : 0u; }
 }
 
 // ---- runs of at most RS_SMALL records: the whole remaining sort inside LDS, one wave per run ----
@@ -230,6 +326,18 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	if (rend.p && !getenv("PGA_NO_TWOBUCKET")) tmp2.alloc(n_total);
 	double pass_ms[9] = {0};
 	if (verbose) { pass_ms[8] = et.stop(); }
+	// (measured: the persistent waves of the dependency-driven variant hold their LDS and slots while they wait and starve the kernels of
+	// the other parts -- 7.9 -> 22 s per step; it stays behind PGA_RS_ASYNC=1)
+	static const bool sync_passes = getenv("PGA_RS_ASYNC") == nullptr;
+	DBuf<uint32_t> ready; DBuf<RsQueue> Qd(1);
+	bool async_overflow = false;
+	if (!sync_passes) {
+		ready.alloc(cap); ready.zero(st);
+		EventTimer ep(st);
+		hipLaunchKernelGGL(k_rs_async_seed, dim3((cap + 255) / 256), dim3(256), 0, st, ctr.p + 0, cap, ready.p, Qd.p);
+		hipLaunchKernelGGL(k_rs_async, dim3(grid), dim3(64), 0, st, a, q0.p, ready.p, Qd.p, qs.p, ctr.p + 18, cap, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p);
+		if (verbose) pass_ms[0] = ep.stop();
+	} else
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
 		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p);
@@ -258,9 +366,10 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	const double ms = et.stop();
 	if (tm) { tm->kern[K_SORT].ms += ms; tm->kern[K_SORT].launches += 1; tm->kern[K_SORT].alg_bytes += 32.0 * (double)n_total; }   // every record read and written once (per level, at least one)
 	std::vector<uint32_t> h = ctr.download(st);
+	if (!sync_passes) async_overflow = Qd.download(st)[0].overflow != 0;
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   sort replay: %llu records in %d arrays, %.3f ms; runs per pass: %u %u %u %u %u %u %u %u; ms: init %.1f, passes %.1f %.1f %.1f %.1f %.1f; %u small runs %.1f ms\n", (unsigned long long)n_total, n_seg, ms, h[0], h[2], h[4], h[6], h[8], h[10], h[12], h[14], pass_ms[8], pass_ms[0], pass_ms[1], pass_ms[2], pass_ms[3], pass_ms[4], h[18], ms_small);
 	for (int pass = 0; pass <= 8; ++pass) if (h[2 * pass] > cap) throw std::runtime_error("pga: run queue overflow in the sort replay");
-	if (h[18] > cap) throw std::runtime_error("pga: run queue overflow in the sort replay");
+	if (h[18] > cap || async_overflow) throw std::runtime_error("pga: run queue overflow in the sort replay");
 }
 
 } // namespace pga
