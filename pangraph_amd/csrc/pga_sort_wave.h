@@ -516,23 +516,50 @@ __device__ inline void rs_split_buckets(u128 *beg, int64_t n, int shift, const u
 			big((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)off[k], src), (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)cnt[k], src));
 		}
 		if (!sm) continue;
-		if (g_hi - g_lo <= RS_POOL) {
-			for (uint32_t i = g_lo + (uint32_t)lane; i < g_hi; i += 64) L.win[i - g_lo] = ld128(&beg[i]);
-			rs_fence_wave();
-			bool changed = false;
-			if (cnt[k] > 1 && cnt[k] <= 64) {
-				u128 *b0 = L.win + (off[k] - g_lo), *b1 = b0 + cnt[k];
-				for (u128 *q = b0 + 1; q < b1; ++q) if (q->x < (q - 1)->x) { changed = true; break; }
-				if (changed) rs_insertion(b0, b1);
+		// the small buckets of the group, staged in the window pool as many lanes' buckets at a time as fit (a 15 k-record run has
+		// 64 x 60 records per group: twice the pool -- the generic window scan it used to fall back to cost 3.7 ms per run)
+		int lane_lo = 0;
+		while (lane_lo < 64) {
+			int span = 64 - lane_lo;
+			uint32_t s_lo, s_hi;
+			for (;;) {
+				s_lo = (uint32_t)__builtin_amdgcn_readlane((int)off[k], __builtin_amdgcn_readfirstlane(lane_lo));
+				s_hi = (uint32_t)__builtin_amdgcn_readlane((int)(off[k] + cnt[k]), __builtin_amdgcn_readfirstlane(lane_lo + span - 1));
+				if (s_hi - s_lo <= RS_POOL || span == 1) break;
+				span = (span + 1) / 2;
 			}
-			rs_fence_wave();
-			if (__ballot(changed)) {
-				for (uint32_t i = g_lo + (uint32_t)lane; i < g_hi; i += 64) beg[i] = L.win[i - g_lo];
-				rs_fence_wg();
+			const bool mine_in = lane >= lane_lo && lane < lane_lo + span;
+			if (s_hi - s_lo <= RS_POOL && __ballot(mine_in && cnt[k] > 1 && cnt[k] <= 64)) {
+				for (uint32_t i = s_lo + (uint32_t)lane; i < s_hi; i += 64) L.win[i - s_lo] = ld128(&beg[i]);
+				rs_fence_wave();
+				bool changed = false;
+				if (mine_in && cnt[k] > 1 && cnt[k] <= 64) {
+					u128 *b0 = L.win + (off[k] - s_lo), *b1 = b0 + cnt[k];
+					for (u128 *q = b0 + 1; q < b1; ++q) if (q->x < (q - 1)->x) { changed = true; break; }
+					if (changed && cnt[k] <= 12) rs_insertion(b0, b1);        // a handful of records: one lane each, all buckets at once
+				}
+				// larger buckets one after the other, the whole wave on each: the insertion sort of ksort.h:101-112 is a STABLE sort, i.e. record i
+				// lands at rank #{j: x_j < x_i or (x_j == x_i and j < i)} -- m broadcast reads per lane instead of ~m*m/4 moves of 16 bytes by one
+				unsigned long long coop = __ballot(changed && cnt[k] > 12);
+				while (coop) {
+					const int src = __ffsll((long long)coop) - 1;
+					coop &= coop - 1;
+					const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)(off[k] - s_lo), src), m = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k], src);
+					u128 mine; mine.x = mine.y = 0;
+					if ((uint32_t)lane < m) mine = L.win[b + (uint32_t)lane];
+					uint32_t rank = 0;
+					for (uint32_t j = 0; j < m; ++j) { const uint64_t xj = L.win[b + j].x; rank += (xj < mine.x) | ((xj == mine.x) & (j < (uint32_t)lane)); }
+					rs_fence_wave();
+					if ((uint32_t)lane < m) L.win[b + rank] = mine;
+					rs_fence_wave();
+				}
+				rs_fence_wave();
+				if (__ballot(changed)) {
+					for (uint32_t i = s_lo + (uint32_t)lane; i < s_hi; i += 64) beg[i] = L.win[i - s_lo];
+					rs_fence_wg();
+				}
 			}
-		} else {
-			// the group spans more than the pool: generic window scan over its range (large buckets were queued above)
-			rs_runs_wave(beg + g_lo, (int64_t)(g_hi - g_lo), shift, L, lane, [&](int64_t, int64_t) {});
+			lane_lo += span;
 		}
 	}
 	(void)n;
