@@ -320,12 +320,18 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 	for (int d = lane; d < 256; d += 64) L.head[d] = 0, L.wbase[d] = RS_NONE;
 	rs_fence_wave();
 	// digit histogram, four loads in flight per lane
-	for (int64_t i0 = 0; i0 < n; i0 += 256) {
+	uint32_t n_druns = 0, d_prev = 257u;                        // digit runs of the original order (counted here: the run-length walk and its
+	for (int64_t i0 = 0; i0 < n; i0 += 256) {                   // backward pass over the array only pay when runs are long)
 		uint32_t dg[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; dg[k] = i < n ? (uint32_t)((beg[i].x >> shift) & 255) : 256u; }
 #pragma unroll
-		for (int k = 0; k < 4; ++k) if (dg[k] < 256u) atomicAdd(&L.head[dg[k]], 1u);
+		for (int k = 0; k < 4; ++k) {
+			if (dg[k] < 256u) atomicAdd(&L.head[dg[k]], 1u);
+			const uint32_t left = (uint32_t)wave_shr1((int)dg[k], (int)d_prev);
+			n_druns += (uint32_t)__popcll(__ballot(dg[k] < 256u && dg[k] != left));
+			d_prev = (uint32_t)__builtin_amdgcn_readlane((int)dg[k], 63);
+		}
 	}
 	rs_fence_wave();
 	// counts -> offsets: lane l holds buckets l, l+64, l+128, l+192
@@ -348,7 +354,7 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 		for (int k = 3; k >= 0; --k) if (nonempty[k]) { const int l = __ffsll((long long)nonempty[k]) - 1; dA = l + 64 * k; cA = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k], l); }
 		if (rs_level_two(beg, n, shift, (uint32_t)dA, cA, tmp, rend, lane)) return true;
 	}
-	if (rend && n >= 4096) {
+	if (rend && n >= 4096 && (uint64_t)n >= 64ull * n_druns) {
 		// digit runs of the original order, back to front: rend[p] = first position after p whose digit differs
 		uint32_t nb = 0, carry_end = (uint32_t)n;
 		for (int64_t c0 = (n - 1) & ~63LL; c0 >= 0; c0 -= 64) {
