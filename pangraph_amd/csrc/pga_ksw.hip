@@ -349,9 +349,10 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //   9      large unbanded first-pass gap fills, one problem spread over several workgroups in column strips (pga_ksw_strips.hip)
 //   10     banded problems whose band ring fits 2048 columns (end extensions, banded fills): rows in registers, one barrier per
 //          diagonal (pga_ksw_lanes.hip); what classes 2 and 3 held before
+//   11     like 10 with 1024-thread workgroups: rings of up to 8192 columns (exact second passes of 2-8 kb, wide bands)
 //   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
 //          first passes of class 4 keep room for their sequences in LDS)
-#define DP_NCLASS 11
+#define DP_NCLASS 12
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -377,10 +378,10 @@ size_t strips_bnd_words(const DpJob &j);
 void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, const uint8_t *nt4, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                           uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
-bool lanes_eligible(const DpJob &j);
+bool lanes_eligible(const DpJob &j, int nt);
 size_t lanes_cig_bytes(int q_cap, int t_cap);
 size_t lanes_chunk_bytes();
-void launch_extd2_lanes(unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
+void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
@@ -393,7 +394,11 @@ static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
-	if (!no_lanes && allow_band && lanes_eligible(j)) return 10;      // (allow_band is off in the second pass over problems a kernel handed back)
+	if (!no_lanes && allow_band && lanes_eligible(j, 256)) return 10;      // (allow_band is off in the second pass over problems a kernel handed back)
+	// (measured slower than the workgroup kernel: sixteen waves each pay the per-diagonal skeleton, four to a SIMD -- 2 x 4 kb second passes
+	// 56 ms against 11-20 ms; kept behind PGA_LANES_BIG=1)
+	static const bool lanes_big = getenv("PGA_LANES_BIG") != nullptr;
+	if (!no_lanes && lanes_big && allow_band && lanes_eligible(j, 1024)) return 11;
 	const size_t rows = (size_t)14 * wide_ring(j), l = rows + 2 * (size_t)wide_seqcap(j);
 	if (l <= 48 * 1024) return 2;
 	if (l <= 76 * 1024) return 3;
@@ -532,7 +537,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
 	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd; DBuf<uint64_t> d_slab_off, d_bnd_off; };   // (class 9: block tables, strip boundaries)
@@ -551,11 +556,11 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// scratch slabs: one grow-only buffer per launch lane (classes of a lane run one after the other and share it); sized
 	// before anything is launched so that no buffer moves under a running kernel
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
-	uint32_t lanes_pool_chunks = 0;
+	uint32_t lanes_pool_chunks[2] = {0, 0};
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
 		static const int c8w = getenv("PGA_C8_WAVES") ? atoi(getenv("PGA_C8_WAVES")) : 16;
-		size_t n_waves = c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
+		size_t n_waves = c == 11 ? 256 : c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
 		if (c == 9) {                                                                   // every problem of the class is in flight at once, each with its whole matrix
@@ -564,7 +569,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], tot);
 			continue;
 		}
-		if (c == 10) {
+		if (c == 10 || c == 11) {
 			// one CIGAR buffer per workgroup + a pool of direction-matrix chunks: what the class would need if every problem ran to its
 			// last diagonal, but not more than half of the budget (most extensions z-drop early; a dry pool hands problems back)
 			int q_cap = 16, t_cap = 16; size_t tot = 0;
@@ -572,7 +577,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			const size_t cigb = n_waves * lanes_cig_bytes(q_cap, t_cap);
 			size_t pool = std::min(tot, std::max(budget / 2, 4 * n_waves * lanes_chunk_bytes()));
 			pool = std::max(pool, 2 * n_waves * lanes_chunk_bytes()) / lanes_chunk_bytes() * lanes_chunk_bytes();
-			lanes_pool_chunks = (uint32_t)(pool / lanes_chunk_bytes());
+			lanes_pool_chunks[c - 10] = (uint32_t)(pool / lanes_chunk_bytes());
 			waves_of[c] = n_waves;
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], cigb + pool + 256);
 			continue;
@@ -594,7 +599,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
-	static const int launch_order[DP_NCLASS] = {9, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
+	static const int launch_order[DP_NCLASS] = {9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
 		if (cls[c].empty()) continue;
@@ -640,10 +645,10 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
 			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
 		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		else if (c == 10) {
+		else if (c == 10 || c == 11) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_extd2_lanes((unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, lanes_pool_chunks, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_extd2_lanes(c == 11 ? 1024 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
@@ -709,11 +714,11 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 				part_b[(size_t)s] += bases; part_c[(size_t)s] += cells;
 			});
 			double bases = 0, cells = 0; for (double x : part_b) bases += x; for (double x : part_c) cells += x;
-			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c == 9 ? K_STRIPS : c == 10 ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
+			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c == 9 ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->kern[kk].cells += cells; tm->dp_bases += bases;
 		}
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
-		if (((c >= 2 && c <= 4) || c == 7 || c == 10) && verbose) {
+		if (((c >= 2 && c <= 4) || c == 7 || c == 10 || c == 11) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];

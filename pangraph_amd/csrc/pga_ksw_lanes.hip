@@ -38,7 +38,7 @@ namespace pga {
 #define LBT 64
 #define LANES_C 8
 #define LANES_CHUNK (2u << 20)     // bytes of a direction-matrix chunk
-#define LANES_MAXCHUNK 64
+#define LANES_MAXCHUNK 192
 
 __device__ __forceinline__ void diag_range_l(int r, int qlen, int tlen, int w, int &st0, int &en0)
 {
@@ -530,8 +530,9 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 	}
 }
 
-// a problem the lane kernel takes: its band ring fits the NT*8 columns of a 256-thread workgroup and its query fits LDS
-bool lanes_eligible(const DpJob &j)
+// a problem the lane kernel takes: its band ring fits the NT*8 columns of an NT-thread workgroup (256: end extensions and banded fills, many per
+// CU; 1024: the few exact second passes and wide bands of up to 8 k columns, four waves per SIMD) and its windows fit LDS
+bool lanes_eligible(const DpJob &j, int nt)
 {
 	if (j.flag & PGA_JOB_LL) return false;
 	if (j.qlen < 1 || j.tlen < 1 || j.qlen > 28 * 1024 || j.tlen > 28 * 1024) return false;
@@ -539,7 +540,7 @@ bool lanes_eligible(const DpJob &j)
 	const int w = j.w < 0 ? (j.tlen > j.qlen ? j.tlen : j.qlen) : j.w;
 	int R = ((w < j.tlen ? w : j.tlen) + 15) / 16 * 16 + 96;
 	if (R > T) R = T;
-	if (R > 256 * LANES_C) return false;
+	if (R > nt * LANES_C) return false;
 	int n_col = j.qlen < j.tlen ? j.qlen : j.tlen;
 	n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
 	return ((size_t)j.qlen + j.tlen) / (LANES_CHUNK / (size_t)n_col) + 2 <= LANES_MAXCHUNK;
@@ -548,13 +549,20 @@ bool lanes_eligible(const DpJob &j)
 size_t lanes_cig_bytes(int q_cap, int t_cap) { return (4 * ((size_t)q_cap + t_cap + 8) + 255) & ~(size_t)255; }
 size_t lanes_chunk_bytes() { return LANES_CHUNK; }
 
-void launch_extd2_lanes(unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
-                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
+template <int NT> static void launch_lanes_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab,
+                                              size_t cig_bytes, uint32_t n_chunks, int q_cap, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
 {
 	static bool attr_set = false;
-	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_lanes<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
+	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_lanes<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
+	hipLaunchKernelGGL(k_extd2_lanes<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, cig_bytes, n_chunks, q_cap, res, pool, cursor, pool_cap);
+}
+
+void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
+                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
+{
 	const size_t lds = (((size_t)q_cap + 15) & ~(size_t)15) + (((size_t)t_cap + 15) & ~(size_t)15) + 16;
-	hipLaunchKernelGGL(k_extd2_lanes<256>, dim3(n_blocks), dim3(256), lds, st, jobs, n_jobs, nt4, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
+	if (nt >= 1024) launch_lanes_nt<1024>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
+	else launch_lanes_nt<256>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga
