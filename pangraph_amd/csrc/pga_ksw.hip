@@ -577,7 +577,7 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			const size_t cigb = n_waves * lanes_cig_bytes(q_cap, t_cap);
 			size_t pool = std::min(tot, std::max(budget / 2, 4 * n_waves * lanes_chunk_bytes()));
 			pool = std::max(pool, 2 * n_waves * lanes_chunk_bytes()) / lanes_chunk_bytes() * lanes_chunk_bytes();
-			lanes_pool_chunks[c - 10] = (uint32_t)(pool / lanes_chunk_bytes());
+			lanes_pool_chunks[c - 10] = (uint32_t)(pool / lanes_chunk_bytes()) | (pool >= tot ? 0x80000000u : 0u);   // (top bit: the pool covers every problem in full: no reservation tiers)
 			waves_of[c] = n_waves;
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], cigb + pool + 256);
 			continue;

@@ -69,7 +69,7 @@ struct __attribute__((aligned(16))) LaneRec {      // what a wave publishes per 
 template <int NT>
 __global__ __launch_bounds__(NT)
 void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
-                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t cig_bytes, uint32_t n_chunks, int q_cap,
+                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t cig_bytes, uint32_t n_chunks_arg, int q_cap,
                    DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
 	constexpr int NW = NT / 64, C = LANES_C, RC = NT * C;
@@ -82,6 +82,8 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 	// scratch: one CIGAR buffer per workgroup, then the pool of direction-matrix CHUNKS.  A workgroup takes chunks as its diagonals
 	// need them (most extensions z-drop after ~1.5 k diagonals and touch 2 MB of a matrix that would reserve 30 MB) and keeps them
 	// for its next problems; job_counter[1] is the pool's cursor.  An exhausted pool hands the problem back (n_cigar = -9).
+	const uint32_t n_chunks = n_chunks_arg & 0x7fffffffu;
+	const bool tiers = !(n_chunks_arg >> 31);
 	uint32_t *cig_tmp = (uint32_t*)(slab_all + (size_t)blockIdx.x * cig_bytes);
 	uint8_t *pool_base = slab_all + (size_t)gridDim.x * cig_bytes;
 	__shared__ uint32_t s_chunk[LANES_MAXCHUNK];
@@ -131,7 +133,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 			if (c < LANES_MAXCHUNK && c >= s_have) {
 				// the second half of the pool is reserved progressively for the workgroups with the lower indices (they hold the largest
 				// problems: the queue is sorted): when the pool runs dry the others give up early instead of everybody late
-				const uint32_t limit = n_chunks - (uint32_t)((unsigned long long)(n_chunks / 2) * blockIdx.x / gridDim.x);
+				const uint32_t limit = tiers ? n_chunks - (uint32_t)((unsigned long long)(n_chunks / 2) * blockIdx.x / gridDim.x) : n_chunks;
 				uint32_t id = 0xffffffffu;
 				if (c < 2 || __hip_atomic_load(job_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < limit) {
 					id = atomicAdd(job_counter + 1, 1u);
