@@ -71,6 +71,19 @@ def pmc_traffic(kernel: str):
     return tot / n if n else None
 
 
+def pmc_issue():
+    """VALU / LDS issue fractions of the DP kernels (SQ_ACTIVE_INST_VALU|LDS / SQ_WAVE_CYCLES) from the committed rocprofv3 --pmc passes of this
+    same workload (profiles/r*_pmc_issue_dp_kernels.json, dev/r02_pmc_issue.sh).  NOT measured in this run; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue_dp_kernels.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1])).get("kernels", {})
+    return {"source": os.path.relpath(files[-1], ROOT),
+            "kernels": {k.replace("pga::", ""): {"valu_issue_frac": v.get("valu_issue_frac_of_wave_cycles"), "lds_issue_frac": v.get("lds_issue_frac_of_wave_cycles")}
+                        for k, v in d.items() if any(t in k for t in ("k_extd2", "k_gapfill", "k_ll_i16", "k_approx_strips"))}}
+
+
 def _cpu_worker(args):
     so, seqs, names = args
     from pangraph_amd.mm2ffi import Mm2Lib
@@ -290,7 +303,8 @@ def main():
                      "note": "device_ms_per_step are HIP-event times on each kernel's own stream; streams overlap, so they do not add up to ms_per_step",
                      "kernels": table},
         "dp": {"cells_evaluated": dp_cells, "gcups_over_dp_kernel_time": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
-               "gcups_over_step": dp_cells / (ms_step * 1e-3) / 1e9, "nominal_cells_qlen_x_tlen": st["n_dp_cells"], "jobs": st["n_dp_jobs"]},
+               "gcups_over_step": dp_cells / (ms_step * 1e-3) / 1e9, "nominal_cells_qlen_x_tlen": st["n_dp_cells"], "jobs": st["n_dp_jobs"],
+               "issue_counters": pmc_issue()},
         "stages_s": {k: st[k] for k in ("upload", "sketch", "index", "seed", "chain", "align", "total")},
         "counts": {k: st[k] for k in ("n_bases", "n_minimizers", "n_anchors", "n_dp_jobs", "n_matches")},
         "n_matches_gathered": last["n_matches"],
