@@ -388,7 +388,7 @@ static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
 {
 	static const bool no_lanes = getenv("PGA_NO_LANES") != nullptr;     // A/B: the workgroup kernel takes the banded problems again
 	if (j.flag & PGA_JOB_LL) return 6;
-	if (strips_eligible(j, P)) return 9;
+	if (strips_eligible(j, P) && (allow_band || (j.flag & EZ_APPROX_MAX))) return 9;      // (exact problems the strips handed back go to the workgroup kernel)
 	if (allow_band && j.flag == EZ_APPROX_MAX && j.w >= j.qlen && j.w >= j.tlen && j.qlen >= 1 && j.tlen >= 1 && j.qlen <= BAND_MAXLEN && j.tlen <= BAND_MAXLEN &&
 	    j.tlen - j.qlen <= 12 && j.qlen - j.tlen <= 12) return 8;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;

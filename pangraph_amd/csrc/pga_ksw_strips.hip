@@ -19,6 +19,7 @@
 #include "pga_dp.h"
 #include "pga_wave.h"
 #include "pga_pk16.h"
+#include <cstring>
 
 namespace pga {
 
@@ -47,6 +48,13 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	__shared__ uint8_t s_win[ST_BT * ST_BT];
 	__shared__ uint32_t s_last;
 	__shared__ uint32_t s_bnd[16];                        // boundary words of 2 x 8 diagonals: slot (d - first) & 15 holds bnd_in[d]
+	// exact-maximum problems (second passes: flag == 0): H of the strip's columns; H of the diagonal's LAST column (it runs along the first
+	// query row from strip to strip, then stays on the last target column); the waves' best keys of a diagonal, by diagonal parity
+	__shared__ int32_t s_H[ST_S + 16];
+	__shared__ int32_t s_hen;
+	__shared__ uint32_t s_part[4][ST_NT / 64];            // (four diagonals deep: a diagonal's key is published two diagonals later, see s_late)
+	__shared__ uint32_t s_late[4];                        // odd target length: the key of H[tlen-1], which is only known one diagonal late
+	__shared__ int32_t s_hm2[2];                          // ... and H[tlen-2] as each diagonal left it, by parity
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t jl = blk_job[blockIdx.x], k = blk_strip[blockIdx.x];
 	const DpJob J = jobs[jl];
@@ -60,6 +68,9 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const int n_strips = (tlen + ST_S - 1) / ST_S;
+	const bool exact = !(J.flag & 0x08);
+	const int qe_h = P.q + P.e;
+	const size_t Ld = (size_t)(qlen + tlen);
 	const int c0 = (int)k * ST_S, c1 = c0 + ST_S < tlen ? c0 + ST_S : tlen;
 	int n_col = qlen < tlen ? qlen : tlen;
 	n_col = ((n_col + 15) / 16 + 1) * 16;                 // (w + 1 > both lengths)
@@ -67,6 +78,12 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	uint32_t *cig_tmp = (uint32_t*)(pmat + (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15));
 	uint32_t *bnd_in = k > 0 ? bnd_all + bnd_off[jl] + (size_t)(k - 1) * (size_t)(qlen + tlen) : nullptr;      // written by strip k-1, indexed by diagonal
 	uint32_t *bnd_out = (int)k + 1 < n_strips ? bnd_all + bnd_off[jl] + (size_t)k * (size_t)(qlen + tlen) : nullptr;
+	// exact mode, behind the boundary words: one key per strip and diagonal; H of the diagonal's last column and of its first column (for
+	// the end-of-sequence scores) per diagonal; one word per strip: H of its last column at the moment the diagonal's end stood there
+	uint32_t *keys_all = bnd_all + bnd_off[jl] + (size_t)(n_strips - 1) * Ld;
+	uint32_t *keys = keys_all + (size_t)k * Ld;
+	int32_t *hen_arr = (int32_t*)(keys_all + (size_t)n_strips * Ld), *hst_arr = hen_arr + Ld;
+	uint32_t *hb_all = (uint32_t*)(hst_arr + Ld);
 	auto target_at = [&](int i) -> int { return i < tlen ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 0; };
 	auto query_at = [&](int j) -> int {
 		if (j < 0 || j >= qlen) return 0;
@@ -80,7 +97,10 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 		s_x[0][t] = s_x[1][t] = s_v[0][t] = s_v[1][t] = (int8_t)(-q - e);
 		s_x2[0][t] = s_x2[1][t] = (int8_t)(-q2 - e2);
 		s_t[t] = (uint8_t)target_at(c0 + t);
+		s_H[t] = KSW_NEG_INF;
 	}
+	if (tid == 0) s_hen = KSW_NEG_INF;
+	if (tid < 4) s_late[tid] = 0;
 	for (int p = tid; p < qlen + 64; p += ST_NTL) { const int j = qlen - 1 - (p - 32); s_q[p] = (j >= 0 && j < qlen) ? (uint8_t)query_at(j) : (uint8_t)0; }
 	__syncthreads();
 
@@ -115,6 +135,14 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 			continue;
 		}
+		if (exact && tid == 0 && r >= r_first + 2) {           // the key of the diagonal before the previous one: every contribution to it is in LDS by now
+			uint32_t kk = s_late[(r - 2) & 3];
+			s_late[(r - 2) & 3] = 0;
+#pragma unroll
+			for (int wv = 0; wv < ST_NT / 64; ++wv) { const uint32_t o = s_part[(r - 2) & 3][wv]; kk = o > kk ? o : kk; }
+			keys[r - 2] = kk;
+		}
+		uint32_t kbest = 0;
 		// left boundary of the strip's first column
 		int x1, v1, x21;
 		if (c0 == 0) {
@@ -168,10 +196,78 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 			// the strip's last column feeds the strip on the right
 			if (bnd_out && t + 1 == c1 - 1 && c1 - 1 >= st0 && c1 - 1 <= en0)
 				__hip_atomic_store(&bnd_out[r], 0x80000000u | (uint32_t)(xn8 >> 8) | (uint32_t)(vn8 >> 8) << 8 | (uint32_t)(x2n8 >> 8) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (exact) {
+				// H[t] += v[t] over [st0, en0); H[en0] = H[en0-1](as the previous diagonal left it) + u[en0] (ksw2_extd2_sse.c:325-340).  The
+				// target length is even (eligibility), so tlen-2 and tlen-1 are one pair: the owner of en0 either holds en0-1 as the low column
+				// of its pair, or en0 moved on by one column and H[en0-1] is what the previous diagonal's owner left in s_hen (in the strip on
+				// the left when en0 is this strip's first column).  The maximum with the reference's tie order (H[en0] first, then four lanes
+				// by (t - st0) & 3 over [st0, en1), then the tail) is one key per column: (clamp16(H) + 32768) << 16 | field << 12 | 511 - column.
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				const uint16_t un8 = pack_i8x2(un);
+				const int old0 = s_H[l], old1 = s_H[l + 1];
+#pragma unroll
+				for (int hh = 0; hh < 2; ++hh) {
+					const int tc = t + hh, lc = l + hh;
+					if (tc < lo || tc > hi) continue;
+					const int vv = (int)(int8_t)(hh ? vn8 >> 8 : vn8 & 0xff), uu = (int)(int8_t)(hh ? un8 >> 8 : un8 & 0xff);
+					int h; uint32_t field;
+					if (tc == en0) {
+						if (r == 0) h = vv - qe_h;
+						else if (hh == 0 && en0 < r) {
+							// odd target length, the diagonal's end rests on column tlen-1 = the LOW column of its pair: H[tlen-2] belongs to
+							// another thread, which is changing it right now.  H[en0] of the PREVIOUS diagonal follows from what that diagonal
+							// left behind: H[tlen-2](new) - v[tlen-2](new) is H[tlen-2] before its update, plus u[tlen-1](new).  Nobody reads
+							// H[tlen-1] (there is no column to its right): its key and its value are simply recorded one diagonal late.
+							if (r - 1 >= tlen) {
+								const int hl = s_hm2[(r - 1) & 1] - vl + (int)ut.x;
+								hen_arr[r - 1] = hl;
+								const int hcl = hl < -32768 ? -32768 : hl > 32767 ? 32767 : hl;
+								s_late[(r - 1) & 3] = ((uint32_t)(hcl + 32768) << 16) | 8u << 12 | (uint32_t)(511 - lc);
+							}
+							continue;
+						} else {
+							int hp;
+							if (hh == 1) hp = old0;
+							else if (lc > 0 || k == 0) hp = s_hen;
+							else { uint32_t wd; do wd = __hip_atomic_load(&hb_all[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while (!(wd >> 31)); hp = (int)(wd & 0x7fffffffu) - 0x20000000; }
+							h = hp + uu;
+						}
+						field = 8u;
+						s_hen = h;
+						hen_arr[r] = h;
+						if (bnd_out && tc == c1 - 1) __hip_atomic_store(&hb_all[k], 0x80000000u | ((uint32_t)(h + 0x20000000) & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					} else {
+						h = (hh ? old1 : old0) + vv;
+						field = 7u - (tc < en1 ? (uint32_t)((tc - st0) & 3) : 4u);
+						if ((tlen & 1) && tc == tlen - 2) s_hm2[r & 1] = h;
+					}
+					s_H[lc] = h;
+					if (tc == st0 && r - st0 == qlen - 1) hst_arr[r] = h;
+					const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;
+					const uint32_t key = ((uint32_t)(hc + 32768) << 16) | field << 12 | (uint32_t)(511 - lc);
+					kbest = key > kbest ? key : kbest;
+				}
+			}
 		}
+		if (exact) { kbest = wave_max_u32(kbest); if (lane == 0) s_part[r & 3][wave] = kbest; }
 		// the barrier orders the LDS rows only: the direction bytes and the boundary word are fire-and-forget (a __syncthreads() would
 		// wait for every outstanding store to device memory on every diagonal); they are fenced once, before the completion counter
 		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+	if (exact && tid == 0) {                                  // the keys of the strip's last two diagonals (and, odd target length, the late H[tlen-1])
+		if ((tlen & 1) && c1 == tlen && r_last >= tlen) {
+			const int lc = tlen - 1 - c0;
+			const int hl = s_H[lc - 1] + (int)s_u[lc];          // (column tlen-2 is not part of the last diagonal: its H is the value before it)
+			hen_arr[r_last] = hl; hst_arr[r_last] = hl;       // (the last diagonal is the single cell (tlen-1, qlen-1))
+			const int hcl = hl < -32768 ? -32768 : hl > 32767 ? 32767 : hl;
+			s_late[r_last & 3] = ((uint32_t)(hcl + 32768) << 16) | 8u << 12 | (uint32_t)(511 - lc);
+		}
+		for (int rr = r_last - 1 > r_first ? r_last - 1 : r_first; rr <= r_last; ++rr) {
+			uint32_t kk = s_late[rr & 3];
+#pragma unroll
+			for (int wv = 0; wv < ST_NT / 64; ++wv) { const uint32_t o = s_part[rr & 3][wv]; kk = o > kk ? o : kk; }
+			keys[rr] = kk;
+		}
 	}
 	// ---- the last workgroup of the problem to finish walks the path back and scores it ----
 	__threadfence();
@@ -182,7 +278,56 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	__threadfence();
 	if (wave != 0) return;
 	int n_cigar = 0;
-	int i = tlen - 1, j = qlen - 1, state = 0; long long guard = 0;
+	int bi = tlen - 1, bj = qlen - 1;
+	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1, zdropped = 0;
+	if (exact) {
+		// The maxima of all diagonals are on record: what the reference decides diagonal by diagonal (ksw_apply_zdrop, the end-of-sequence
+		// scores) is decided here in one sweep, 64 diagonals per trip: a lane combines the strips' keys of its diagonal (equal H and field:
+		// the lower strip, then the lower column), then the trip's diagonals are taken in order.
+		const int n_diag = qlen + tlen - 1, zdrop = J.zdrop;
+		int sat = 0;
+		for (int r0 = 0; r0 < n_diag && !zdropped; r0 += 64) {
+			const int r = r0 + lane;
+			unsigned long long best = 0; int hen = KSW_NEG_INF, hst = KSW_NEG_INF;
+			if (r < n_diag) {
+				int st0, en0; st_range(r, qlen, tlen, st0, en0);
+				for (int kk = 0; kk < n_strips; ++kk) {
+					const int c0k = kk * ST_S, c1k = c0k + ST_S < tlen ? c0k + ST_S : tlen;
+					if (c0k <= en0 && c1k - 1 >= st0) {
+						const uint32_t key = keys_all[(size_t)kk * Ld + (size_t)r];
+						const unsigned long long comb = (unsigned long long)(key >> 12) << 14 | (unsigned long long)(31 - kk) << 9 | (unsigned long long)(key & 511u);
+						best = comb > best ? comb : best;
+					}
+				}
+				hen = hen_arr[r];
+				if (r - st0 == qlen - 1) hst = hst_arr[r];
+			}
+			const uint32_t h16 = (uint32_t)(best >> 18) & 0xffffu;
+			const int mH_l = (int)h16 - 32768, mt_l = (31 - (int)((best >> 9) & 31)) * ST_S + (511 - (int)(best & 511));
+			const int sat_l = r < n_diag && (h16 == 0 || h16 == 65535u) ? 1 : 0;
+			const int lim = n_diag - r0 < 64 ? n_diag - r0 : 64;
+			for (int ii = 0; ii < lim; ++ii) {
+				const int rr = r0 + ii;
+				const int mH = __builtin_amdgcn_readlane(mH_l, ii), mt = __builtin_amdgcn_readlane(mt_l, ii);
+				const int he = __builtin_amdgcn_readlane(hen, ii), hs = __builtin_amdgcn_readlane(hst, ii);
+				sat |= __builtin_amdgcn_readlane(sat_l, ii);
+				int st0, en0; st_range(rr, qlen, tlen, st0, en0);
+				if (en0 == tlen - 1 && he > ez_mte) ez_mte = he, ez_mte_q = rr - en0;
+				if (rr - st0 == qlen - 1 && hs > ez_mqe) ez_mqe = hs, ez_mqe_t = st0;
+				if (mH > ez_max) ez_max = mH, ez_max_t = mt, ez_max_q = rr - mt;
+				else if (mt >= ez_max_t && rr - mt >= ez_max_q) {
+					const int tl = mt - ez_max_t, ql = (rr - mt) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+					if (zdrop >= 0 && ez_max - mH > zdrop + l * e2) { zdropped = 1; break; }
+				}
+			}
+		}
+		if (sat) {                                            // a maximum outside the keys' 16 bits: the workgroup kernel redoes the problem
+			if (lane == 0) { DpRes R; memset(&R, 0, sizeof(R)); R.n_cigar = -9; res[jl] = R; }
+			return;
+		}
+		if (zdropped) bi = ez_max_t, bj = ez_max_q;
+	}
+	int i = bi, j = bj, state = 0; long long guard = 0;
 	uint32_t last_op = 0xffffffffu;
 	uint32_t run_len = 0;                               // the operation being extended lives in registers: one store per operation, not a
 	auto cg_push = [&](uint32_t op, uint32_t len) {     // read-modify-write of device memory per path step
@@ -234,7 +379,7 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
-	if (n_cigar >= 0) {
+	if (bi >= 0 && bj >= 0 && n_cigar >= 0) {
 		if (i >= 0) cg_push(2u, (uint32_t)(i + 1));
 		if (j >= 0) cg_push(1u, (uint32_t)(j + 1));
 	}
@@ -242,7 +387,7 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	// score of the path: cig_tmp runs from the end of the alignment to its start
 	int score = KSW_NEG_INF;
-	if (n_cigar > 0) {
+	if (n_cigar > 0 && !zdropped) {
 		int ti = tlen, qj = qlen; score = 0;
 		for (int c = 0; c < n_cigar; ++c) {
 			const uint32_t op = cig_tmp[c] & 0xf; const int len = (int)(cig_tmp[c] >> 4);
@@ -270,8 +415,8 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 		for (int c = lane; c < n_cigar; c += 64) cigar_pool[base + c] = cig_tmp[n_cigar - 1 - c];
 	if (lane == 0) {
 		DpRes R;
-		R.max = 0, R.max_q = -1, R.max_t = -1, R.mqe = KSW_NEG_INF, R.mqe_t = -1, R.mte = KSW_NEG_INF, R.mte_q = -1;
-		R.score = score, R.zdropped = 0, R.reach_end = 0, R.n_cigar = n_cigar, R.pad = qlen + tlen - 1, R.cigar_off = base;
+		R.max = ez_max, R.max_q = ez_max_q, R.max_t = ez_max_t, R.mqe = ez_mqe, R.mqe_t = ez_mqe_t, R.mte = ez_mte, R.mte_q = ez_mte_q;
+		R.score = score, R.zdropped = zdropped, R.reach_end = 0, R.n_cigar = n_cigar, R.pad = qlen + tlen - 1, R.cigar_off = base;
 		res[jl] = R;
 	}
 }
@@ -279,8 +424,11 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 bool strips_eligible(const DpJob &j, const DpParams &P)
 {
 	static const int min_t = getenv("PGA_STRIPS_MIN") ? atoi(getenv("PGA_STRIPS_MIN")) : 2048;      // below four strips the single workgroup wins
+	static const int min_x = getenv("PGA_STRIPS_EXACT_MIN") ? atoi(getenv("PGA_STRIPS_EXACT_MIN")) : 4096;   // exact second passes (every diagonal is computed, no early exit on z-drop): from 6 kb
 	if (min_t <= 0) return false;
-	return j.flag == 0x08 && j.w >= j.qlen && j.w >= j.tlen && j.tlen >= min_t && j.qlen >= 256 && j.qlen + 64 <= ST_QMAX && P.sc_mch >= 0 && P.sc_mch < 127;
+	if (!(j.w >= j.qlen && j.w >= j.tlen && j.qlen >= 256 && j.qlen + 64 <= ST_QMAX && P.sc_mch >= 0 && P.sc_mch < 127)) return false;
+	if (j.flag == 0x08) return j.tlen >= min_t;
+	return j.flag == 0 && min_x > 0 && j.tlen >= min_x && (j.tlen + ST_S - 1) / ST_S <= 32 && (j.tlen % ST_S) != 1;
 }
 size_t strips_slab_bytes(const DpJob &j)
 {
@@ -289,7 +437,11 @@ size_t strips_slab_bytes(const DpJob &j)
 	return (((((size_t)(j.qlen + j.tlen - 1) * n_col + 15) & ~(size_t)15) + 4 * ((size_t)j.qlen + j.tlen + 8)) + 255) & ~(size_t)255;
 }
 int strips_count(const DpJob &j) { return (j.tlen + ST_S - 1) / ST_S; }
-size_t strips_bnd_words(const DpJob &j) { return (size_t)(strips_count(j) > 1 ? strips_count(j) - 1 : 0) * (size_t)(j.qlen + j.tlen); }
+size_t strips_bnd_words(const DpJob &j)
+{
+	const size_t L = (size_t)(j.qlen + j.tlen), ns = (size_t)strips_count(j);
+	return (ns > 1 ? ns - 1 : 0) * L + ((j.flag & 0x08) ? 0 : ns * L + 2 * L + ns + 8);      // exact mode: keys, H of the first / last column per diagonal, hand-off words
+}
 
 void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, const uint8_t *nt4, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                           uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
