@@ -171,6 +171,8 @@ def main():
     single = os.environ.get("PGA_BENCH_SINGLE_DEVICE") == "1"
     if single:
         local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, the node exposes {torch.cuda.device_count()} (one rank per GPU; PGA_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 for debugging)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     batch.set_device(local)
