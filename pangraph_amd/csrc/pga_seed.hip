@@ -238,6 +238,12 @@ __global__ void k_split128(const u128 *__restrict__ a, uint64_t n, uint64_t *__r
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) { u128 v = a[i]; x[i] = v.x; y[i] = v.y; }
 }
+// the sort key of an anchor without its unused bits: strand | target id | target position, packed (same order as x)
+__global__ void k_anchor_key(const uint64_t *__restrict__ x, uint64_t n, int rid_bits, int pos_bits, uint64_t *__restrict__ key)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { const uint64_t v = x[i]; key[i] = (v >> 63) << (rid_bits + pos_bits) | ((v >> 32) & 0x7fffffffULL) << pos_bits | (v & 0xffffffffULL); }
+}
 __global__ void k_join128(const uint64_t *__restrict__ x, const uint64_t *__restrict__ y, uint64_t n, u128 *__restrict__ a)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,10 +369,20 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 		// query id (LSD order) equals a per-query sort, without the one-block-per-segment cost of a segmented sort
 		DBuf<uint32_t> idx0(n_a), idx1(n_a), qk0(n_a), qk1(n_a), idx2(n_a);
 		hipLaunchKernelGGL(k_iota32, dim3(nba), dim3(256), 0, st, idx0.p, n_a);
+		// x = strand << 63 | target << 32 | position uses 1 + log2(group size) + log2(longest sequence) of its 64 bits: the sort runs over a
+		// packed key of just those (25 bits for a pair of 5 Mbp genomes: four digit passes instead of eight)
+		uint32_t max_len = 1; int64_t max_grp = 1;
+		for (uint32_t l : S.len) max_len = std::max(max_len, l);
+		for (int g = 0; g < S.n_grp; ++g) max_grp = std::max<int64_t>(max_grp, S.grp_off[(size_t)g + 1] - S.grp_off[(size_t)g]);
+		int pos_bits = 1, rid_bits = 1;
+		while (pos_bits < 32 && (1ULL << pos_bits) <= (uint64_t)max_len) ++pos_bits;
+		while (rid_bits < 31 && (1LL << rid_bits) < max_grp) ++rid_bits;
+		hipLaunchKernelGGL(k_anchor_key, dim3(nba), dim3(256), 0, st, x0.p, n_a, rid_bits, pos_bits, x1.p);
+		DBuf<uint64_t> kc2(n_a);
 		size_t tb = 0;
-		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, x0.p, x1.p, idx0.p, idx1.p, n_a, 0, 64, st));
+		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, x1.p, kc2.p, idx0.p, idx1.p, n_a, 0, 1 + rid_bits + pos_bits, st));
 		DBuf<uint8_t> tmp(tb ? tb : 1);
-		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, x0.p, x1.p, idx0.p, idx1.p, n_a, 0, 64, st));
+		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, x1.p, kc2.p, idx0.p, idx1.p, n_a, 0, 1 + rid_bits + pos_bits, st));
 		if (n_seq > 1) {
 			hipLaunchKernelGGL(k_query_of_anchor, dim3(nba), dim3(256), 0, st, idx1.p, O.q_aoff.p, n_seq, n_a, qk0.p);
 			int bits = 1; while ((1LL << bits) < n_seq) ++bits;
