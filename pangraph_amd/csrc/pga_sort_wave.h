@@ -29,6 +29,7 @@ struct __attribute__((aligned(16))) RsLds {
 	uint8_t wslot[256];
 	uint32_t ppos[256]; uint32_t pk[256];   // the cycle being followed by the run-length walk: slot and bucket of every stop
 	uint32_t hpos[256], hrem[256]; uint16_t hdig[256];   // what sits at a bucket's head (digit, remainder of its digit run), valid while head == hpos: following a cycle reads LDS only
+	uint32_t vmark[256];         // bucket -> (path stamp << 8 | stop index) of its last visit: "was this bucket a stop of the path being followed" is one read
 	unsigned long long prof[4];  // ticks (diagnostics)
 };
 
@@ -85,8 +86,10 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 		const uint32_t pos = L.head[k], tk = L.tail[k];
 		if (pos < tk) { uint32_t r2 = rend[pos]; if (r2 > tk) r2 = tk; L.hpos[k] = pos; L.hdig[k] = (uint16_t)digit_at(pos); L.hrem[k] = r2 - pos; }
 		else L.hpos[k] = RS_NONE;
+		L.vmark[k] = 0;
 	}
 	rs_fence_wave();
+	uint32_t stamp = 0;                                     // (24 bits: a level of 2^24 paths would clear the marks; arrays are far shorter)
 #pragma unroll 1
 	for (int kk = 0; kk < 4; ++kk) {
 		unsigned long long todo = nonempty[kk];
@@ -100,16 +103,14 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 				if (d0 == i) { h = re; continue; }                      // a run of records that are home already
 				// follow the cycle that starts with beg[h] without moving anything
 				uint32_t M = re - h, k = d0; int Lc = 0; bool simple = true;
+				++stamp;
 				for (;;) {
-					bool hit = false;
-#pragma unroll
-					for (int c = 0; c < 4; ++c) hit |= lane + 64 * c < Lc && L.pk[lane + 64 * c] == k;
-					if (__ballot(hit) || Lc == 256) { simple = false; break; }
+					if ((L.vmark[k] >> 8) == stamp || Lc == 256) { simple = false; break; }
 					const uint32_t pos = L.head[k], tk = L.tail[k];
 					uint32_t dd, r2;
 					peek(k, pos, tk, dd, r2);
 					if (dd == k) { simple = false; break; }               // the record at the head is home: the token would push it along
-					if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; }
+					if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; L.vmark[k] = stamp << 8 | (uint32_t)Lc; }
 					rs_fence_wave();
 					++Lc;
 					if (r2 < M) M = r2;
@@ -148,18 +149,16 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 				uint32_t dst = d0;
 				while (dst != i) {
 					int Lc = 0, q0 = -1; uint32_t k = dst, T = 0xffffffffu; bool home = false;
+					++stamp;
 					for (;;) {
-						int hitq = 0x7fffffff;
-#pragma unroll
-						for (int c = 0; c < 4; ++c) if (lane + 64 * c < Lc && L.pk[lane + 64 * c] == k) hitq = lane + 64 * c;
-						hitq = wave_min_i32(hitq);
-						if (hitq != 0x7fffffff) { q0 = hitq; break; }
+						const uint32_t vm = L.vmark[k];
+						if ((vm >> 8) == stamp) { q0 = (int)(vm & 255u); break; }
 						if (Lc == 256) break;
 						const uint32_t pos = L.head[k], tk = L.tail[k];
 						uint32_t dd, r2u;
 						peek(k, pos, tk, dd, r2u);
 						if (dd == k) { home = true; break; }
-						if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; }
+						if (lane == 0) { L.ppos[Lc] = pos; L.pk[Lc] = k; L.vmark[k] = stamp << 8 | (uint32_t)Lc; }
 						rs_fence_wave();
 						++Lc;
 						if (dd == i) break;
@@ -170,14 +169,24 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 					}
 					// the stops before the loop (or all of them, when there is no loop worth taking): ordinary steps
 					const int n_plain = (q0 >= 0 && T >= 2) ? q0 : Lc;
-					for (int q = 0; q < n_plain; ++q) {
-						u128 *slot = &beg[L.ppos[q]];
-						const u128 nxt = ld128(slot);
-						if (lane == 0) { *slot = carry; L.head[L.pk[q]] = L.ppos[q] + 1; }
-						carry = nxt;
-						if (lane == 0) L.prof[3] += 1;
+					// (the stops are distinct slots and the path is known: stop q takes what stop q-1 held, the first one the carry -- 64 stops per
+					// trip with all loads in flight together, instead of one dependent load-store round trip to device memory per stop)
+					for (int qb = 0; qb < n_plain; qb += 64) {
+						const int q = qb + lane;
+						const bool on = q < n_plain;
+						u128 old; old.x = 0, old.y = 0;
+						uint32_t pp = 0;
+						if (on) { pp = L.ppos[q]; old = ld128(&beg[pp]); }
+						u128 in;
+						in.x = (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)old.x, (int)(uint32_t)carry.x) | (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)(old.x >> 32), (int)(uint32_t)(carry.x >> 32)) << 32;
+						in.y = (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)old.y, (int)(uint32_t)carry.y) | (uint64_t)(uint32_t)wave_shr1((int)(uint32_t)(old.y >> 32), (int)(uint32_t)(carry.y >> 32)) << 32;
+						if (on) { beg[pp] = in; L.head[L.pk[q]] = pp + 1; }
+						const int top = n_plain - qb > 64 ? 63 : n_plain - qb - 1;
+						carry.x = (uint64_t)(uint32_t)rl32((int)(uint32_t)old.x, top) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(old.x >> 32), top) << 32;
+						carry.y = (uint64_t)(uint32_t)rl32((int)(uint32_t)old.y, top) | (uint64_t)(uint32_t)rl32((int)(uint32_t)(old.y >> 32), top) << 32;
 					}
-					rs_fence_wave();
+					if (lane == 0) L.prof[3] += (unsigned long long)n_plain;
+					rs_fence_wg();
 					if (n_plain < Lc) {
 						// T rounds of the loop [q0, Lc)
 						if (lane == 0) { L.prof[0] += 1; L.prof[1] += T; }
