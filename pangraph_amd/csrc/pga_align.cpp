@@ -467,7 +467,7 @@ struct WalkAsk { RegTask *T; size_t seg; };
 
 struct QueryCtx {
 	int qid = 0; int32_t qlen = 0; int base = 0;   // base: first sequence of the query's group (record rids are group-relative)
-	std::vector<u128> a; int32_t n_a = 0;
+	u128 *a = nullptr; int32_t n_a = 0;   // the query's compacted anchors: a view into the chain stage's (pinned) download, flags are set in place
 	std::vector<RegTask*> list;      // the reference's regs[] order, grown by insertions
 	std::vector<std::unique_ptr<RegTask>> pool;
 	int rep_len = 0;
@@ -529,7 +529,7 @@ struct Driver {
 	// ---- plan (align.c:583-700): everything mm_align1 decides before its first DP call ----
 	void plan(QueryCtx &Q, RegTask &T)
 	{
-		Reg &r = T.r; Anchors A{Q.a.data(), Q.n_a}; const int32_t qlen = Q.qlen;
+		Reg &r = T.r; Anchors A{Q.a, Q.n_a}; const int32_t qlen = Q.qlen;
 		T.planned = true;
 		if (r.cnt == 0) { T.done = true; return; }
 		T.rid = (int32_t)(A.a[r.as].x << 1 >> 33), T.rev = (int32_t)(A.a[r.as].x >> 63);
@@ -646,7 +646,7 @@ struct Driver {
 	bool advance(QueryCtx &Q, RegTask &T, Reg &r2, int &r2_split_inv_ll)
 	{
 		r2_split_inv_ll = -1;
-		Reg &r = T.r; const Anchors A{Q.a.data(), Q.n_a}; const int32_t qlen = Q.qlen;
+		Reg &r = T.r; const Anchors A{Q.a, Q.n_a}; const int32_t qlen = Q.qlen;
 		r2.cnt = 0;
 		if (T.done) return true;
 		if (T.fin == 1) return false;
@@ -929,7 +929,7 @@ struct RoundRunner {
 			order_regions(regs);
 			assign_mapq(regs, opt.min_chain_score, opt.a, q.rep_len);
 			out[qi] = std::move(regs);
-			q.finished = true; q.pool.clear(); q.list.clear(); q.a.clear(); q.a.shrink_to_fit();
+			q.finished = true; q.pool.clear(); q.list.clear();
 		});
 		return unfinished.load();
 	}
@@ -1069,12 +1069,12 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 		const int n_u = C.n_u[qi];
 		if (q.qlen == 0 || n_u == 0) { q.finished = true; return; }
 		const uint64_t b = q_aoff[qi];
-		q.a.assign(C.a.begin() + b, C.a.begin() + b + C.n_v[qi]);
+		q.a = C.a.data() + b;
 		q.n_a = C.n_v[qi];                          // chains are contiguous and every chain becomes a region: nothing to squeeze (hit.c:311-329)
 		uint32_t salt = !(opt.flag & MM_F_NO_HASH_NAME) ? name_hash31(S.name[qi]) : 0;
 		salt = mix32(salt ^ (mix32((uint32_t)q.qlen) + mix32((uint32_t)opt.seed)));
 		std::vector<Reg> regs;
-		regions_from_chains(salt, q.qlen, n_u, C.u.data() + b, Anchors{q.a.data(), q.n_a}, regs);
+		regions_from_chains(salt, q.qlen, n_u, C.u.data() + b, Anchors{q.a, q.n_a}, regs);
 		for (auto &r : regs) { q.pool.emplace_back(new RegTask()); q.pool.back()->r = r; q.list.push_back(q.pool.back().get()); }
 		if (!(opt.flag & MM_F_CIGAR)) return;
 		for (RegTask *t : q.list) D.plan(q, *t);
