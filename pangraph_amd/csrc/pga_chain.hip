@@ -967,6 +967,14 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	}
 }
 
+__global__ void k_gather_chains(const uint64_t *__restrict__ u, const uint64_t *__restrict__ q_aoff, const uint64_t *__restrict__ coff, int n_seq, uint64_t *__restrict__ out)
+{
+	const int q = blockIdx.x;
+	if (q >= n_seq) return;
+	const uint64_t b = q_aoff[q], o = coff[q], n = coff[q + 1] - o;
+	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = u[b + i];
+}
+
 void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm)
 {
 	const int n_seq = S.n_seq;
@@ -1073,7 +1081,22 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	}
 	PGA_HIP(hipGetLastError());
 	O.n_u = n_u.download(st); O.n_v = n_v.download(st);
-	download_to(O.u, u.p, u.n, st);
+	// the chains of a query are the first n_u entries of its slice of u: only those travel (a leaf part holds ~5 k chains in an array of
+	// 57 M slots), and land at the same positions of the host array
+	{
+		std::vector<uint64_t> h_off = q_aoff.download(st);
+		std::vector<uint64_t> coff((size_t)n_seq + 1, 0);
+		for (int q = 0; q < n_seq; ++q) coff[(size_t)q + 1] = coff[(size_t)q] + (uint64_t)O.n_u[(size_t)q];
+		const uint64_t total = coff[(size_t)n_seq];
+		O.u.resize(u.n);
+		if (total) {
+			DBuf<uint64_t> d_coff; d_coff.upload(coff, st);
+			DBuf<uint64_t> uc((size_t)total);
+			hipLaunchKernelGGL(k_gather_chains, dim3((unsigned)n_seq), dim3(64), 0, st, u.p, q_aoff.p, d_coff.p, n_seq, uc.p);
+			PinVec<uint64_t> hc; download_to(hc, uc.p, (size_t)total, st);
+			for (int q = 0; q < n_seq; ++q) if (O.n_u[(size_t)q] > 0) memcpy(O.u.data() + h_off[(size_t)q], hc.data() + coff[(size_t)q], (size_t)O.n_u[(size_t)q] * sizeof(uint64_t));
+		}
+	}
 	download_to(O.a, out.p, out.n, st);
 }
 
