@@ -19,6 +19,7 @@
 // and w+k <= 64; any other (w,k) runs the serial kernel at the bottom (one lane per sequence), exact for
 // all inputs, slow, and never hit by pangraph's presets except through -K with an even k.
 #include "pga_common.h"
+#include "pga_wave.h"
 #include <sched.h>
 #include <unistd.h>
 #include <atomic>
@@ -212,7 +213,7 @@ void k_sketch_tiles(const uint32_t *__restrict__ pk2, const uint16_t *__restrict
 	__shared__ uint64_t s_hash[SK_TILE + W_MAX + 1];        // hash of the k-mer ENDING at a position, SK_NONE if none; index 0 <-> tile_start-w-... see HB
 	__shared__ uint8_t  s_strand[SK_TILE + W_MAX + 1];
 	__shared__ uint16_t s_cur[SK_TILE + 1];                 // rightmost window minimum after each position, index 0 <-> tile_start-1
-	__shared__ uint32_t s_wsum[SK_THREADS / 64];
+	__shared__ uint32_t s_wsum8[SK_PER][SK_THREADS / 64];
 	__shared__ uint32_t s_base;
 
 	const SkTile tl = tiles[blockIdx.x];
@@ -273,67 +274,70 @@ void k_sketch_tiles(const uint32_t *__restrict__ pk2, const uint16_t *__restrict
 	}
 	__syncthreads();
 
-	// ---- 4. emission rules (see oracle/pgo_sketch.c header: rules A-D), two passes: count, then write
+	// ---- 4. emission rules (see oracle/pgo_sketch.c header: rules A-D), evaluated ONCE per position: the eight positions of a thread (one per
+	//         256-position slab) keep their rule flags and counts in registers, the eight wave scans run back to back, one barrier publishes
+	//         the 8 x 4 wave totals, and every thread knows where its minimizers go (slab by slab, position order).
 	const int tile_n = (int)min((int64_t)SK_TILE, (int64_t)len - t0);
-	uint32_t running = 0;
-	for (int pass = 0; pass < 2; ++pass) {
-		running = 0;
-		for (int j = 0; j < SK_PER; ++j) {
-			const int c = j * SK_THREADS + tid;               // position t0+c
-			uint32_t cnt = 0;
-			int prev = 0, cur = 0, hi = 0, run = 0;
-			uint64_t xp = SK_NONE, xprev = SK_NONE;
-			bool ruleA = false, ruleB = false, ruleC1 = false, ruleC2 = false, ruleD = false;
-			if (c < tile_n) {
-				hi = c + w + 1;                               // hash index of this position
-				prev = s_cur[c], cur = s_cur[c + 1];
-				xp = s_hash[hi], xprev = s_hash[prev];
-				{   // run length again (cheap): needed for the l-thresholds
-					int lq = pad + SK_HALO + c;
-					uint64_t nwin = lds_bits(s_nmask, (uint32_t)(lq - nb + 1), (uint32_t)nb);
-					uint64_t top = nwin << (64 - nb);
-					run = top == 0 ? nb : __clzll((long long)top);
-				}
-				const bool prev_real = xprev != SK_NONE;
-				ruleA = run == w + k - 1 && prev_real;
-				if (xp <= xprev) ruleB = run >= w + k && prev_real;
-				else if (prev == hi - w) { ruleC1 = run >= w + k - 1 && prev_real; ruleC2 = run >= w + k - 1 && s_hash[cur] != SK_NONE; }
-				ruleD = (t0 + c == (int64_t)len - 1) && s_hash[cur] != SK_NONE;
-				if (ruleA) for (int t = hi - w + 1; t < hi; ++t) cnt += (s_hash[t] == xprev && t != prev);
-				cnt += ruleB + ruleC1;
-				if (ruleC2) { uint64_t xc = s_hash[cur]; for (int t = hi - w + 1; t <= hi; ++t) cnt += (s_hash[t] == xc && t != cur); }
-				cnt += ruleD;
-			}
-			// block-wide exclusive scan of cnt in position order (slab j holds positions j*256 .. j*256+255)
-			uint32_t incl = cnt;
+	uint32_t cnt[SK_PER], incl[SK_PER]; int prevv[SK_PER], curv[SK_PER]; uint32_t flg[SK_PER];
 #pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { uint32_t n = __shfl_up(incl, d); if ((tid & 63) >= d) incl += n; }
-			if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-			__syncthreads();
-			uint32_t wbase = 0, total = 0;
-#pragma unroll
-			for (int wv = 0; wv < SK_THREADS / 64; ++wv) { uint32_t s = s_wsum[wv]; if (wv < (tid >> 6)) wbase += s; total += s; }
-			__syncthreads();
-			uint32_t o = running + wbase + incl - cnt;
-			running += total;
-			if (pass == 1 && cnt) {
-				u128 *out = stage + (size_t)blockIdx.x * stage_cap;
-				const uint64_t ybase = (uint64_t)rid << 32;
-				const int64_t pos0 = t0 - w - 1;              // sequence position of hash index 0
-				auto emit = [&](int t) {
-					if (o < stage_cap) { u128 r; r.x = s_hash[t] << 8 | (uint64_t)k; r.y = ybase | (uint64_t)(uint32_t)(pos0 + t) << 1 | s_strand[t]; out[o] = r; }
-					++o;
-				};
-				if (ruleA) for (int t = hi - w + 1; t < hi; ++t) if (s_hash[t] == xprev && t != prev) emit(t);
-				if (ruleB || ruleC1) emit(prev);
-				if (ruleC2) { uint64_t xc = s_hash[cur]; for (int t = hi - w + 1; t <= hi; ++t) if (s_hash[t] == xc && t != cur) emit(t); }
-				if (ruleD) emit(cur);
+	for (int j = 0; j < SK_PER; ++j) {
+		const int c = j * SK_THREADS + tid;                   // position t0+c
+		uint32_t n = 0, f = 0; int prev = 0, cur = 0;
+		if (c < tile_n) {
+			const int hi = c + w + 1;                         // hash index of this position
+			prev = s_cur[c], cur = s_cur[c + 1];
+			const uint64_t xp = s_hash[hi], xprev = s_hash[prev];
+			int run;
+			{   // run length again (cheap): needed for the l-thresholds
+				const int lq = pad + SK_HALO + c;
+				const uint64_t nwin = lds_bits(s_nmask, (uint32_t)(lq - nb + 1), (uint32_t)nb);
+				const uint64_t top = nwin << (64 - nb);
+				run = top == 0 ? nb : __clzll((long long)top);
 			}
+			const bool prev_real = xprev != SK_NONE;
+			const bool ruleA = run == w + k - 1 && prev_real;
+			bool ruleB = false, ruleC1 = false, ruleC2 = false;
+			if (xp <= xprev) ruleB = run >= w + k && prev_real;
+			else if (prev == hi - w) { ruleC1 = run >= w + k - 1 && prev_real; ruleC2 = run >= w + k - 1 && s_hash[cur] != SK_NONE; }
+			const bool ruleD = (t0 + c == (int64_t)len - 1) && s_hash[cur] != SK_NONE;
+			if (ruleA) for (int t = hi - w + 1; t < hi; ++t) n += (s_hash[t] == xprev && t != prev);
+			n += ruleB + ruleC1;
+			if (ruleC2) { const uint64_t xc = s_hash[cur]; for (int t = hi - w + 1; t <= hi; ++t) n += (s_hash[t] == xc && t != cur); }
+			n += ruleD;
+			f = (ruleA ? 1u : 0u) | (ruleB || ruleC1 ? 2u : 0u) | (ruleC2 ? 4u : 0u) | (ruleD ? 8u : 0u);
 		}
-		if (pass == 0) {
-			if (tid == 0) { tile_cnt[blockIdx.x] = running; if (running > stage_cap) atomicExch(overflow, 1); }
-			if (running == 0) break;
-		}
+		cnt[j] = n; flg[j] = f; prevv[j] = prev; curv[j] = cur;
+		incl[j] = wave_prefix_sum_incl(n);
+		if ((tid & 63) == 63) s_wsum8[j][tid >> 6] = incl[j];
+	}
+	__syncthreads();
+	uint32_t running = 0, o[SK_PER];
+#pragma unroll
+	for (int j = 0; j < SK_PER; ++j) {
+		uint32_t wbase = 0, total = 0;
+#pragma unroll
+		for (int wv = 0; wv < SK_THREADS / 64; ++wv) { const uint32_t sv = s_wsum8[j][wv]; if (wv < (tid >> 6)) wbase += sv; total += sv; }
+		o[j] = running + wbase + incl[j] - cnt[j];
+		running += total;
+	}
+	if (tid == 0) { tile_cnt[blockIdx.x] = running; if (running > stage_cap) atomicExch(overflow, 1); }
+	if (running == 0) return;
+	u128 *out = stage + (size_t)blockIdx.x * stage_cap;
+	const uint64_t ybase = (uint64_t)rid << 32;
+	const int64_t pos0 = t0 - w - 1;                          // sequence position of hash index 0
+#pragma unroll
+	for (int j = 0; j < SK_PER; ++j) {
+		if (!cnt[j]) continue;
+		const int c = j * SK_THREADS + tid, hi = c + w + 1, prev = prevv[j], cur = curv[j];
+		uint32_t oo = o[j];
+		auto emit = [&](int t) {
+			if (oo < stage_cap) { u128 r; r.x = s_hash[t] << 8 | (uint64_t)k; r.y = ybase | (uint64_t)(uint32_t)(pos0 + t) << 1 | s_strand[t]; out[oo] = r; }
+			++oo;
+		};
+		if (flg[j] & 1u) { const uint64_t xprev = s_hash[prev]; for (int t = hi - w + 1; t < hi; ++t) if (s_hash[t] == xprev && t != prev) emit(t); }
+		if (flg[j] & 2u) emit(prev);
+		if (flg[j] & 4u) { const uint64_t xc = s_hash[cur]; for (int t = hi - w + 1; t <= hi; ++t) if (s_hash[t] == xc && t != cur) emit(t); }
+		if (flg[j] & 8u) emit(cur);
 	}
 }
 
