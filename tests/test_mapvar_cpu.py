@@ -1,0 +1,112 @@
+"""SURVEY 8(f)-1, map_variations / align_with_nextclade: the CPU restatement (oracle/pgo_mapvar.c) against the known-answer vectors of
+the reference's own unit tests (align_with_nextclade.rs:92-311, map_variations.rs:190-365, align.rs:191-250).  CPU only."""
+import json
+import os
+
+import numpy as np
+
+import mapvarbind as mb
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _strip(qry_aln, ref_aln):
+    return "".join(q for q, r in zip(qry_aln, ref_aln) if r != "-")
+
+
+def test_nuc_alphabet_and_match_matrix(oracle_lib):
+    # the 16 x 16 table of score_matrix_nuc.rs:6-26 and the letter order of nuc.rs:10-30 (fixture made by tests/golden/make_golden_mapvar.py)
+    g = json.load(open(os.path.join(GOLDEN, "nuc_matrix.json")))
+    d = oracle_lib.dll
+    for i, c in enumerate(g["letters"]):
+        assert d.pgo_to_nuc(ord(c)) == i
+    for c in "acgtnXZ*. ":
+        assert d.pgo_to_nuc(ord(c)) == -1
+    assert [[d.pgo_nuc_match(x, y) for y in range(16)] for x in range(16)] == g["matrix"]
+
+
+def test_align_with_nextclade_known_answers(oracle_lib):
+    d = oracle_lib.dll
+    p = mb.params(min_length=3, max_alignment_attempts=3)
+    # align_with_nextclade.rs:92-152 (general case; BandParameters::new(0, 4 + EXTRA_BANDWIDTH))
+    ref = "CTTGGAGGTTCCGTGGCTAGATAACAGAACATTCTTGGAATGCTGATCTTTATAAGCTCATGCGACACTTCGCATGGTGAGCCTTTGT"
+    qry = "CTTGGAGGTTCCGTGGCTATAAAGATAACAGAACATTCTTGGAATGCTGATCAAGCTCATGGGACANNTCGCATGGTGGACAGCCTTTGT"
+    r = mb.oracle_map_variations(d, ref, qry, 0, 4, p, want_aln=True)
+    assert r["status"] == 0 and r["hit_boundary"] == 0
+    assert r["ref_aln"] == "CTTGGAGGTTCCGTGGCTA----GATAACAGAACATTCTTGGAATGCTGATCTTTATAAGCTCATGCGACACTTCGCATGGTG---AGCCTTTGT"
+    assert _strip(r["qry_aln"], r["ref_aln"]) == "CTTGGAGGTTCCGTGGCTAGATAACAGAACATTCTTGGAATGCTGATC-----AAGCTCATGGGACANNTCGCATGGTGAGCCTTTGT"
+    assert r["subs"] == [(62, "G"), (67, "N"), (68, "N")]
+    assert r["dels"] == [(48, 5)]
+    assert r["inss"] == [(18 + 1, "TAAA"), (78 + 1, "GAC")]
+    # :154-206 (N in the reference: substitutions, never matches)
+    ref = "TGGTGCTGCAGCTTATTATGTGGNNNNNTTTTCTATTAAAATATAATGAAA"
+    qry = "TGGTGCTGCAGCTTATTATGTGGAGGACTTTTCTATTAAAATATAATGAAA"
+    r = mb.oracle_map_variations(d, ref, qry, 0, 0, p, want_aln=True)
+    assert (r["qry_aln"], r["ref_aln"]) == (qry, ref) and r["hit_boundary"] == 0
+    assert r["subs"] == [(23, "A"), (24, "G"), (25, "G"), (26, "A"), (27, "C")] and r["dels"] == [] and r["inss"] == []
+    # :208-272 (edge case)
+    ref = "TGGTGCTGCNNNNNATTATGTGGGTTATCTTCAACCTTTTTTTAAAATATAATGAAAATGGAACCATTACAGATGCTNNNNNNNNTGCACTTGACCCTCTC"
+    qry = "TGGTGCTGCAGCTTATTATGTGGGTTATCTTCAACCTTTTTTTAAAATATAATGAAAATGGAACCATTACAGATGCTGTAGACTGTGCACTTGACCCTCTC"
+    r = mb.oracle_map_variations(d, ref, qry, 0, 0, p, want_aln=True)
+    assert (r["qry_aln"], r["ref_aln"]) == (qry, ref) and r["hit_boundary"] == 0
+    assert r["subs"] == [(9, "A"), (10, "G"), (11, "C"), (12, "T"), (13, "T"), (77, "G"), (78, "T"), (79, "A"), (80, "G"), (81, "A"), (82, "C"), (83, "T"), (84, "G")]
+    assert r["dels"] == [] and r["inss"] == []
+    # :274-311 (nothing alignable inside the band: the whole reference deleted, the whole query inserted behind it)
+    r = mb.oracle_map_variations(d, "A" * 37, "G" * 18, 70, 0, p, want_aln=True)
+    assert r["ref_aln"] == "A" * 37 + "-" * 18 and _strip(r["qry_aln"], r["ref_aln"]) == "-" * 37
+    assert r["subs"] == [] and r["dels"] == [(0, 37)] and r["inss"] == [(36 + 1, "G" * 18)] and r["hit_boundary"] == 0
+
+
+MAPVAR_KATS = [
+    # map_variations.rs:190-231
+    ("ACTTTGCGTCTGATAGCTTAGCGGATATTTACTGTA", "ACTAGATTGAGTCTGATAGCTTAGCGGATATTGTA", -2, 3, [(6, "A")], [(29, 4)], [(3, "AGA")]),
+    # :233-275 (leading and trailing deletions come behind the internal ones: align_with_nextclade.rs:46-64)
+    ("ACACTGATTTCGTCCCTTAGGTACTCTACACTGTAGCCTA", "CTGATTTAGTCCCTTAGGGGTTACTCTACACTGTAG", 2, 2, [(10, "A")], [(0, 3), (36, 4)], [(21, "GGT")]),
+    # :277-319
+    ("ACACTGATTTCGTCCCTTAGGTACTCTACACTGTAGCCTA", "CCTGACACTGATTTAGTCCTAGGGGTTACTCTACACCGTAGCCTAGCCGCCG", -4, 2, [(10, "A"), (31, "C")], [(15, 2)],
+     [(0, "CCTG"), (21, "GGT"), (40, "GCCGCCG")]),
+    # :321-365
+    ("CGCCCTACTACAAGAGGGAACTTTTTTTTTAAGTATAGCCACAATAGCTGG", "CGCCCTACTACAAGAGGGAACGGGGGGGGGGGGGAAGTATAGCCACAATAGCTGG", -2, 11, [], [(21, 9)], [(21, "G" * 13)]),
+]
+
+
+def test_map_variations_known_answers(oracle_lib):
+    for ref, qry, ms, bw, subs, dels, inss in MAPVAR_KATS:
+        r = mb.oracle_map_variations(oracle_lib.dll, ref, qry, ms, bw)
+        assert r["status"] == 0
+        assert (r["subs"], r["dels"], r["inss"]) == (subs, dels, inss)
+        assert mb.apply_edit(ref, r) == qry
+
+
+def test_simplestripe_band_hit_known_answers(oracle_lib):
+    d = oracle_lib.dll
+    # align.rs:191-222: NextalignParams::default() with one attempt, the band handed over as it is (no extra width)
+    core = "TTGGCCCCGGTGCTGTCCGTCAACACGTCGTCGTCCGGCGACCTACCTGGTCTCAAAGGAGGTTTTGTTAAATGAATTAGATGGGTAAGGTTACCACGTCA"
+    ref, qry = core + "A" * 30, "G" * 30 + core
+    p = mb.params(min_length=100, max_alignment_attempts=1, extra_band_width=0)
+    assert mb.oracle_map_variations(d, ref, qry, -30, 1, p)["hit_boundary"] == 0
+    assert mb.oracle_map_variations(d, ref, qry, 0, 31, p)["hit_boundary"] == 0
+    assert mb.oracle_map_variations(d, ref, qry, 0, 30, p)["hit_boundary"] == 1
+    # :224-250
+    p = mb.params(min_length=3, max_alignment_attempts=1, extra_band_width=0)
+    r = mb.oracle_map_variations(d, "A" * 37, "G" * 18, 70, 0, p, want_aln=True)
+    assert (r["ref_aln"], r["qry_aln"], r["score"], r["hit_boundary"]) == ("A" * 37 + "-" * 18, "-" * 37 + "G" * 18, 0, 0)
+    # align.rs:42-46: a query shorter than min_length is an error; nuc.rs:99-121: so is a letter outside the alphabet
+    assert mb.oracle_map_variations(d, "ACGT", "AC", 0, 0, p)["status"] == 1
+    assert mb.oracle_map_variations(d, "ACGT", "ACgT", 0, 0, p)["status"] == 2
+
+
+def test_random_members_round_trip(oracle_lib):
+    # size-independent property: the edits map the consensus back onto the member sequence, whatever the band did
+    rng = np.random.default_rng(7)
+    n_retry = 0
+    for it in range(60):
+        L = int(rng.integers(1, 900))
+        ref = mb.random_seq(rng, L)
+        qry = mb.mutate(rng, ref, snp=0.03, indel=0.01, max_indel=int(rng.integers(1, 40)), n_frac=0.01 if it % 3 == 0 else 0.0) or "A"
+        ms = int(rng.integers(-3, 4)); bw = int(rng.integers(0, 12))
+        p = mb.params(gap_align_left=it % 2, penalty_gap_extend=it % 4 == 3, left_terminal_gaps_free=it % 5 != 4, right_terminal_gaps_free=it % 7 != 6)
+        r = mb.oracle_map_variations(oracle_lib.dll, ref, qry, ms, bw, p)
+        assert r["status"] == 0 and mb.apply_edit(ref, r) == qry
+        n_retry += r["attempts"] > 1
+    assert n_retry > 0
