@@ -117,6 +117,35 @@ int pga_guide_tree(int32_t n, const char *const *seqs, const uint32_t *lens, int
 /* stage tap: the minimizers of every sequence in the reference's order (value = Minimizer.value, position = Minimizer.position with
  * the sequence's index as id); seq_off has n + 1 entries */
 int pga_stage_mash_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, uint64_t **value, uint64_t **position, uint64_t *seq_off);
+/* ---- the re-alignment of a merged block's member sequences onto the anchor consensus ----
+ * pga_map_variations replaces the loop of MergePromise::solve_promise (packages/pangraph/src/pangraph/reweave.rs:40-94) over
+ * map_variations (packages/pangraph/src/align/map_variations.rs:39-77): align_with_nextclade (align/nextclade/align_with_nextclade.rs:
+ * 24-75) = banded global alignment with free terminal gaps over simple_stripes(mean_shift, band_width + extra_band_width)
+ * (align/nextclade/align/{band_2d.rs:36-57, score_matrix.rs:23-199, backtrace.rs:17-85}), the band doubled while the path touches
+ * its boundary (align/nextclade/align/align.rs:55-62), then insertions_strip / find_nuc_changes and the terminal deletions.
+ * One job per member sequence; ref and qry are upper-case IUPAC letters (not NUL-terminated); jobs that share a consensus should
+ * pass the same pointer (it is uploaded once).  The caller keeps Edit::apply, reverse_complement and BandParameters::from_edits
+ * (reweave.rs:53-75).  Per job: status 0, or the reference's error -- 1 the query is shorter than min_length (align.rs:42-46),
+ * 2 a letter to_nuc rejects (alphabet/nuc.rs:99-121), 3 the traceback left the band (the reference panics).  Substitutions in
+ * reference order, deletions as the reference pushes them (internal ones ascending, then the leading, then the trailing one),
+ * insertions ascending with pangraph's position convention (map_variations.rs:71-74).  The four arrays are freed with pga_free().
+ * Returns 0, or -1 with the message in pga_last_error(). */
+typedef struct {
+	int32_t score_match, penalty_mismatch, penalty_gap_open, penalty_gap_extend;   /* NextalignParams::default(): 3, 1, 6, 0 (params.rs:142-170) */
+	int32_t left_terminal_gaps_free, right_terminal_gaps_free, gap_align_left;     /* 1, 1, 1 */
+	int32_t min_length, max_alignment_attempts, extra_band_width;                  /* map_variations.rs:45-52: 1, args (4), args (5) (build_args.rs:76-85) */
+} pga_mapvar_params_t;
+typedef struct { const char *ref, *qry; uint32_t ref_len, qry_len; int32_t mean_shift; uint32_t band_width; } pga_mapvar_job_t;
+typedef struct { uint32_t pos, alt; } pga_sub_t;                    /* Sub { pos, alt }: alt is the query's letter */
+typedef struct { uint32_t pos, len; } pga_del_t;                    /* Del { pos, len } */
+typedef struct { uint32_t pos, len; uint64_t seq_off; } pga_ins_t;  /* Ins { pos, seq = ins_seq[seq_off .. seq_off + len) } */
+typedef struct {
+	int32_t status, score, attempts, hit_boundary;
+	uint32_t n_subs, n_dels, n_inss, n_ins_bases;
+	uint64_t sub_off, del_off, ins_off;                             /* first entry of the job in subs / dels / inss */
+} pga_mapvar_res_t;
+int pga_map_variations(int64_t n_jobs, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t *params, pga_mapvar_res_t *res,
+                       pga_sub_t **subs, pga_del_t **dels, pga_ins_t **inss, char **ins_seq);
 void pga_free(void *p);
 #ifdef __cplusplus
 }

@@ -681,6 +681,25 @@ extern "C" int pga_guide_tree(int32_t n, const char *const *seqs, const uint32_t
 	catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 
+// ---------------------------------------------------------------- map_variations over all member sequences (pga_mapvar.hip)
+namespace pga {
+void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t &prm, pga_mapvar_res_t *res,
+                         std::vector<pga_sub_t> &subs, std::vector<pga_del_t> &dels, std::vector<pga_ins_t> &inss, std::vector<char> &seq);
+}
+
+extern "C" int pga_map_variations(int64_t n_jobs, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t *params, pga_mapvar_res_t *res,
+                                  pga_sub_t **subs, pga_del_t **dels, pga_ins_t **inss, char **ins_seq)
+{
+	try {
+		require_device();
+		if (n_jobs < 0 || (n_jobs && (!jobs || !res)) || !params || !subs || !dels || !inss || !ins_seq) throw std::runtime_error("pga_map_variations: null argument");
+		std::vector<pga_sub_t> s; std::vector<pga_del_t> d; std::vector<pga_ins_t> i; std::vector<char> q;
+		if (n_jobs) { memset(res, 0, sizeof(*res) * (size_t)n_jobs); map_variations_host(n_jobs, jobs, *params, res, s, d, i, q); }
+		*subs = dup_out(s); *dels = dup_out(d); *inss = dup_out(i); *ins_seq = dup_out(q);
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
+
 extern "C" int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy)
 {
 	try {
