@@ -29,6 +29,7 @@
 #include "../../include/pga_align.h"
 #include <unordered_map>
 #include <cstdio>
+#include <chrono>
 
 namespace pga {
 
@@ -42,6 +43,7 @@ struct MvParams { int32_t match, mismatch, gap_open, ext, left_free, right_free,
 struct MvJob { uint64_t ref_off, qry_off; uint32_t ref_len, qry_len; int32_t ms; uint32_t bw, attempt, orig; };
 struct MvOut { int32_t status, score, attempts, hit; uint32_t n_subs, n_dels, n_inss, n_ib; uint64_t sub_off, del_off, ins_off, ib_off; };
 struct MvCursors { unsigned long long subs, dels, inss, ib; };
+struct MvCaps { unsigned long long subs, dels, inss, ib; };
 
 // nuc.rs:10-30 / :99-121: the sixteen letters in enum order; anything else is an error of the job
 __global__ void k_mv_encode(const char *__restrict__ ascii, uint64_t n, uint8_t *__restrict__ codes)
@@ -71,7 +73,7 @@ template <int RING> __device__ __forceinline__ void mv_row_fence() { if (RING > 
 template <int RING>
 __global__ __launch_bounds__(64)
 void k_mapvar(const MvJob *__restrict__ jobs, int n_jobs, MvParams P, const uint8_t *__restrict__ codes, uint32_t *job_counter,
-              uint8_t *slabs, uint64_t slab_bytes, int32_t *gring, int ring_n, MvOut *__restrict__ out, MvCursors *cur,
+              uint8_t *slabs, uint64_t slab_bytes, int32_t *gring, int ring_n, MvOut *__restrict__ out, MvCursors *cur, MvCaps cap,
               pga_sub_t *subs, pga_del_t *dels, pga_ins_t *inss, char *ins_seq)
 {
 	__shared__ int32_t s_ring[RING > 0 ? 3 * RING : 1];
@@ -122,73 +124,69 @@ void k_mapvar(const MvJob *__restrict__ jobs, int n_jobs, MvParams P, const uint
 		int32_t final_score = (P.left_free || qlen == 0) ? 0 : -(P.gap_open + (qlen - 1) * P.ext);   // ref_len == 0: the corner lies in row 0
 		int refreg = 0;
 		int qc_pref = 0;
-		{ const int q1 = sbeg(1) + lane; if (ref_len >= 1 && q1 >= 1 && q1 < send(1)) qc_pref = qry[q1 - 1]; }
+		// the stripes of the rows ri - 2 (end), ri - 1, ri, ri + 1 roll along; the cell arithmetic is branch-free (a branch costs more than the cell)
+		int pb = 0, pe = send(0), ppe = 0, b = ref_len >= 1 ? sbeg(1) : 0, e = ref_len >= 1 ? send(1) : 0;
+		{ const int q1 = b + lane; if (ref_len >= 1 && q1 >= 1 && q1 < e) qc_pref = qry[q1 - 1]; }
 		for (int ri = 1; ri <= ref_len; ++ri) {
 			if (((ri - 1) & 63) == 0) refreg = ri - 1 + lane < ref_len ? ref[ri - 1 + lane] : 0;
 			const int r = rl(refreg, (ri - 1) & 63);
-			const int b = sbeg(ri), e = send(ri), pb = sbeg(ri - 1), pe = send(ri - 1), ppe = ri >= 2 ? send(ri - 2) : 0;
+			const bool rN = r == MV_N;
+			const int mr = rN ? 31 : r + 1;                                                            // letters as sets: mv_match(x, y) = sets intersect
 			const bool last = ri == ref_len;
+			const int nb = last ? 0 : sbeg(ri + 1), ne = last ? 0 : send(ri + 1);
 			const int o_r = (last && P.right_free) ? 0 : P.gap_open, x_r = (last && P.right_free) ? 0 : P.ext;    // :136-143
 			const int ep = x_r < o_r ? x_r : o_r;
+			const int32_t s0 = P.left_free ? 0 : -(P.gap_open + (ri - 1) * P.ext);                     // column 0 (:96-107)
 			const int32_t *prevS = bufS + (size_t)((ri - 1) & 1) * RN;
 			int32_t *curS = bufS + (size_t)(ri & 1) * RN;
 			int32_t carryA = INT32_MIN, carryS = 0, carryG = 0;
 			const size_t rowbase = (size_t)(ri - 1) * pitch;
 			const int qc_first = qc_pref;
-			if (ri < ref_len) { const int qn = sbeg(ri + 1) + lane; qc_pref = (qn >= 1 && qn < send(ri + 1)) ? qry[qn - 1] : 0; }   // the next row's letters, in flight during this row
+			{ const int qn = nb + lane; qc_pref = (qn >= 1 && qn < ne) ? qry[qn - 1] : 0; }             // the next row's letters, in flight during this row
 			for (int c0 = b; c0 < e; c0 += 64) {
 				const int q = c0 + lane;
 				const bool on = q < e;
 				const int qc = c0 == b ? qc_first : ((on && q >= 1) ? (int)qry[q - 1] : 0);
 				const int32_t Sd = prevS[(q - 1) & M], Su = prevS[q & M], QG = qg[q & M];
-				int tmp_path = 0, origin = 0;
-				int32_t score = MV_NO_ALIGN, Ht, tq = 0, qg_new = MV_NO_ALIGN;
-				bool up_ok = false, extq = false;
-				if (q == 0) {                                                                          // :96-107
-					tmp_path = MV_QRY_GAP_EXTEND; origin = MV_QRY_GAP_MATRIX;
-					score = P.left_free ? 0 : -(P.gap_open + (ri - 1) * P.ext);
-					Ht = score;
-				} else {
-					if (q > pb && q - 1 < pe) {                                                         // :115-124
-						const int sc = (qc == MV_N || r == MV_N) ? P.match - 1 : (mv_match(qc, r) ? P.match : -P.mismatch);
-						score = Sd + sc; origin = MV_MATCH;
-					} else if (ri < ref_len && q < qlen) tmp_path |= MV_BOUNDARY;
-					up_ok = q < pe;
-					if (up_ok) {                                                                        // :165-183
-						const bool fr = q == qlen && P.right_free;
-						const int32_t qe = QG - (fr ? 0 : P.ext), qo = Su - (fr ? 0 : P.gap_open);
-						extq = qe >= qo && ri >= 2 && q < ppe;
-						tq = extq ? qe : qo;
-					}
-					Ht = (up_ok && tq > score) ? tq : score;
-				}
+				const bool q0 = q == 0;
+				const bool inner = !last && q < qlen;
+				const bool diag_ok = q > pb && q - 1 < pe;                                              // :115-124
+				const bool up_ok = !q0 && q < pe;                                                       // :165
+				const int mq = qc == MV_N ? 31 : qc + 1;
+				const int sc = (qc == MV_N || rN) ? P.match - 1 : ((mq & mr) ? P.match : -P.mismatch);
+				int32_t score = diag_ok ? Sd + sc : MV_NO_ALIGN;
+				int origin = diag_ok ? MV_MATCH : 0;
+				const bool fr = q == qlen && P.right_free;
+				const int32_t qe = QG - (fr ? 0 : P.ext), qo = Su - (fr ? 0 : P.gap_open);
+				const bool extq = up_ok && qe >= qo && q < ppe;                                         // :175 (ppe = 0 in row 1)
+				const int32_t tq = extq ? qe : qo;
+				int32_t Ht = (up_ok && tq > score) ? tq : score;
+				Ht = q0 ? s0 : Ht;
 				// ref_gaps of every column of the chunk: exclusive prefix maximum of Ht[j] + ep * (j - b)
 				const int32_t A = on ? Ht + ep * (q - b) : INT32_MIN;
 				const int32_t Pin = wave_prefix_max_incl(A);
 				int32_t excl = wave_shr1(Pin, INT32_MIN);
-				if (carryA > excl) excl = carryA;
-				{ const int32_t top = rl(Pin, 63); if (top > carryA) carryA = top; }
+				excl = carryA > excl ? carryA : excl;
+				{ const int32_t top = rl(Pin, 63); carryA = top > carryA ? top : carryA; }
 				const int32_t G = q > b ? excl - o_r - ep * (q - 1 - b) : 0;
-				if (on && q > 0) {
-					if (q > b) { if (score - la < G) { score = G; origin = MV_REF_GAP_MATRIX; } }      // :135-160
-					else if (ri < ref_len && q < qlen) tmp_path |= MV_BOUNDARY;
-					if (up_ok) {
-						qg_new = tq;
-						if (extq) tmp_path += MV_QRY_GAP_EXTEND;
-						if (score - la < tq) { score = tq; origin = MV_QRY_GAP_MATRIX; }
-					} else if (q < qlen && ri < ref_len) tmp_path |= MV_BOUNDARY;                      // :184-187 (qry_gaps of a column entering the band is NO_ALIGN)
-				}
+				const bool refg = q > b && score - la < G;                                              // :147-150
+				score = refg ? G : score; origin = refg ? MV_REF_GAP_MATRIX : origin;
+				const bool qryg = up_ok && score - la < tq;                                             // :180-183
+				score = qryg ? tq : score; origin = qryg ? MV_QRY_GAP_MATRIX : origin;
+				score = q0 ? s0 : score; origin = q0 ? MV_QRY_GAP_MATRIX : origin;
 				const int32_t Sl = wave_shr1(score, carryS), Gl = wave_shr1(G, carryG);
-				if (on && q > b + 1 && Gl - x_r >= Sl - o_r) tmp_path += MV_REF_GAP_EXTEND;           // :144-146
+				int tmp_path = q0 ? MV_QRY_GAP_EXTEND : ((inner && (!diag_ok || q <= b || !up_ok)) ? MV_BOUNDARY : 0) + (extq ? MV_QRY_GAP_EXTEND : 0);
+				tmp_path += (q > b + 1 && Gl - x_r >= Sl - o_r) ? MV_REF_GAP_EXTEND : 0;                // :144-146
 				carryS = rl(score, 63); carryG = rl(G, 63);
 				if (on) {
 					slab[rowbase + (size_t)(q - b)] = (uint8_t)(tmp_path + origin);
 					curS[q & M] = score;
-					qg[q & M] = qg_new;
+					qg[q & M] = up_ok ? tq : MV_NO_ALIGN;                                               // :184-187 (qry_gaps of a column entering the band is NO_ALIGN)
 				}
 				if (last && qlen >= c0 && qlen < c0 + 64) final_score = rl(score, qlen - c0);
 			}
 			mv_row_fence<RING>();
+			ppe = pe; pb = b; pe = e; b = nb; e = ne;
 		}
 		mv_fence();                                                         // the path bytes, for the lanes that read them below
 		O.score = final_score;
@@ -291,6 +289,8 @@ void k_mapvar(const MvJob *__restrict__ jobs, int n_jobs, MvParams P, const uint
 				unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 				if (lane == 0) { a0 = atomicAdd(&cur->subs, (unsigned long long)n_subs); a1 = atomicAdd(&cur->dels, (unsigned long long)n_dels); a2 = atomicAdd(&cur->inss, (unsigned long long)n_inss); a3 = atomicAdd(&cur->ib, (unsigned long long)n_ib); }
 				O.sub_off = (uint64_t)__shfl((long long)a0, 0); O.del_off = (uint64_t)__shfl((long long)a1, 0); O.ins_off = (uint64_t)__shfl((long long)a2, 0); O.ib_off = (uint64_t)__shfl((long long)a3, 0);
+				// the pools are sized for typical divergence, not for the worst case: a job that does not fit comes back (status 4) and runs again
+				if (O.sub_off + n_subs > cap.subs || O.del_off + n_dels > cap.dels || O.ins_off + n_inss > cap.inss || O.ib_off + n_ib > cap.ib) { O.status = 4; go = false; }
 			}
 		}
 		if (lane == 0) out[j] = O;
@@ -348,16 +348,25 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 	const size_t budget = (size_t)((eb ? atof(eb) : 16.0) * (double)(1ULL << 30));
 	h_subs.clear(); h_dels.clear(); h_inss.clear(); h_seq.clear();
 	int round = 0;
+	bool overflowed = false;
 	while (!pending.empty()) {
 		++round;
 		// big slabs first; one launch per (ring class, need within a factor of four)
 		std::stable_sort(pending.begin(), pending.end(), [](const MvJob &a, const MvJob &b) { const int ca = mv_ring_class(a), cb = mv_ring_class(b); if (ca != cb) return (ca == 0 ? 1 << 30 : ca) > (cb == 0 ? 1 << 30 : cb); return mv_slab_need(a) > mv_slab_need(b); });
+		const auto t_round = std::chrono::steady_clock::now();
 		DBuf<MvJob> d_jobs; d_jobs.upload(pending, st);
 		DBuf<MvOut> d_out(pending.size());
+		// output pools: the worst case (every base a substitution, every other base an insertion) would be 40 bytes per base; the first
+		// round reserves an eighth of it, jobs that overflow run again in a round whose pools hold their worst case
 		uint64_t cap_subs = 0, cap_dels = 0, cap_inss = 0, cap_ib = 0;
 		for (const MvJob &J : pending) { const uint64_t m = std::min(J.ref_len, J.qry_len); cap_subs += m; cap_dels += (uint64_t)J.ref_len / 2 + 3; cap_inss += std::min<uint64_t>(J.qry_len, (uint64_t)J.ref_len + 1) + 1; cap_ib += J.qry_len; }
-		if ((cap_subs + cap_dels) * 8 + cap_inss * 16 + cap_ib > (64ULL << 30)) throw std::runtime_error("pga_map_variations: more than 64 GB of worst-case output in one call; split the batch");
+		if (!overflowed) {
+			if (getenv("PGA_MAPVAR_TIGHT_POOLS")) { cap_subs = cap_subs / 64 + 8; cap_dels = cap_dels / 64 + 8; cap_inss = cap_inss / 64 + 8; cap_ib = cap_ib / 64 + 8; }   // tests: force the overflow round
+			else { cap_subs = cap_subs / 8 + 4096 + 4 * pending.size(); cap_dels = cap_dels / 16 + 4096 + 4 * pending.size(); cap_inss = cap_inss / 16 + 4096 + 4 * pending.size(); cap_ib = cap_ib / 8 + 65536; }
+		}
+		if ((cap_subs + cap_dels) * 8 + cap_inss * 16 + cap_ib > (64ULL << 30)) throw std::runtime_error("pga_map_variations: more than 64 GB of output pools in one call; split the batch");
 		DBuf<pga_sub_t> d_subs(cap_subs + 1); DBuf<pga_del_t> d_dels(cap_dels + 1); DBuf<pga_ins_t> d_inss(cap_inss + 1); DBuf<char> d_seq(cap_ib + 1);
+		const MvCaps caps{cap_subs, cap_dels, cap_inss, cap_ib};
 		DBuf<MvCursors> d_cur(1); d_cur.zero(st);
 		std::vector<DBuf<uint8_t>> keep_slabs; std::vector<DBuf<int32_t>> keep_rings; std::vector<DBuf<uint32_t>> keep_ctr;
 		size_t s0 = 0;
@@ -379,7 +388,7 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 			int32_t *gr = nullptr;
 			if (cls == 0) { keep_rings.emplace_back(n_slots * (size_t)ring_n * 3); gr = keep_rings.back().p; }
 			if (verbose) fprintf(stderr, "[pga]   map_variations round %d: %zu jobs, ring %d, slab %.1f KB x %zu waves\n", round, nj, cls ? cls : ring_n, slab_bytes / 1024.0, n_slots);
-#define MV_LAUNCH(R) k_mapvar<R><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes.p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, gr, ring_n, d_out.p + s0, d_cur.p, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
+#define MV_LAUNCH(R) k_mapvar<R><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes.p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, gr, ring_n, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
 			if (cls == 128) MV_LAUNCH(128); else if (cls == 512) MV_LAUNCH(512); else if (cls == 2048) MV_LAUNCH(2048); else MV_LAUNCH(0);
 #undef MV_LAUNCH
 			PGA_HIP(hipGetLastError());
@@ -388,16 +397,21 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 		std::vector<MvOut> ho = d_out.download(st);
 		const std::vector<MvCursors> hc = d_cur.download(st);
 		const size_t b_subs = h_subs.size(), b_dels = h_dels.size(), b_inss = h_inss.size(), b_seq = h_seq.size();
-		h_subs.resize(b_subs + hc[0].subs); h_dels.resize(b_dels + hc[0].dels); h_inss.resize(b_inss + hc[0].inss); h_seq.resize(b_seq + hc[0].ib);
-		if (hc[0].subs) PGA_HIP(hipMemcpyAsync(h_subs.data() + b_subs, d_subs.p, hc[0].subs * sizeof(pga_sub_t), hipMemcpyDeviceToHost, st));
-		if (hc[0].dels) PGA_HIP(hipMemcpyAsync(h_dels.data() + b_dels, d_dels.p, hc[0].dels * sizeof(pga_del_t), hipMemcpyDeviceToHost, st));
-		if (hc[0].inss) PGA_HIP(hipMemcpyAsync(h_inss.data() + b_inss, d_inss.p, hc[0].inss * sizeof(pga_ins_t), hipMemcpyDeviceToHost, st));
-		if (hc[0].ib) PGA_HIP(hipMemcpyAsync(h_seq.data() + b_seq, d_seq.p, hc[0].ib, hipMemcpyDeviceToHost, st));
+		std::vector<MvCursors> hcm = hc;                                    // the cursors run past the pools when a job overflowed
+		hcm[0].subs = std::min<unsigned long long>(hcm[0].subs, cap_subs); hcm[0].dels = std::min<unsigned long long>(hcm[0].dels, cap_dels);
+		hcm[0].inss = std::min<unsigned long long>(hcm[0].inss, cap_inss); hcm[0].ib = std::min<unsigned long long>(hcm[0].ib, cap_ib);
+		h_subs.resize(b_subs + hcm[0].subs); h_dels.resize(b_dels + hcm[0].dels); h_inss.resize(b_inss + hcm[0].inss); h_seq.resize(b_seq + hcm[0].ib);
+		if (hcm[0].subs) PGA_HIP(hipMemcpyAsync(h_subs.data() + b_subs, d_subs.p, hcm[0].subs * sizeof(pga_sub_t), hipMemcpyDeviceToHost, st));
+		if (hcm[0].dels) PGA_HIP(hipMemcpyAsync(h_dels.data() + b_dels, d_dels.p, hcm[0].dels * sizeof(pga_del_t), hipMemcpyDeviceToHost, st));
+		if (hcm[0].inss) PGA_HIP(hipMemcpyAsync(h_inss.data() + b_inss, d_inss.p, hcm[0].inss * sizeof(pga_ins_t), hipMemcpyDeviceToHost, st));
+		if (hcm[0].ib) PGA_HIP(hipMemcpyAsync(h_seq.data() + b_seq, d_seq.p, hcm[0].ib, hipMemcpyDeviceToHost, st));
 		PGA_HIP(hipStreamSynchronize(st));
 		for (size_t k = b_inss; k < h_inss.size(); ++k) h_inss[k].seq_off += b_seq;
 		std::vector<MvJob> next;
+		size_t n_over = 0;
 		for (size_t k = 0; k < pending.size(); ++k) {
 			const MvOut &o = ho[k]; const MvJob &J = pending[k];
+			if (o.status == 4) { next.push_back(J); n_over++; continue; }                                 // the output pools were full
 			if (o.status == 0 && o.hit && (int)J.attempt < P.max_attempts) {                          // align.rs:55-62
 				MvJob N = J;
 				const uint64_t a = (uint64_t)std::llabs((long long)J.ms);
@@ -412,7 +426,10 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 			R.n_subs = o.n_subs; R.n_dels = o.n_dels; R.n_inss = o.n_inss; R.n_ins_bases = o.n_ib;
 			R.sub_off = b_subs + o.sub_off; R.del_off = b_dels + o.del_off; R.ins_off = b_inss + o.ins_off;
 		}
-		if (verbose) fprintf(stderr, "[pga]   map_variations round %d: %zu of %zu jobs hit the band boundary and go again\n", round, next.size(), pending.size());
+		if (verbose) fprintf(stderr, "[pga]   map_variations round %d: %zu of %zu jobs hit the band boundary and go again; %.1f ms (kernels + download of %.1f MB of edits)\n", round, next.size(), pending.size(),
+		                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count(), (hcm[0].subs * 8 + hcm[0].dels * 8 + hcm[0].inss * 16 + hcm[0].ib) / 1e6);
+		overflowed = n_over > 0;
+		if (verbose && n_over) fprintf(stderr, "[pga]   map_variations round %d: %zu jobs did not fit the output pools and run again\n", round, n_over);
 		pending.swap(next);
 	}
 }

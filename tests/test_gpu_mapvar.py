@@ -97,6 +97,21 @@ def test_wide_bands_and_ambiguity_letters_vs_oracle(gpu_lib, oracle_lib):
         assert mb.apply_edit(ref, g) == qry
 
 
+def test_output_pools_overflow_round(gpu_lib, oracle_lib, monkeypatch):
+    # the edit pools are sized for typical divergence; jobs that do not fit run again in a round with worst-case pools
+    monkeypatch.setenv("PGA_MAPVAR_TIGHT_POOLS", "1")
+    rng = np.random.default_rng(19)
+    jobs = []
+    for it in range(150):
+        ref = mb.random_seq(rng, int(rng.integers(20, 500)))
+        qry = mb.random_seq(rng, int(rng.integers(20, 500))) if it % 3 == 0 else mb.mutate(rng, ref, snp=0.2, indel=0.05, max_indel=6)
+        jobs.append((ref, qry or "A", int(rng.integers(-3, 4)), int(rng.integers(0, 30))))
+    got = mb.product_map_variations(gpu_lib.dll, jobs)
+    _same(got, _oracle(oracle_lib.dll, jobs, mb.params()))
+    for (ref, qry, _, _), g in zip(jobs, got):
+        assert mb.apply_edit(ref, g) == qry
+
+
 def test_block_of_many_members_round_trip(gpu_lib, oracle_lib):
     # a merge at bench scale: 600 members of a 12 kb block (sampled against the oracle, all through the round trip)
     rng = np.random.default_rng(17)
