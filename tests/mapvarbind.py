@@ -135,3 +135,48 @@ def mutate(rng, ref, snp=0.02, indel=0.004, max_indel=30, n_frac=0.0):
 
 def random_seq(rng, n):
     return "".join(np.array(list("ACGT"))[rng.integers(0, 4, n)])
+
+
+# ---- host-side helpers of the callers (packages/pangraph/src/pangraph/edits.rs:418-531), restated for the tests ----
+def aligned_count_after(e, p, cons_len):
+    total = max(cons_len - p, 0)
+    overlap = sum((d[0] + d[1]) - max(p, d[0]) for d in e["dels"] if d[0] + d[1] > p)
+    return max(total - overlap, 0)
+
+
+def _round_half_away(x):
+    return int(x + 0.5) if x >= 0 else -int(-x + 0.5)          # f64::round
+
+
+def band_from_edits(e, cons_len):
+    """BandParameters::from_edits (align/map_variations.rs:29-37) = (Edit::aln_mean_shift, Edit::aln_bandwidth)"""
+    ac = aligned_count_after(e, 0, cons_len)
+    if ac == 0:
+        return None
+    total = 0
+    for pos, seq in e["inss"]:
+        total -= len(seq) * aligned_count_after(e, pos, cons_len)
+    for pos, ln in e["dels"]:
+        total += ln * aligned_count_after(e, pos, cons_len)
+    ms = _round_half_away(total / ac)
+    tuples = sorted([(pos, -len(seq)) for pos, seq in e["inss"]] + [(pos, ln) for pos, ln in e["dels"]], key=lambda t: t[0])   # sorted_by_key: stable
+    bw, cur = 0, 0
+    for i, (pos, shift) in enumerate(tuples):
+        if i == 0 and pos > 0:
+            bw = max(bw, abs(cur - ms))
+        cur += shift
+        if i == len(tuples) - 1 and (pos == cons_len or (shift > 0 and pos + shift == cons_len)):
+            continue
+        bw = max(bw, abs(cur - ms))
+    return ms, bw
+
+
+def realign_jobs(consensus, members, majority):
+    """PangraphBlock::edit_consensus_and_realign (pangraph/pangraph_block.rs:295-332): the new consensus and one map_variations job per member"""
+    new_cons = apply_edit(consensus, majority)
+    bms, bbw = band_from_edits(majority, len(consensus))
+    jobs = []
+    for e in members:
+        oms, obw = band_from_edits(e, len(consensus))
+        jobs.append((new_cons, apply_edit(consensus, e), oms - bms, obw + bbw))
+    return new_cons, jobs

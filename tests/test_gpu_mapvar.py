@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import mapvarbind as mb
-from test_mapvar_cpu import MAPVAR_KATS
+from test_mapvar_cpu import MAPVAR_KATS, RECONSENSUS_KATS, E
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +46,17 @@ def test_reference_known_answers_through_the_product(gpu_lib):
     g = mb.product_map_variations(d, [("ACGT", "AC", 0, 0), ("ACGT", "ACgT", 0, 0), ("ACGT", "ACGT", 0, 0)], mb.params(min_length=3))
     assert [x["status"] for x in g] == [1, 2, 0]
     assert mb.product_map_variations(d, []) == []
+
+
+def test_reconsensus_realign_known_answers_through_the_product(gpu_lib):
+    # reconsensus.rs:400-428: edit_consensus_and_realign of the reference's test blocks 1 and 3, all members of both blocks in one call
+    jobs, exp = [], []
+    for cons, members, majority, new_cons, expected in RECONSENSUS_KATS:
+        got_cons, j = mb.realign_jobs(cons, members, majority)
+        assert got_cons == new_cons
+        jobs += j; exp += expected
+    got = mb.product_map_variations(gpu_lib.dll, jobs)
+    assert [E(g["inss"], g["dels"], g["subs"]) for g in got] == exp
 
 
 def test_random_members_vs_oracle(gpu_lib, oracle_lib):

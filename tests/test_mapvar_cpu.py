@@ -78,6 +78,49 @@ def test_map_variations_known_answers(oracle_lib):
         assert mb.apply_edit(ref, r) == qry
 
 
+def E(inss=(), dels=(), subs=()):
+    return dict(inss=list(inss), dels=list(dels), subs=list(subs))
+
+
+# reconsensus.rs:185-329: blocks 1 and 3 of the reference's reconsensus tests -- consensus, member edits, majority edits (:338-358), and what
+# edit_consensus_and_realign must return (:400-428): new consensus and the members' edits after map_variations
+RECONSENSUS_KATS = [
+    ("AGGACTTCGATCTATTCGGAGAA",
+     [E([(17, "TTTT")], [(5, 2)], [(1, "T"), (17, "A")]), E([], [(5, 2)], [(1, "T"), (10, "C")]), E([], [(5, 2), (16, 2)], [(1, "T"), (10, "C")]),
+      E([], [(9, 3)], [(1, "C"), (17, "A")]), E([(5, "AA")], [(5, 2)], [(17, "A")])],
+     E([], [(5, 2)], [(1, "T"), (17, "A")]),
+     "ATGACCGATCTATTCAGAGAA",
+     [E([(15, "TTTT")]), E([], [], [(8, "C"), (15, "G")]), E([], [(14, 2)], [(8, "C")]), E([(5, "TT")], [(7, 3)], [(1, "C")]), E([(5, "AA")], [], [(1, "G")])]),
+    ("GCCTCTTCCCGACCACGCGTTACAACATGGGACAGGCCTGCGCTTGAGGC",
+     [E([], [(19, 4)], [(5, "A")]), E([(35, "AA"), (50, "TT")], [(20, 3)], [(5, "A")]), E([], [], [(14, "G"), (27, "G")]), E([(50, "TT")], [(20, 3)], [(5, "A")]), E([(50, "TT")])],
+     E([(50, "TT")], [(20, 3)], [(5, "A")]),
+     "GCCTCATCCCGACCACGCGTAACATGGGACAGGCCTGCGCTTGAGGCTT",
+     [E([], [(19, 1), (47, 2)]), E([(32, "AA")]), E([(20, "TAC")], [(47, 2)], [(5, "T"), (14, "G"), (24, "G")]), E(), E([(20, "TAC")], [], [(5, "T")])]),
+]
+
+
+def test_band_parameters_known_answers():
+    # map_variations.rs:88-188 (host-side helper of the callers, restated in tests/mapvarbind.py)
+    assert mb.band_from_edits(E(), 10) == (0, 0)
+    assert mb.band_from_edits(E([(0, "AAA")]), 10) == (-3, 0)
+    assert mb.band_from_edits(E([], [(0, 2)]), 10) == (2, 0)
+    assert mb.band_from_edits(E([(9, "C")]), 10) == (0, 1)
+    assert mb.band_from_edits(E([(2, "CCC")], [(2, 3)]), 25) == (0, 3)
+    assert mb.band_from_edits(E([(8, "CCC"), (20, "GG")], [(2, 3), (15, 2)], [(5, "A"), (10, "T")]), 25) == (1, 2)
+    for ref, qry, ms, bw, subs, dels, inss in MAPVAR_KATS:             # :214-218 and the like: the examples state their own band
+        assert mb.band_from_edits(E(inss, dels, subs), len(ref)) == (ms, bw)
+
+
+def test_reconsensus_realign_known_answers(oracle_lib):
+    # the re-alignment inside reconsensus is the same map_variations: reconsensus.rs:400-428
+    for cons, members, majority, new_cons, expected in RECONSENSUS_KATS:
+        got_cons, jobs = mb.realign_jobs(cons, members, majority)
+        assert got_cons == new_cons
+        for (r, q, ms, bw), exp in zip(jobs, expected):
+            g = mb.oracle_map_variations(oracle_lib.dll, r, q, ms, bw)
+            assert g["status"] == 0 and E(g["inss"], g["dels"], g["subs"]) == exp
+
+
 def test_simplestripe_band_hit_known_answers(oracle_lib):
     d = oracle_lib.dll
     # align.rs:191-222: NextalignParams::default() with one attempt, the band handed over as it is (no extra width)
