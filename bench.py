@@ -138,6 +138,76 @@ def respawn_under_torchrun(n: int):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def next_rows(pop, seed: int):
+    """SURVEY 8(f) rows that are built, timed once each OUTSIDE the timed region (rank 0, N = 1): the guide tree of the population's leaf
+    genomes and the re-alignment of member sequences onto block consensus sequences (synthetic merge: 200 blocks of ~10 kb, 100 members
+    each).  Reported next to the headline, never part of `value`.  A failure is reported as text, it does not fail the bench."""
+    import ctypes as C
+    import numpy as np
+    from pangraph_amd import batch
+    out = {}
+    dll = batch.lib()
+    try:
+        genomes = [pop.genomes[v] for v in pop.leaves]
+        n = len(genomes)
+        ptrs = (C.c_char_p * n)(*[C.cast(g.ctypes.data, C.c_char_p) for g in genomes])
+        lens = (C.c_uint32 * n)(*[len(g) for g in genomes])
+        merges = np.zeros((max(n - 1, 1), 2), dtype=np.int32)
+        dll.pga_guide_tree.restype = C.c_int
+        dll.pga_guide_tree.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        t0 = time.perf_counter()
+        rc = dll.pga_guide_tree(n, ptrs, lens, 15, 100, None, merges.ctypes.data)
+        dt = time.perf_counter() - t0
+        gbp = sum(len(g) for g in genomes) * 1e-9
+        out["f3_guide_tree"] = {"genomes": n, "Gbp": gbp, "seconds": dt, "gbp_s": gbp / dt, "rc": rc, "entry": "pga_guide_tree (mash distance k=15 w=100 + neighbor joining)"}
+    except Exception as e:                                       # noqa: BLE001
+        out["f3_guide_tree"] = {"error": repr(e)}
+    try:
+        from pangraph_amd import mapvar as mb
+        rng = np.random.default_rng(seed)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        refs, qrys = [], []
+        for b in range(200):
+            ref = acgt[rng.integers(0, 4, int(10000 * rng.uniform(0.5, 1.5)))]
+            rb = ref.tobytes()
+            for m in range(100):
+                a = ref.copy()
+                k = rng.random(len(a)) < 0.01
+                a[k] = acgt[rng.integers(0, 4, int(k.sum()))]
+                q = a.tobytes()
+                for _ in range(int(rng.integers(0, 4))):
+                    p0 = int(rng.integers(0, len(q))); ln = int(rng.integers(1, 20))
+                    q = q[:p0] + q[p0 + ln:] if rng.random() < 0.5 else q[:p0] + acgt[rng.integers(0, 4, ln)].tobytes() + q[p0:]
+                refs.append(rb); qrys.append(q)
+        n = len(qrys)
+        J = (mb.job_t * n)()
+        for i in range(n):
+            J[i].ref = refs[i]; J[i].qry = qrys[i]; J[i].ref_len = len(refs[i]); J[i].qry_len = len(qrys[i]); J[i].mean_shift = 0; J[i].band_width = 20
+        R = (mb.res_t * n)()
+        subs = C.POINTER(mb.sub_t)(); dels = C.POINTER(mb.del_t)(); inss = C.POINTER(mb.ins_t)(); iseq = C.POINTER(C.c_char)()
+        dll.pga_map_variations.restype = C.c_int
+        dll.pga_map_variations.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        dll.pga_free.argtypes = [C.c_void_p]
+        p = mb.params()
+        best = None
+        for rep in range(2):                                      # the first call also grows the allocator's pools
+            t0 = time.perf_counter()
+            rc = dll.pga_map_variations(n, J, C.byref(p), R, C.byref(subs), C.byref(dels), C.byref(inss), C.byref(iseq))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            for ptr in (subs, dels, inss, iseq):
+                if ptr:
+                    dll.pga_free(C.cast(ptr, C.c_void_p))
+        mbp = sum(len(q) for q in qrys) * 1e-6
+        # round trip of a sample through Edit::apply is the GPU tests' job; here: every job finished, none left the band
+        ok = all(R[i].status == 0 for i in range(0, n, 97))
+        out["f1_map_variations"] = {"members": n, "member_Mbp": mbp, "seconds": best, "gbp_s": mbp * 1e-3 / best, "rc": rc, "sample_status_ok": ok,
+                                    "retried": sum(R[i].attempts > 1 for i in range(n)), "entry": "pga_map_variations (band 20 + 5, up to 4 attempts), upload and edit download included"}
+    except Exception as e:                                       # noqa: BLE001
+        out["f1_map_variations"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +218,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--leaf-only", action="store_true", help="diagnosis: only the waves of height 1")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work per core (0 disables)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the one-off timings of the SURVEY 8(f) rows (guide tree, map_variations) reported next to the headline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -317,6 +388,8 @@ def main():
     if rank == 0:
         if args.cpu_budget > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(waves, args.cpu_budget)
+        if world == 1 and not args.no_next_rows:
+            out["next_rows"] = next_rows(pop, args.seed)
         elif world > 1:
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "reference", "sample": "measured at N=1 only"}
         print(json.dumps(out))
