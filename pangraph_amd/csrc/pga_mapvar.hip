@@ -30,6 +30,7 @@
 #include <unordered_map>
 #include <cstdio>
 #include <chrono>
+#include <thread>
 
 namespace pga {
 
@@ -68,6 +69,121 @@ __device__ __forceinline__ unsigned long long mv_low(int n) { return n >= 64 ? ~
 __device__ __forceinline__ void mv_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 // between rows: LDS operations of one wave execute in order, so the LDS rings only need the compiler to keep that order
 template <int RING> __device__ __forceinline__ void mv_row_fence() { if (RING > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// traceback and edit extraction of one job by the whole wave (the path bytes are in `slab`, written by the score-matrix pass)
+__device__ __forceinline__ void mv_finish(const uint8_t *ref, const uint8_t *qry, int ref_len, int qlen, long long ms, long long bw, int attempt, uint8_t *slab,
+                                          const MvParams &P, int lane, MvOut &O, MvCursors *cur, const MvCaps &cap, pga_sub_t *subs, pga_del_t *dels, pga_ins_t *inss, char *ins_seq)
+{
+	auto sbeg = [&](int i) -> int { if (i == 0) return 0; const long long v = (long long)i - ms - bw; return (int)(v < 0 ? 0 : v > qlen ? qlen : v); };
+	auto send = [&](int i) -> int { if (i == ref_len) return qlen + 1; const long long v = (long long)i - ms + bw + 1; return (int)(v < 1 ? 1 : v > (long long)qlen + 1 ? qlen + 1 : v); };
+	const long long pitch_ll = 2 * bw + 2 < (long long)qlen + 2 ? 2 * bw + 2 : (long long)qlen + 2;
+	const size_t pitch = (size_t)pitch_ll;
+	const size_t path_bytes = ref_len > 0 ? (size_t)(ref_len - 1) * pitch + (size_t)qlen + 2 : 0;
+	uint32_t *runs = (uint32_t*)(slab + ((path_bytes + 15) & ~(size_t)15));
+	auto paddr = [&](int ri, int q) -> size_t { return (size_t)(ri - 1) * pitch + (size_t)(q - sbeg(ri)); };
+	uint32_t n_runs = 0;
+	bool go = true;
+	// ---- backtrace.rs:17-85, 64 cells per trip ----
+	int r = ref_len, q = qlen, cm = 0, hit = 0, cur_t = -1;
+	uint32_t cur_n = 0;
+	auto push = [&](int t, uint32_t n) {
+		if (t == cur_t) { cur_n += n; return; }
+		if (cur_t >= 0) { if (lane == 0) runs[n_runs] = (uint32_t)cur_t << 30 | cur_n; ++n_runs; }
+		cur_t = t; cur_n = n;
+	};
+	while ((r > 0 || q > 0) && O.status == 0) {
+		if (r == 0) {                                                       // row 0 is REF_GAP_EXTEND + REF_GAP_MATRIX all the way (:63-64)
+			if (q >= send(0)) { O.status = 3; break; }
+			push(1, (uint32_t)q); q = 0; break;
+		}
+		int rr = r - lane, qq = q - lane;
+		bool v = rr >= 1 && qq >= 0 && qq >= sbeg(rr) && qq < send(rr);
+		int o = v ? (int)slab[paddr(rr, qq)] : 0;
+		if (!(__ballot(v) & 1ULL)) { O.status = 3; break; }                 // the reference would panic (band_2d.rs:118-124)
+		const int o0 = rl(o, 0);
+		if (o0 & MV_BOUNDARY) hit = 1;
+		if (cm == 0 && (o0 & MV_MATCH)) {
+			const unsigned long long m = __ballot(v && (o & MV_MATCH) && qq >= 1);
+			const int n = m == ~0ULL ? 64 : __builtin_ctzll(~m);
+			if (__ballot(o & MV_BOUNDARY) & mv_low(n)) hit = 1;
+			push(0, (uint32_t)n); r -= n; q -= n;
+		} else if ((cm == 0 && (o0 & MV_REF_GAP_MATRIX)) || cm == MV_REF_GAP_MATRIX) {
+			qq = q - lane;
+			v = qq >= 1 && qq >= sbeg(r) && qq < send(r);
+			o = v ? (int)slab[paddr(r, qq)] : 0;
+			const unsigned long long vm = __ballot(v), em = __ballot(v && (o & MV_REF_GAP_EXTEND));
+			if (!(vm & 1ULL)) { O.status = 3; break; }
+			const int k = em == ~0ULL ? 64 : __builtin_ctzll(~em);
+			int n;
+			if (k < 64 && ((vm >> k) & 1ULL)) { n = k + 1; cm = 0; } else { n = k; cm = MV_REF_GAP_MATRIX; }
+			if (__ballot(o & MV_BOUNDARY) & mv_low(n)) hit = 1;
+			push(1, (uint32_t)n); q -= n;
+		} else if ((cm == 0 && (o0 & MV_QRY_GAP_MATRIX)) || cm == MV_QRY_GAP_MATRIX) {
+			rr = r - lane;
+			v = rr >= 1 && q >= sbeg(rr) && q < send(rr);
+			o = v ? (int)slab[paddr(rr, q)] : 0;
+			const unsigned long long vm = __ballot(v), em = __ballot(v && (o & MV_QRY_GAP_EXTEND));
+			if (!(vm & 1ULL)) { O.status = 3; break; }
+			const int k = em == ~0ULL ? 64 : __builtin_ctzll(~em);
+			int n;
+			if (k < 64 && ((vm >> k) & 1ULL)) { n = k + 1; cm = 0; } else { n = k; cm = MV_QRY_GAP_MATRIX; }
+			if (__ballot(o & MV_BOUNDARY) & mv_low(n)) hit = 1;
+			push(2, (uint32_t)n); r -= n;
+		} else O.status = 3;                                                 // unreachable!() in the reference
+	}
+	if (cur_t >= 0) { if (lane == 0) runs[n_runs] = (uint32_t)cur_t << 30 | cur_n; ++n_runs; }
+	mv_fence();
+	O.hit = hit;
+	if (O.status || (hit && attempt < P.max_attempts)) go = false;   // align.rs:55: another attempt with a wider band
+	// ---- insertions_strip + find_nuc_changes + the terminal deletions, from the runs (front to back = the list backwards) ----
+	const unsigned long long lt = (1ULL << lane) - 1;
+	for (int pass = 0; go && pass < 2; ++pass) {
+		uint32_t n_subs = 0, n_dels = 0, n_inss = 0, n_ib = 0;
+		long long n_del = 0, del_pos = -1, a_start = -1, a_end = -1;
+		bool before = true;
+		int rp = 0, qp = 0;
+		for (int t = (int)n_runs - 1; t >= 0; --t) {
+			const uint32_t w = runs[t];
+			const int kind = (int)(w >> 30); const int L = (int)(w & 0x3fffffffu);
+			if (kind == 0) {
+				if (before) { a_start = rp; before = false; }
+				else if (n_del > 0) { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = (uint32_t)del_pos; dels[O.del_off + n_dels].len = (uint32_t)n_del; } ++n_dels; n_del = 0; }
+				for (int i0 = 0; i0 < L; i0 += 64) {
+					const int i = i0 + lane;
+					int a = 0, c = 0;
+					if (i < L) { a = ref[rp + i]; c = qry[qp + i]; }
+					const bool diff = i < L && a != c;
+					const unsigned long long dm = __ballot(diff);
+					if (pass && diff) { pga_sub_t s; s.pos = (uint32_t)(rp + i); s.alt = (uint32_t)mv_letter(c); subs[O.sub_off + n_subs + (uint32_t)__popcll(dm & lt)] = s; }
+					n_subs += (uint32_t)__popcll(dm);
+				}
+				rp += L; qp += L; a_end = rp;
+			} else if (kind == 1) {
+				if (pass) {
+					if (lane == 0) { pga_ins_t s; s.pos = (uint32_t)rp; s.len = (uint32_t)L; s.seq_off = O.ib_off + n_ib; inss[O.ins_off + n_inss] = s; }   // map_variations.rs:71-74: position + 1
+					for (int i = lane; i < L; i += 64) ins_seq[O.ib_off + n_ib + (uint32_t)i] = mv_letter(qry[qp + i]);
+				}
+				++n_inss; n_ib += (uint32_t)L; qp += L;
+			} else {
+				if (!before) { if (n_del == 0) del_pos = rp; n_del += L; }
+				rp += L;
+			}
+		}
+		// align_with_nextclade.rs:46-64: leading and trailing gaps, behind the internal deletions
+		if (a_start >= 0 && a_end >= 0) {
+			if (a_start > 0) { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = 0; dels[O.del_off + n_dels].len = (uint32_t)a_start; } ++n_dels; }
+			if (a_end < ref_len) { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = (uint32_t)a_end; dels[O.del_off + n_dels].len = (uint32_t)(ref_len - a_end); } ++n_dels; }
+		} else { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = 0; dels[O.del_off + n_dels].len = (uint32_t)ref_len; } ++n_dels; }
+		if (pass == 0) {
+			O.n_subs = n_subs; O.n_dels = n_dels; O.n_inss = n_inss; O.n_ib = n_ib;
+			unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+			if (lane == 0) { a0 = atomicAdd(&cur->subs, (unsigned long long)n_subs); a1 = atomicAdd(&cur->dels, (unsigned long long)n_dels); a2 = atomicAdd(&cur->inss, (unsigned long long)n_inss); a3 = atomicAdd(&cur->ib, (unsigned long long)n_ib); }
+			O.sub_off = (uint64_t)__shfl((long long)a0, 0); O.del_off = (uint64_t)__shfl((long long)a1, 0); O.ins_off = (uint64_t)__shfl((long long)a2, 0); O.ib_off = (uint64_t)__shfl((long long)a3, 0);
+			// the pools are sized for typical divergence, not for the worst case: a job that does not fit comes back (status 4) and runs again
+			if (O.sub_off + n_subs > cap.subs || O.del_off + n_dels > cap.dels || O.ins_off + n_inss > cap.inss || O.ib_off + n_ib > cap.ib) { O.status = 4; go = false; }
+		}
+	}
+}
 
 // RING > 0: the rings live in LDS (RING columns); RING == 0: in device memory, ring_n columns per wave
 template <int RING>
@@ -191,108 +307,8 @@ void k_mapvar(const MvJob *__restrict__ jobs, int n_jobs, MvParams P, const uint
 		mv_fence();                                                         // the path bytes, for the lanes that read them below
 		O.score = final_score;
 
-		// ---- backtrace.rs:17-85, 64 cells per trip ----
-		int r = ref_len, q = qlen, cm = 0, hit = 0, cur_t = -1;
-		uint32_t cur_n = 0;
-		auto push = [&](int t, uint32_t n) {
-			if (t == cur_t) { cur_n += n; return; }
-			if (cur_t >= 0) { if (lane == 0) runs[n_runs] = (uint32_t)cur_t << 30 | cur_n; ++n_runs; }
-			cur_t = t; cur_n = n;
-		};
-		while ((r > 0 || q > 0) && O.status == 0) {
-			if (r == 0) {                                                       // row 0 is REF_GAP_EXTEND + REF_GAP_MATRIX all the way (:63-64)
-				if (q >= send(0)) { O.status = 3; break; }
-				push(1, (uint32_t)q); q = 0; break;
-			}
-			int rr = r - lane, qq = q - lane;
-			bool v = rr >= 1 && qq >= 0 && qq >= sbeg(rr) && qq < send(rr);
-			int o = v ? (int)slab[paddr(rr, qq)] : 0;
-			if (!(__ballot(v) & 1ULL)) { O.status = 3; break; }                 // the reference would panic (band_2d.rs:118-124)
-			const int o0 = rl(o, 0);
-			if (o0 & MV_BOUNDARY) hit = 1;
-			if (cm == 0 && (o0 & MV_MATCH)) {
-				const unsigned long long m = __ballot(v && (o & MV_MATCH) && qq >= 1);
-				const int n = m == ~0ULL ? 64 : __builtin_ctzll(~m);
-				if (__ballot(o & MV_BOUNDARY) & mv_low(n)) hit = 1;
-				push(0, (uint32_t)n); r -= n; q -= n;
-			} else if ((cm == 0 && (o0 & MV_REF_GAP_MATRIX)) || cm == MV_REF_GAP_MATRIX) {
-				qq = q - lane;
-				v = qq >= 1 && qq >= sbeg(r) && qq < send(r);
-				o = v ? (int)slab[paddr(r, qq)] : 0;
-				const unsigned long long vm = __ballot(v), em = __ballot(v && (o & MV_REF_GAP_EXTEND));
-				if (!(vm & 1ULL)) { O.status = 3; break; }
-				const int k = em == ~0ULL ? 64 : __builtin_ctzll(~em);
-				int n;
-				if (k < 64 && ((vm >> k) & 1ULL)) { n = k + 1; cm = 0; } else { n = k; cm = MV_REF_GAP_MATRIX; }
-				if (__ballot(o & MV_BOUNDARY) & mv_low(n)) hit = 1;
-				push(1, (uint32_t)n); q -= n;
-			} else if ((cm == 0 && (o0 & MV_QRY_GAP_MATRIX)) || cm == MV_QRY_GAP_MATRIX) {
-				rr = r - lane;
-				v = rr >= 1 && q >= sbeg(rr) && q < send(rr);
-				o = v ? (int)slab[paddr(rr, q)] : 0;
-				const unsigned long long vm = __ballot(v), em = __ballot(v && (o & MV_QRY_GAP_EXTEND));
-				if (!(vm & 1ULL)) { O.status = 3; break; }
-				const int k = em == ~0ULL ? 64 : __builtin_ctzll(~em);
-				int n;
-				if (k < 64 && ((vm >> k) & 1ULL)) { n = k + 1; cm = 0; } else { n = k; cm = MV_QRY_GAP_MATRIX; }
-				if (__ballot(o & MV_BOUNDARY) & mv_low(n)) hit = 1;
-				push(2, (uint32_t)n); r -= n;
-			} else O.status = 3;                                                 // unreachable!() in the reference
 		}
-		if (cur_t >= 0) { if (lane == 0) runs[n_runs] = (uint32_t)cur_t << 30 | cur_n; ++n_runs; }
-		mv_fence();
-		O.hit = hit;
-		if (O.status || (hit && (int)J.attempt < P.max_attempts)) go = false;   // align.rs:55: another attempt with a wider band
-		}
-
-		// ---- insertions_strip + find_nuc_changes + the terminal deletions, from the runs (front to back = the list backwards) ----
-		const unsigned long long lt = (1ULL << lane) - 1;
-		for (int pass = 0; go && pass < 2; ++pass) {
-			uint32_t n_subs = 0, n_dels = 0, n_inss = 0, n_ib = 0;
-			long long n_del = 0, del_pos = -1, a_start = -1, a_end = -1;
-			bool before = true;
-			int rp = 0, qp = 0;
-			for (int t = (int)n_runs - 1; t >= 0; --t) {
-				const uint32_t w = runs[t];
-				const int kind = (int)(w >> 30); const int L = (int)(w & 0x3fffffffu);
-				if (kind == 0) {
-					if (before) { a_start = rp; before = false; }
-					else if (n_del > 0) { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = (uint32_t)del_pos; dels[O.del_off + n_dels].len = (uint32_t)n_del; } ++n_dels; n_del = 0; }
-					for (int i0 = 0; i0 < L; i0 += 64) {
-						const int i = i0 + lane;
-						int a = 0, c = 0;
-						if (i < L) { a = ref[rp + i]; c = qry[qp + i]; }
-						const bool diff = i < L && a != c;
-						const unsigned long long dm = __ballot(diff);
-						if (pass && diff) { pga_sub_t s; s.pos = (uint32_t)(rp + i); s.alt = (uint32_t)mv_letter(c); subs[O.sub_off + n_subs + (uint32_t)__popcll(dm & lt)] = s; }
-						n_subs += (uint32_t)__popcll(dm);
-					}
-					rp += L; qp += L; a_end = rp;
-				} else if (kind == 1) {
-					if (pass) {
-						if (lane == 0) { pga_ins_t s; s.pos = (uint32_t)rp; s.len = (uint32_t)L; s.seq_off = O.ib_off + n_ib; inss[O.ins_off + n_inss] = s; }   // map_variations.rs:71-74: position + 1
-						for (int i = lane; i < L; i += 64) ins_seq[O.ib_off + n_ib + (uint32_t)i] = mv_letter(qry[qp + i]);
-					}
-					++n_inss; n_ib += (uint32_t)L; qp += L;
-				} else {
-					if (!before) { if (n_del == 0) del_pos = rp; n_del += L; }
-					rp += L;
-				}
-			}
-			// align_with_nextclade.rs:46-64: leading and trailing gaps, behind the internal deletions
-			if (a_start >= 0 && a_end >= 0) {
-				if (a_start > 0) { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = 0; dels[O.del_off + n_dels].len = (uint32_t)a_start; } ++n_dels; }
-				if (a_end < ref_len) { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = (uint32_t)a_end; dels[O.del_off + n_dels].len = (uint32_t)(ref_len - a_end); } ++n_dels; }
-			} else { if (pass && lane == 0) { dels[O.del_off + n_dels].pos = 0; dels[O.del_off + n_dels].len = (uint32_t)ref_len; } ++n_dels; }
-			if (pass == 0) {
-				O.n_subs = n_subs; O.n_dels = n_dels; O.n_inss = n_inss; O.n_ib = n_ib;
-				unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-				if (lane == 0) { a0 = atomicAdd(&cur->subs, (unsigned long long)n_subs); a1 = atomicAdd(&cur->dels, (unsigned long long)n_dels); a2 = atomicAdd(&cur->inss, (unsigned long long)n_inss); a3 = atomicAdd(&cur->ib, (unsigned long long)n_ib); }
-				O.sub_off = (uint64_t)__shfl((long long)a0, 0); O.del_off = (uint64_t)__shfl((long long)a1, 0); O.ins_off = (uint64_t)__shfl((long long)a2, 0); O.ib_off = (uint64_t)__shfl((long long)a3, 0);
-				// the pools are sized for typical divergence, not for the worst case: a job that does not fit comes back (status 4) and runs again
-				if (O.sub_off + n_subs > cap.subs || O.del_off + n_dels > cap.dels || O.ins_off + n_inss > cap.inss || O.ib_off + n_ib > cap.ib) { O.status = 4; go = false; }
-			}
-		}
+		if (go) mv_finish(ref, qry, ref_len, qlen, ms, bw, (int)J.attempt, slab, P, lane, O, cur, cap, subs, dels, inss, ins_seq);
 		if (lane == 0) out[j] = O;
 	}
 }
@@ -314,14 +330,19 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 	if (prm.max_alignment_attempts < 1) throw std::runtime_error("pga_map_variations: max_alignment_attempts must be at least 1");
 	hipStream_t st = 0;
 	// sequences: one copy per distinct (pointer, length) -- the members of a block share the anchor consensus
+	// (offsets first, then the distinct sequences are copied into ONE pinned staging buffer by a few host threads and leave in one DMA:
+	// growing a std::vector by 200 MB and a pageable copy cost more than the kernels)
 	struct Placed { uint32_t len; uint64_t off; };
 	std::unordered_map<const char*, Placed> seen;
-	std::vector<char> cat;
+	struct Piece { const char *p; uint32_t len; uint64_t off; };
+	std::vector<Piece> pieces;
+	uint64_t cat_size = 0;
 	auto place = [&](const char *p, uint32_t len) -> uint64_t {
 		auto it = seen.find(p);
 		if (it != seen.end() && it->second.len == len) return it->second.off;
-		const uint64_t off = cat.size();
-		cat.insert(cat.end(), p, p + len);
+		const uint64_t off = cat_size;
+		pieces.push_back(Piece{p, len, off});
+		cat_size += len;
 		seen[p] = Placed{len, off};
 		return off;
 	};
@@ -339,9 +360,17 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 		J.attempt = 1; J.orig = (uint32_t)i;
 	}
 	DBuf<char> d_ascii; DBuf<uint8_t> d_codes;
-	d_ascii.upload(cat.data(), cat.size(), st);
-	d_codes.alloc(cat.size() + 64);
-	if (!cat.empty()) k_mv_encode<<<(unsigned)std::min<size_t>((cat.size() + 255) / 256, 65535), 256, 0, st>>>(d_ascii.p, cat.size(), d_codes.p);
+	PinVec<char> stage;
+	stage.resize(cat_size + 1);
+	{
+		const int nt = cat_size > (8u << 20) ? 4 : 1;
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)nt) memcpy(stage.data() + pieces[i].off, pieces[i].p, pieces[i].len); });
+		for (auto &x : th) x.join();
+	}
+	d_ascii.upload(stage.data(), cat_size, st);
+	d_codes.alloc(cat_size + 64);
+	if (cat_size) k_mv_encode<<<(unsigned)std::min<size_t>((cat_size + 255) / 256, 65535), 256, 0, st>>>(d_ascii.p, cat_size, d_codes.p);
 	const MvParams P{prm.score_match, prm.penalty_mismatch, prm.penalty_gap_open, prm.penalty_gap_extend, prm.left_terminal_gaps_free != 0, prm.right_terminal_gaps_free != 0,
 	                 prm.gap_align_left != 0, prm.min_length, prm.max_alignment_attempts};
 	const char *eb = getenv("PGA_MAPVAR_SLAB_GB");
