@@ -100,7 +100,9 @@ def test_wide_bands_and_ambiguity_letters_vs_oracle(gpu_lib, oracle_lib):
         qry = "".join(iupac[rng.integers(0, 15, int(rng.integers(5, 300)))])
         jobs.append((ref, qry, int(rng.integers(-50, 50)), int(rng.integers(0, 40))))           # unrelated: every attempt hits the boundary
     jobs.append(("A", "C", 0, 0)); jobs.append(("ACGT" * 10, "A", -100, 0)); jobs.append(("A", "ACGT" * 10, 100, 0))
-    p = mb.params()
+    jobs.append(("", "ACGT", 0, 0)); jobs.append(("ACGT", "", 0, 0)); jobs.append(("", "", 0, 0))    # empty sides (min_length 0 below): one insertion / one deletion / nothing
+    jobs.append(("ACGT" * 50, "ACGT" * 50, 0, 2 ** 31 - 1)); jobs.append(("ACGT" * 50, "TTTT" + "ACGT" * 50, -(2 ** 31 - 1), 0))   # band and shift at the ends of their types
+    p = mb.params(min_length=0)
     exp = _oracle(oracle_lib.dll, jobs, p)
     got = mb.product_map_variations(gpu_lib.dll, jobs, p)
     _same(got, exp)
