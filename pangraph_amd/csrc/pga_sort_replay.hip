@@ -52,7 +52,7 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 // persistent waves over the run queue of this pass
 __global__ __launch_bounds__(64)
 void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
-               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint, u128 *__restrict__ tmp_all)
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint, u128 *__restrict__ tmp_all, uint2 *__restrict__ lg_all)
 {
 	__shared__ RsLds L;
 	const int lane = threadIdx.x;
@@ -76,7 +76,7 @@ void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_
 			uint32_t cnt[4], off[4];
 			uint32_t *rend = rend_all ? rend_all + cur_start : nullptr;    // scratch of the run-length walk, one word per record
 			const unsigned long long tl0 = wall_clock64();
-			while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend, tmp_all ? tmp_all + cur_start : nullptr)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
+			while (shift >= 0 && !rs_level_wave(beg, n, shift, L, lane, cnt, off, rend, tmp_all ? tmp_all + cur_start : nullptr, lg_all ? lg_all + cur_start : nullptr)) shift = rs_next_level(R.vary, shift - 8);   // levels that leave the run in one bucket
 			t_walk += wall_clock64() - tl0;
 			if (shift <= 0) break;                                // nothing below the last byte
 			const int next = rs_next_level(R.vary, shift - 8);
@@ -324,6 +324,8 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	if (!getenv("PGA_NO_RUNWALK")) rend.alloc(n_total);
 	DBuf<u128> tmp2;                        // the out-of-place image of the two-bucket levels
 	if (rend.p && !getenv("PGA_NO_TWOBUCKET")) tmp2.alloc(n_total);
+	DBuf<uint2> lg;                          // the digit walk's record of moves (destination slot, source slot)
+	if (tmp2.p && !getenv("PGA_NO_DIGITWALK")) lg.alloc(n_total);
 	double pass_ms[9] = {0};
 	if (verbose) { pass_ms[8] = et.stop(); }
 	// (measured: the persistent waves of the dependency-driven variant hold their LDS and slots while they wait and starve the kernels of
@@ -340,7 +342,7 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	} else
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
-		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p);
+		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p);
 		if (verbose) {
 			pass_ms[pass] = ep.stop();
 			uint32_t nr = 0; PGA_HIP(hipMemcpy(&nr, ctr.p + 2 * (pass + 1), 4, hipMemcpyDeviceToHost));

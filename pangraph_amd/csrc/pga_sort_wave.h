@@ -324,7 +324,107 @@ __device__ inline bool rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA
 	return true;
 }
 
-__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4], uint32_t *rend = nullptr, u128 *tmp = nullptr)
+// ---- a level whose digit runs are SHORT (chain scores, the low bytes of positions): the walk of ksort.h:128-141 simulated on digits ----
+// Where the token goes depends only on the ORIGINAL digit sequence (slots at or beyond a head still hold their original records), so the
+// walk does not have to move records to know its way: it runs over a byte array of the original digits (read-only, cached per bucket in
+// LDS windows of 128-4096 digits instead of 8-64 records: a refill every few hundred steps instead of every eighth), and writes down
+// for every slot it fills where the record came from (each slot at a head is filled exactly once, from a slot that still held its
+// original record).  One step is two dependent LDS reads (head, digit) instead of a 16-byte exchange through a window with its flush and
+// refill traffic; the records then move in two parallel passes (gather into `tmp`, scatter back).
+__device__ inline void rs_level_sim(u128 *beg, int64_t n, int shift, RsLds &L, int lane, const uint32_t (&cnt)[4], const uint32_t (&off)[4], const unsigned long long (&nonempty)[4], uint32_t n_ne,
+                                    uint8_t *dig, uint2 *lg, u128 *tmp)
+{
+	for (int64_t i0 = 0; i0 < n; i0 += 256) {
+		uint32_t dg[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; dg[k] = i < n ? (uint32_t)((beg[i].x >> shift) & 255) : 0u; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; if (i < n) dig[i] = (uint8_t)dg[k]; }
+	}
+	int wdl = 6;
+	while (wdl < 12 && (n_ne << (wdl + 1)) <= (uint32_t)(RS_POOL * 16)) ++wdl;
+	const uint32_t WD = 1u << wdl;
+	uint8_t *dwin = (uint8_t*)L.win;
+	{
+		uint32_t rank0 = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int b = lane + 64 * k;
+			L.head[b] = off[k]; L.tail[b] = off[k] + cnt[k]; L.wbase[b] = RS_NONE;
+			L.wslot[b] = (uint8_t)(rank0 + (uint32_t)__popcll(nonempty[k] & ((1ULL << lane) - 1)));
+			rank0 += (uint32_t)__popcll(nonempty[k]);
+		}
+	}
+	rs_fence_wg();                                              // the digit bytes, for the lanes that fill windows from them
+	// the window of bucket k covers position pos (uniform arguments); returns the window's base
+	auto cover = [&](uint32_t k, uint32_t pos, uint32_t ws) -> uint32_t {
+		const uint32_t wb = L.wbase[k];
+		if (wb != RS_NONE && pos - wb < WD) return wb;
+		const uint32_t tk = L.tail[k];
+		for (uint32_t i = (uint32_t)lane; i < WD; i += 64) if (pos + i < tk) dwin[ws + i] = dig[pos + i];
+		if (lane == 0) L.wbase[k] = pos;
+		rs_fence_wave();
+		return pos;
+	};
+	uint32_t n_log = 0;
+#pragma unroll 1
+	for (int kk = 0; kk < 4; ++kk) {
+		unsigned long long todo = nonempty[kk];
+		while (todo) {
+			const uint32_t i = (uint32_t)(64 * kk + (__ffsll((long long)todo) - 1));
+			todo &= todo - 1;
+			uint32_t h = L.head[i]; const uint32_t tl = L.tail[i];
+			const uint32_t wsi = (uint32_t)L.wslot[i] << wdl;
+			while (h < tl) {
+				const uint32_t wb = cover(i, h, wsi);
+				// records that are home already: 64 window digits per step
+				const uint32_t p = h + (uint32_t)lane;
+				const bool inw = p - wb < WD && p < tl;
+				const unsigned long long vm = __ballot(inw), fm = __ballot(inw && (uint32_t)dwin[wsi + (p - wb)] != i);
+				if (!fm) { h += (uint32_t)__popcll(vm); continue; }
+				h += (uint32_t)(__ffsll((long long)fm) - 1);
+				// the displacement cycle that starts with the record at h (ksort.h:131-138), on digits
+				uint32_t src = h, k = (uint32_t)dwin[wsi + (h - wb)];
+				do {
+					const uint32_t pos = L.head[k];
+					const uint32_t ws = (uint32_t)L.wslot[k] << wdl;
+					const uint32_t wbk = cover(k, pos, ws);
+					const uint32_t dd = (uint32_t)dwin[ws + (pos - wbk)];
+					if (lane == 0) { lg[n_log] = make_uint2(pos, src); L.head[k] = pos + 1; }
+					rs_fence_wave();
+					++n_log;
+					src = pos; k = dd;
+				} while (k != i);
+				if (lane == 0) lg[n_log] = make_uint2(h, src);
+				++n_log;
+				++h;
+			}
+			if (lane == 0) L.head[i] = h;
+			rs_fence_wave();
+		}
+	}
+	rs_fence_wg();
+	if (lane == 0) { L.prof[2] += 1; L.prof[3] += n_log; }
+	// the records follow: final[dst] = original[src]
+	for (uint32_t e0 = 0; e0 < n_log; e0 += 256) {
+		u128 v[4]; uint32_t e[4];
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { e[c] = e0 + (uint32_t)lane + 64u * c; if (e[c] < n_log) v[c] = ld128(&beg[lg[e[c]].y]); }
+#pragma unroll
+		for (int c = 0; c < 4; ++c) if (e[c] < n_log) tmp[e[c]] = v[c];
+	}
+	rs_fence_wg();
+	for (uint32_t e0 = 0; e0 < n_log; e0 += 256) {
+		u128 v[4]; uint32_t e[4];
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { e[c] = e0 + (uint32_t)lane + 64u * c; if (e[c] < n_log) v[c] = ld128(&tmp[e[c]]); }
+#pragma unroll
+		for (int c = 0; c < 4; ++c) if (e[c] < n_log) beg[lg[e[c]].x] = v[c];
+	}
+	rs_fence_wg();
+}
+
+__device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, int lane, uint32_t (&cnt)[4], uint32_t (&off)[4], uint32_t *rend = nullptr, u128 *tmp = nullptr, uint2 *lg = nullptr)
 {
 	for (int d = lane; d < 256; d += 64) L.head[d] = 0, L.wbase[d] = RS_NONE;
 	rs_fence_wave();
@@ -389,6 +489,7 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 			return true;
 		}
 	}
+	if (rend && tmp && lg && n >= 512) { rs_level_sim(beg, n, shift, L, lane, cnt, off, nonempty, n_ne, (uint8_t*)rend, lg, tmp); return true; }
 	// window space: the non-empty buckets share the pool, 16 to 64 records each
 	int wlog = 3;
 	while (wlog < 6 && (n_ne << (wlog + 1)) <= RS_POOL) ++wlog;
