@@ -74,3 +74,19 @@ def map_variations(jobs, p=None, dll=None):
         if ptr:
             dll.pga_free(C.cast(ptr, C.c_void_p))
     return out
+
+
+def shard_jobs(jobs, world):
+    """jobs of one call split over `world` ranks, balanced by band cells (rows x band width): [[job index, ...] per rank].  Jobs are
+    independent (one per member sequence), so a multi-GPU host needs no collective: every rank calls map_variations on its share and the
+    edits are gathered like match lists.  Deterministic (largest first, ties by index), identical on every rank."""
+    cost = [(max(1, len(j[0])) * (2 * (j[3] + 5) + 1), i) for i, j in enumerate(jobs)]
+    order = sorted(cost, key=lambda t: (-t[0], t[1]))
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for c, i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i); load[r] += c
+    for r in range(world):
+        out[r].sort()
+    return out

@@ -92,3 +92,27 @@ def test_header_layout_pinned_against_reference_header(tmp_path):
         outs.append(subprocess.run([exe], check=True, capture_output=True, text=True).stdout)
     assert outs[0] == outs[1], "\n".join(a + "   |   " + b for a, b in zip(outs[0].splitlines(), outs[1].splitlines()) if a != b)
     assert outs[0].splitlines()[0] == "sizeof 24 248 80 24 80 24"
+
+
+def test_batch_header_structs_match_the_ctypes_mirrors(tmp_path):
+    """include/pga_align.h itself against the Python mirrors (pangraph_amd/batch.py, pangraph_amd/mapvar.py): size and the offset of every
+    field, from a C probe compiled against the header."""
+    import ctypes as C
+    from pangraph_amd import batch, mapvar
+    pairs = [("pga_match_t", batch.pga_match_t), ("pga_filter_params_t", batch.pga_filter_params_t), ("pga_mapvar_params_t", mapvar.params_t),
+             ("pga_mapvar_job_t", mapvar.job_t), ("pga_mapvar_res_t", mapvar.res_t), ("pga_sub_t", mapvar.sub_t), ("pga_del_t", mapvar.del_t), ("pga_ins_t", mapvar.ins_t)]
+    rename = {"ref": "ref"}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pga_align.h"', 'int main(void) {']
+    for cname, ct in pairs:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for f in ct._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {rename.get(f[0], f[0])}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "probe")
+    subprocess.run(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    got = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines()
+    want = [" ".join([cname, str(C.sizeof(ct))] + [str(getattr(ct, f[0]).offset) for f in ct._fields_]) for cname, ct in pairs]
+    assert got == want

@@ -135,3 +135,19 @@ def test_block_of_many_members_round_trip(gpu_lib, oracle_lib):
         assert g["status"] == 0 and mb.apply_edit(r, g) == q
     idx = list(range(0, 600, 60))
     _same([got[i] for i in idx], _oracle(oracle_lib.dll, [jobs[i] for i in idx], mb.params()))
+
+
+def test_sharded_jobs_give_the_same_edits(gpu_lib):
+    # multi-GPU shape of this path: every rank takes its share of the jobs (mapvar.shard_jobs), no collective; two shares on one GPU here
+    from pangraph_amd.mapvar import shard_jobs
+    rng = np.random.default_rng(23)
+    jobs = []
+    for _ in range(40):
+        ref = mb.random_seq(rng, int(rng.integers(50, 3000)))
+        jobs += [(ref, mb.mutate(rng, ref, snp=0.02, indel=0.005, max_indel=25) or "A", int(rng.integers(-2, 3)), int(rng.integers(0, 20))) for _ in range(5)]
+    whole = mb.product_map_variations(gpu_lib.dll, jobs)
+    merged = [None] * len(jobs)
+    for share in shard_jobs(jobs, 2):
+        for i, g in zip(share, mb.product_map_variations(gpu_lib.dll, [jobs[i] for i in share])):
+            merged[i] = g
+    assert merged == whole

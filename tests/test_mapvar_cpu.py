@@ -153,3 +153,16 @@ def test_random_members_round_trip(oracle_lib):
         assert r["status"] == 0 and mb.apply_edit(ref, r) == qry
         n_retry += r["attempts"] > 1
     assert n_retry > 0
+
+
+def test_job_sharding_is_balanced_and_complete():
+    # multi-GPU: jobs are independent, every rank takes a share (pangraph_amd/mapvar.py:shard_jobs); no collective on this path
+    from pangraph_amd.mapvar import shard_jobs
+    rng = np.random.default_rng(5)
+    jobs = [("A" * int(rng.integers(1, 20000)), "A", 0, int(rng.integers(0, 60))) for _ in range(500)]
+    for world in (1, 2, 8):
+        sh = shard_jobs(jobs, world)
+        assert sorted(i for s in sh for i in s) == list(range(len(jobs)))
+        cost = [sum(len(jobs[i][0]) * (2 * (jobs[i][3] + 5) + 1) for i in s) for s in sh]
+        assert max(cost) <= 1.05 * (sum(cost) / world) + max(len(j[0]) * (2 * (j[3] + 5) + 1) for j in jobs)
+        assert sh == shard_jobs(jobs, world)
