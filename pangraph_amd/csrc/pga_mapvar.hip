@@ -313,6 +313,139 @@ void k_mapvar(const MvJob *__restrict__ jobs, int n_jobs, MvParams P, const uint
 	}
 }
 
+// ---- narrow bands: SEVERAL JOBS PER WAVE ----
+// A band of 2 * band_width + 1 <= 31 columns leaves half of the lanes of k_mapvar idle (<= 15: three quarters).  Here a wave takes 64 / SEG
+// consecutive jobs of the queue (sorted by size: neighbours are members of the same block), a segment of SEG lanes each: every row of
+// every job fits one segment (the host checks the last row too, which reaches to the end of the query), so there is no chunk loop and no
+// carry; the prefix maximum stops at the segment borders (row-local DPP steps, plus row_bcast15 for 32-lane segments); stripes, letters
+// and scores are per-lane values, the rings per segment.  The jobs of a wave share the row loop (it runs to the longest reference), the
+// traceback and the edits are then done job by job by the whole wave (mv_finish).
+template <int SEG> __device__ __forceinline__ int32_t mv_seg_prefix_max(int32_t v)
+{
+	v = dpp_max_step<0x111, 0xf>(v); v = dpp_max_step<0x112, 0xf>(v); v = dpp_max_step<0x114, 0xf>(v); v = dpp_max_step<0x118, 0xf>(v);
+	if (SEG == 32) v = dpp_max_step<0x142, 0xa>(v);                    // row_bcast15 into rows 1 and 3
+	return v;
+}
+
+template <int SEG>
+__global__ __launch_bounds__(64)
+void k_mapvar_packed(const MvJob *__restrict__ jobs, int n_jobs, MvParams P, const uint8_t *__restrict__ codes, uint32_t *job_counter,
+                     uint8_t *slabs, uint64_t slab_bytes, MvOut *__restrict__ out, MvCursors *cur, MvCaps cap,
+                     pga_sub_t *subs, pga_del_t *dels, pga_ins_t *inss, char *ins_seq)
+{
+	constexpr int NJ = 64 / SEG, RN = 64, M = RN - 1;
+	__shared__ int32_t s_ring[NJ * 3 * RN];
+	const int lane = threadIdx.x, seg = lane / SEG, sl = lane % SEG;
+	int32_t *bufS = s_ring + seg * 3 * RN, *qg = bufS + 2 * RN;
+	const int la = P.left_align ? 1 : 0;
+	for (;;) {
+		int j0 = (int)atomicAdd(job_counter, lane == 0 ? (uint32_t)NJ : 0u);          // (no lane-0 branch: see k_mapvar)
+		j0 = __builtin_amdgcn_readfirstlane(j0);
+		if (j0 >= n_jobs) break;
+		const int nj = n_jobs - j0 < NJ ? n_jobs - j0 : NJ;
+		const bool have = seg < nj;
+		const MvJob J = jobs[j0 + (have ? seg : 0)];
+		const int ref_len = (int)J.ref_len, qlen = (int)J.qry_len, ms = J.ms, bw = (int)J.bw;
+		const uint8_t *ref = codes + J.ref_off, *qry = codes + J.qry_off;
+		uint8_t *slab = slabs + ((size_t)blockIdx.x * NJ + (size_t)seg) * slab_bytes;
+		int status_l = 0;                                                               // to_nuc_seq and the length test, job by job
+		for (int s = 0; s < nj; ++s) {
+			const MvJob Js = jobs[j0 + s];
+			const uint8_t *r2 = codes + Js.ref_off, *q2 = codes + Js.qry_off;
+			bool bad = false;
+			for (int i = lane; i < (int)Js.ref_len; i += 64) bad |= r2[i] == MV_BAD;
+			for (int i = lane; i < (int)Js.qry_len; i += 64) bad |= q2[i] == MV_BAD;
+			const int st = __ballot(bad) ? 2 : ((int)Js.qry_len < P.min_length ? 1 : 0);
+			status_l = seg == s ? st : status_l;
+		}
+		const bool act = have && status_l == 0;
+		auto sbeg = [&](int i) -> int { if (i == 0) return 0; const int v = i - ms - bw; return v < 0 ? 0 : v > qlen ? qlen : v; };
+		auto send = [&](int i) -> int { if (i == ref_len) return qlen + 1; const int v = i - ms + bw + 1; return v < 1 ? 1 : v > qlen + 1 ? qlen + 1 : v; };
+		const int pitch = 2 * bw + 2 < qlen + 2 ? 2 * bw + 2 : qlen + 2;
+		for (int i = sl; i < RN; i += SEG) qg[i] = MV_NO_ALIGN;
+		{
+			const int e0 = send(0);
+			for (int q = (e0 > RN ? e0 - RN : 0) + sl; q < e0; q += SEG) bufS[q & M] = (q == 0 || P.left_free) ? 0 : -(P.gap_open + (q - 1) * P.ext);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		const int max_len = wave_max_i32(act ? ref_len : 0);
+		int32_t fin = 0; bool hasfin = false;
+		int pb = 0, pe = send(0), ppe = 0, b = sbeg(1), e = send(1);
+		int rnext = act ? (int)ref[0] : 0;
+		int qc_pref = 0;
+		{ const int q1 = b + sl; if (act && q1 >= 1 && q1 < e) qc_pref = qry[q1 - 1]; }
+		for (int ri = 1; ri <= max_len; ++ri) {
+			const bool rowon = act && ri <= ref_len;
+			const bool last = ri == ref_len;
+			const bool more = rowon && !last;
+			const int r = rnext;
+			rnext = more ? (int)ref[ri] : 0;
+			const bool rN = r == MV_N;
+			const int mr = rN ? 31 : r + 1;
+			const int nb = more ? sbeg(ri + 1) : 0, ne = more ? send(ri + 1) : 0;
+			const int o_r = (last && P.right_free) ? 0 : P.gap_open, x_r = (last && P.right_free) ? 0 : P.ext;
+			const int ep = x_r < o_r ? x_r : o_r;
+			const int32_t s0 = P.left_free ? 0 : -(P.gap_open + (ri - 1) * P.ext);
+			const int32_t *prevS = bufS + ((ri - 1) & 1) * RN;
+			int32_t *curS = bufS + (ri & 1) * RN;
+			const int q = b + sl;
+			const bool on = rowon && q < e;
+			const int qc = qc_pref;
+			{ const int qn = nb + sl; qc_pref = (more && qn >= 1 && qn < ne) ? (int)qry[qn - 1] : 0; }
+			const int32_t Sd = prevS[(q - 1) & M], Su = prevS[q & M], QG = qg[q & M];
+			const bool q0 = q == 0;
+			const bool inner = !last && q < qlen;
+			const bool diag_ok = q > pb && q - 1 < pe;
+			const bool up_ok = !q0 && q < pe;
+			const int mq = qc == MV_N ? 31 : qc + 1;
+			const int sc = (qc == MV_N || rN) ? P.match - 1 : ((mq & mr) ? P.match : -P.mismatch);
+			int32_t score = diag_ok ? Sd + sc : MV_NO_ALIGN;
+			int origin = diag_ok ? MV_MATCH : 0;
+			const bool fr = q == qlen && P.right_free;
+			const int32_t qe = QG - (fr ? 0 : P.ext), qo = Su - (fr ? 0 : P.gap_open);
+			const bool extq = up_ok && qe >= qo && q < ppe;
+			const int32_t tq = extq ? qe : qo;
+			int32_t Ht = (up_ok && tq > score) ? tq : score;
+			Ht = q0 ? s0 : Ht;
+			const int32_t A = on ? Ht + ep * (q - b) : INT32_MIN;
+			const int32_t Pin = mv_seg_prefix_max<SEG>(A);
+			int32_t excl = wave_shr1(Pin, INT32_MIN);
+			excl = sl == 0 ? INT32_MIN : excl;
+			const int32_t G = (q > b && sl > 0) ? excl - o_r - ep * (q - 1 - b) : 0;
+			const bool refg = q > b && score - la < G;
+			score = refg ? G : score; origin = refg ? MV_REF_GAP_MATRIX : origin;
+			const bool qryg = up_ok && score - la < tq;
+			score = qryg ? tq : score; origin = qryg ? MV_QRY_GAP_MATRIX : origin;
+			score = q0 ? s0 : score; origin = q0 ? MV_QRY_GAP_MATRIX : origin;
+			const int32_t Sl = wave_shr1(score, 0), Gl = wave_shr1(G, 0);
+			int tmp_path = q0 ? MV_QRY_GAP_EXTEND : ((inner && (!diag_ok || q <= b || !up_ok)) ? MV_BOUNDARY : 0) + (extq ? MV_QRY_GAP_EXTEND : 0);
+			tmp_path += (q > b + 1 && Gl - x_r >= Sl - o_r) ? MV_REF_GAP_EXTEND : 0;
+			if (on) {
+				slab[(size_t)(ri - 1) * (size_t)pitch + (size_t)(q - b)] = (uint8_t)(tmp_path + origin);
+				curS[q & M] = score;
+				qg[q & M] = up_ok ? tq : MV_NO_ALIGN;
+			}
+			if (on && last && q == qlen) { fin = score; hasfin = true; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			if (rowon) { ppe = pe; pb = b; pe = e; b = nb; e = ne; }
+		}
+		mv_fence();
+		const unsigned long long finmask = __ballot(hasfin);
+		for (int s = 0; s < nj; ++s) {
+			const MvJob Js = jobs[j0 + s];
+			MvOut O; memset(&O, 0, sizeof(O)); O.attempts = (int32_t)Js.attempt;
+			O.status = rl(status_l, s * SEG);
+			if (O.status == 0) {
+				const unsigned long long m = finmask & (((SEG == 32 ? 0xffffffffULL : 0xffffULL)) << (s * SEG));
+				O.score = m ? rl(fin, __ffsll((long long)m) - 1) : 0;
+				mv_finish(codes + Js.ref_off, codes + Js.qry_off, (int)Js.ref_len, (int)Js.qry_len, (long long)Js.ms, (long long)Js.bw, (int)Js.attempt,
+				          slabs + ((size_t)blockIdx.x * NJ + (size_t)s) * slab_bytes, P, lane, O, cur, cap, subs, dels, inss, ins_seq);
+			}
+			if (lane == 0) out[j0 + s] = O;
+		}
+	}
+}
+
 static inline size_t mv_slab_need(const MvJob &J)
 {
 	const long long p = std::min<long long>(2LL * J.bw + 2, (long long)J.qry_len + 2);
@@ -320,7 +453,17 @@ static inline size_t mv_slab_need(const MvJob &J)
 	return ((path + 15) & ~(size_t)15) + 4 * ((size_t)J.ref_len + J.qry_len + 4);
 }
 static inline long long mv_ring_cols(const MvJob &J) { return std::min<long long>(2LL * J.bw + 2, (long long)J.qry_len + 2); }
-static inline int mv_ring_class(const MvJob &J) { const long long w = mv_ring_cols(J); return w <= 128 ? 128 : w <= 512 ? 512 : w <= 2048 ? 2048 : 0; }
+// 16 / 32: every row of the job fits a segment of that many lanes (k_mapvar_packed); 0: one job per wave
+static inline int mv_pack_seg(const MvJob &J)
+{
+	static const bool off = getenv("PGA_MAPVAR_NO_PACK") != nullptr;
+	if (off || J.ref_len < 1 || J.bw > 15 || std::llabs((long long)J.ms) > (1LL << 28)) return 0;
+	long long lb = (long long)J.ref_len - J.ms - J.bw;
+	lb = lb < 0 ? 0 : lb > (long long)J.qry_len ? (long long)J.qry_len : lb;
+	const long long need = std::max<long long>(2LL * J.bw + 1, (long long)J.qry_len + 1 - lb);     // the widest row: a band row or the last one
+	return need <= 16 ? 16 : need <= 32 ? 32 : 0;
+}
+static inline int mv_ring_class(const MvJob &J) { const int ps = mv_pack_seg(J); if (ps) return ps; const long long w = mv_ring_cols(J); return w <= 128 ? 128 : w <= 512 ? 512 : w <= 2048 ? 2048 : 0; }
 
 void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t &prm, pga_mapvar_res_t *res,
                          std::vector<pga_sub_t> &h_subs, std::vector<pga_del_t> &h_dels, std::vector<pga_ins_t> &h_inss, std::vector<char> &h_seq)
@@ -407,19 +550,23 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 			while (s1 < pending.size() && mv_ring_class(pending[s1]) == cls && mv_slab_need(pending[s1]) * 4 >= need_max) { cols_max = std::max(cols_max, mv_ring_cols(pending[s1])); ++s1; }
 			const size_t nj = s1 - s0;
 			const size_t slab_bytes = (need_max + 255) & ~(size_t)255;
+			const int pack = cls == 16 || cls == 32 ? 64 / cls : 1;                                   // jobs per wave
 			int ring_n = 0;
 			if (cls == 0) { ring_n = 4096; while ((long long)ring_n < cols_max) ring_n <<= 1; }
-			const size_t per_slot = slab_bytes + (cls == 0 ? (size_t)ring_n * 12 : 0);
-			size_t n_slots = std::min<size_t>(nj, std::max<size_t>(1, budget / per_slot));
+			const size_t per_slot = slab_bytes * (size_t)pack + (cls == 0 ? (size_t)ring_n * 12 : 0);
+			size_t n_slots = std::min<size_t>((nj + (size_t)pack - 1) / (size_t)pack, std::max<size_t>(1, budget / per_slot));
 			n_slots = std::min<size_t>(n_slots, cls == 2048 ? 1536 : 8192);
-			keep_slabs.emplace_back(n_slots * slab_bytes);
+			keep_slabs.emplace_back(n_slots * slab_bytes * (size_t)pack);
 			keep_ctr.emplace_back(1); keep_ctr.back().zero(st);
 			int32_t *gr = nullptr;
 			if (cls == 0) { keep_rings.emplace_back(n_slots * (size_t)ring_n * 3); gr = keep_rings.back().p; }
-			if (verbose) fprintf(stderr, "[pga]   map_variations round %d: %zu jobs, ring %d, slab %.1f KB x %zu waves\n", round, nj, cls ? cls : ring_n, slab_bytes / 1024.0, n_slots);
+			if (verbose) fprintf(stderr, "[pga]   map_variations round %d: %zu jobs, %s %d, slab %.1f KB x %zu waves\n", round, nj, pack > 1 ? "segments of" : "ring", cls ? cls : ring_n, slab_bytes / 1024.0, n_slots);
 #define MV_LAUNCH(R) k_mapvar<R><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes.p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, gr, ring_n, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
-			if (cls == 128) MV_LAUNCH(128); else if (cls == 512) MV_LAUNCH(512); else if (cls == 2048) MV_LAUNCH(2048); else MV_LAUNCH(0);
+#define MV_LAUNCH_P(SG) k_mapvar_packed<SG><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes.p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
+			if (cls == 16) MV_LAUNCH_P(16); else if (cls == 32) MV_LAUNCH_P(32);
+			else if (cls == 128) MV_LAUNCH(128); else if (cls == 512) MV_LAUNCH(512); else if (cls == 2048) MV_LAUNCH(2048); else MV_LAUNCH(0);
 #undef MV_LAUNCH
+#undef MV_LAUNCH_P
 			PGA_HIP(hipGetLastError());
 			s0 = s1;
 		}

@@ -151,3 +151,25 @@ def test_sharded_jobs_give_the_same_edits(gpu_lib):
         for i, g in zip(share, mb.product_map_variations(gpu_lib.dll, [jobs[i] for i in share])):
             merged[i] = g
     assert merged == whole
+
+
+def test_several_jobs_per_wave_vs_oracle(gpu_lib, oracle_lib):
+    # narrow bands share a wave (k_mapvar_packed: segments of 16 or 32 lanes): ragged groups, references of very different length in one
+    # wave, jobs with an error between good ones, last rows at the width limit, and the same jobs one per wave (PGA_MAPVAR_NO_PACK)
+    rng = np.random.default_rng(29)
+    for extra, bws in ((0, (0, 1, 3, 7)), (5, (0, 2)), (5, (3, 6, 10)), (2, (13,))):
+        p = mb.params(extra_band_width=extra, min_length=3)
+        jobs = []
+        for it in range(61):                                                   # not a multiple of 2 or 4
+            ref = mb.random_seq(rng, int(rng.integers(1, 40)) if it % 9 == 0 else int(rng.integers(40, 2500)))
+            qry = mb.mutate(rng, ref, snp=0.03, indel=0.004, max_indel=int(rng.integers(1, 6))) or "A"
+            if it % 13 == 5:
+                qry = qry[:max(1, len(qry) // 2)] + "x" + qry[len(qry) // 2:]  # to_nuc rejects it
+            if it % 17 == 3:
+                qry = "AC"                                                      # shorter than min_length
+            if it % 11 == 7:
+                qry = qry + mb.random_seq(rng, int(rng.integers(1, 12)))       # a tail that widens the last row
+            jobs.append((ref, qry, int(rng.integers(-2, 3)), int(bws[it % len(bws)])))
+        exp = _oracle(oracle_lib.dll, jobs, p)
+        got = mb.product_map_variations(gpu_lib.dll, jobs, p)
+        _same(got, exp)
