@@ -52,10 +52,12 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 // persistent waves over the run queue of this pass
 __global__ __launch_bounds__(64)
 void k_rs_pass(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
-               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint, u128 *__restrict__ tmp_all, uint2 *__restrict__ lg_all)
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, RsHint hint, u128 *__restrict__ tmp_all, uint2 *__restrict__ lg_all, int run_min)
 {
 	__shared__ RsLds L;
 	const int lane = threadIdx.x;
+	if (lane == 0) L.run_min = run_min;
+	rs_fence_wave();
 	const uint32_t n_runs = *n_in < cap ? *n_in : cap;
 	for (;;) {
 		uint32_t r = 0;
@@ -327,6 +329,7 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	DBuf<uint2> lg;                          // the digit walk's record of moves (destination slot, source slot)
 	if (tmp2.p && !getenv("PGA_NO_DIGITWALK")) lg.alloc(n_total);
 	double pass_ms[9] = {0};
+	static const int run_min = getenv("PGA_RS_RUN_MIN") ? std::max(1, atoi(getenv("PGA_RS_RUN_MIN"))) : 64;
 	if (verbose) { pass_ms[8] = et.stop(); }
 	// (measured: the persistent waves of the dependency-driven variant hold their LDS and slots while they wait and starve the kernels of
 	// the other parts -- 7.9 -> 22 s per step; it stays behind PGA_RS_ASYNC=1)
@@ -342,7 +345,7 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	} else
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
-		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p);
+		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p, run_min);
 		if (verbose) {
 			pass_ms[pass] = ep.stop();
 			uint32_t nr = 0; PGA_HIP(hipMemcpy(&nr, ctr.p + 2 * (pass + 1), 4, hipMemcpyDeviceToHost));

@@ -31,6 +31,7 @@ struct __attribute__((aligned(16))) RsLds {
 	uint32_t hpos[256], hrem[256]; uint16_t hdig[256];   // what sits at a bucket's head (digit, remainder of its digit run), valid while head == hpos: following a cycle reads LDS only
 	uint32_t vmark[256];         // bucket -> (path stamp << 8 | stop index) of its last visit: "was this bucket a stop of the path being followed" is one read
 	unsigned long long prof[4];  // ticks (diagnostics)
+	int run_min;                 // see rs_level_wave (PGA_RS_RUN_MIN)
 };
 
 __device__ __forceinline__ u128 ld128(const u128 *p) { u128 v; v.x = p->x; v.y = p->y; return v; }
@@ -463,7 +464,8 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 		for (int k = 3; k >= 0; --k) if (nonempty[k]) { const int l = __ffsll((long long)nonempty[k]) - 1; dA = l + 64 * k; cA = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k], l); }
 		if (rs_level_two(beg, n, shift, (uint32_t)dA, cA, tmp, rend, lane)) return true;
 	}
-	if (rend && n >= 4096 && (uint64_t)n >= 64ull * n_druns) {
+	const uint64_t run_min = (lg && tmp) ? (uint64_t)L.run_min : 64ull;      // mean digit run from which the run-length walk beats the walk on digits
+	if (rend && n >= 4096 && (uint64_t)n >= run_min * n_druns) {
 		// digit runs of the original order, back to front: rend[p] = first position after p whose digit differs
 		uint32_t nb = 0, carry_end = (uint32_t)n;
 		for (int64_t c0 = (n - 1) & ~63LL; c0 >= 0; c0 -= 64) {
@@ -481,7 +483,7 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 			carry_end = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
 		}
 		rs_fence_wg();
-		if ((uint64_t)n >= 64ull * nb) {                          // digit runs of 64+ records on average: below that the token walk through the LDS windows is faster
+		if ((uint64_t)n >= run_min * nb) {                          // digit runs of 64+ records on average: below that the token walk through the LDS windows is faster
 #pragma unroll
 			for (int k = 0; k < 4; ++k) { const int b = lane + 64 * k; L.head[b] = off[k]; L.tail[b] = off[k] + cnt[k]; }
 			rs_fence_wave();
