@@ -166,3 +166,33 @@ def test_job_sharding_is_balanced_and_complete():
         cost = [sum(len(jobs[i][0]) * (2 * (jobs[i][3] + 5) + 1) for i in s) for s in sh]
         assert max(cost) <= 1.05 * (sum(cost) / world) + max(len(j[0]) * (2 * (j[3] + 5) + 1) for j in jobs)
         assert sh == shard_jobs(jobs, world)
+
+
+def _overlap_score(ref, qry, match=3, mismatch=1, gap_open=6):
+    """An independent statement of what the aligner maximises with its default switches (gap extension 0, terminal gaps free on both
+    sides of both sequences): textbook three-state dynamic programming over the FULL matrix, best cell of the last row or column."""
+    NEG = -10 ** 9
+    n, m = len(ref), len(qry)
+    H = [[0] * (m + 1) for _ in range(n + 1)]
+    E = [[NEG] * (m + 1) for _ in range(n + 1)]          # gap in the reference (query letters inserted)
+    F = [[NEG] * (m + 1) for _ in range(n + 1)]          # gap in the query (reference letters deleted)
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            a, b = ref[i - 1], qry[j - 1]
+            s = match - 1 if "N" in (a, b) else (match if a == b else -mismatch)
+            E[i][j] = max(E[i][j - 1], H[i][j - 1] - gap_open)
+            F[i][j] = max(F[i - 1][j], H[i - 1][j] - gap_open)
+            H[i][j] = max(H[i - 1][j - 1] + s, E[i][j], F[i][j])
+    return max(max(H[n]), max(row[m] for row in H))
+
+
+def test_full_band_score_is_the_optimum_of_an_independent_dp(oracle_lib):
+    # with a band that covers the whole matrix the corner score must be the optimum, whatever the tie rules did to the path
+    rng = np.random.default_rng(31)
+    for it in range(150):
+        ref = mb.random_seq(rng, int(rng.integers(1, 45)))
+        qry = (mb.mutate(rng, ref, snp=0.1, indel=0.08, max_indel=5, n_frac=0.03) if it % 3 else mb.random_seq(rng, int(rng.integers(1, 45)))) or "A"
+        r = mb.oracle_map_variations(oracle_lib.dll, ref, qry, 0, 200, mb.params(gap_align_left=it % 2))
+        assert r["status"] == 0 and r["hit_boundary"] == 0 and r["attempts"] == 1
+        assert r["score"] == _overlap_score(ref, qry), (ref, qry)
+        assert mb.apply_edit(ref, r) == qry
