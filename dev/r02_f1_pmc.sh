@@ -1,14 +1,14 @@
 #!/bin/bash
 # SURVEY 8(f)-1 kernel (k_mapvar): rocprofv3 kernel stats and counters of dev/f1_bench.py (200 blocks x 100 members x ~10 kb, band 20), one counter per pass
-# usage: dev/r02_f1_pmc.sh <tag>  -> gpurun_out/profiles_out/r02_<tag>_f1_mapvar_{kernel_stats.csv,pmc.json}
+# usage: [BAND=20] dev/r02_f1_pmc.sh <tag>  -> gpurun_out/profiles_out/r02_<tag>_f1_mapvar_{kernel_stats.csv,pmc.json}
 TAG=${1:-x}
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out/profiles_out
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/f1prof -o f1 -- python $R/dev/f1_bench.py 200 100 10000 20 > $R/gpurun_out/f1_prof.json 2>/dev/null )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/f1prof -o f1 -- python $R/dev/f1_bench.py 200 100 10000 ${BAND:-20} > $R/gpurun_out/f1_prof.json 2>/dev/null )
 f=$(find gpurun_out/f1prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/profiles_out/r02_${TAG}_f1_mapvar_kernel_stats.csv
 for c in SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/f1pmc_$c -o pmc -- python $R/dev/f1_bench.py 200 100 10000 20 > /dev/null 2> $R/gpurun_out/f1pmc_$c.err ); echo "$c rc=$?"
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/f1pmc_$c -o pmc -- python $R/dev/f1_bench.py 200 100 10000 ${BAND:-20} > /dev/null 2> $R/gpurun_out/f1pmc_$c.err ); echo "$c rc=$?"
 done
 python - <<PY
 import csv, glob, collections, json
