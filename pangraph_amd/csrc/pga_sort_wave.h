@@ -35,6 +35,10 @@ struct __attribute__((aligned(16))) RsLds {
 };
 
 __device__ __forceinline__ u128 ld128(const u128 *p) { u128 v; v.x = p->x; v.y = p->y; return v; }
+// a use the compiler cannot move: loads issued in front of it stay in front (without it a load whose value is only needed under a
+// condition is sunk into that branch with a wait of its own: four loads "in flight" become four round trips)
+__device__ __forceinline__ void rs_pin(u128 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void rs_pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ int rl32(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 __device__ __forceinline__ void rs_fence_wave() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 __device__ __forceinline__ void rs_fence_wg() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -128,7 +132,9 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 						for (int q0 = 0; q0 < Lc; q0 += 8) {
 							u128 v[8];
 #pragma unroll
-							for (int c = 0; c < 8; ++c) if (q0 + c < Lc) v[c] = ld128(&beg[L.ppos[q0 + c] + m]);
+							for (int c = 0; c < 8; ++c) v[c] = ld128(&beg[L.ppos[q0 + c < Lc ? q0 + c : Lc - 1] + m]);   // (unconditional and pinned: see rs_pin)
+#pragma unroll
+							for (int c = 0; c < 8; ++c) rs_pin(v[c]);
 #pragma unroll
 							for (int c = 0; c < 8; ++c) if (q0 + c < Lc) { beg[L.ppos[q0 + c] + m] = t; t = v[c]; }
 						}
@@ -222,7 +228,9 @@ __device__ inline void rs_walk_runs(u128 *beg, int shift, const uint32_t *rend, 
 							for (uint32_t hi = p; hi > hd; ) {
 								u128 v[4]; uint32_t q[4];
 #pragma unroll
-								for (int c = 0; c < 4; ++c) { q[c] = hi - (uint32_t)lane - 64u * c; if ((int64_t)hi - lane - 64 * c > (int64_t)hd) v[c] = ld128(&beg[q[c] - 1]); }
+								for (int c = 0; c < 4; ++c) { q[c] = hi - (uint32_t)lane - 64u * c; v[c] = ld128(&beg[(int64_t)hi - lane - 64 * c > (int64_t)hd ? q[c] - 1 : hd]); }
+#pragma unroll
+								for (int c = 0; c < 4; ++c) rs_pin(v[c]);
 #pragma unroll
 								for (int c = 0; c < 4; ++c) if ((int64_t)hi - lane - 64 * c > (int64_t)hd) beg[q[c]] = v[c];
 								hi = hi - hd > 256 ? hi - 256 : hd;
@@ -268,7 +276,7 @@ __device__ inline bool rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA
 	for (int64_t c0 = 0; c0 < n; c0 += 256) {
 		bool mis[4]; int64_t p[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { p[k] = c0 + lane + 64 * k; const bool isA = p[k] < n && (uint32_t)((beg[p[k]].x >> shift) & 255) == dA; mis[k] = p[k] < n && (p[k] < (int64_t)cA ? !isA : isA); }
+		for (int k = 0; k < 4; ++k) { p[k] = c0 + lane + 64 * k; const uint64_t x = beg[p[k] < n ? p[k] : n - 1].x; const bool isA = (uint32_t)((x >> shift) & 255) == dA; mis[k] = (p[k] < n) & (p[k] < (int64_t)cA ? !isA : isA); }   // (no short circuit in front of the load's use: the compiler would sink the load into a branch of its own)
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const unsigned long long bm = __ballot(mis[k]);
@@ -289,27 +297,39 @@ __device__ inline bool rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA
 	for (int64_t c0 = 0; c0 < n; c0 += 256) {
 		u128 v[4]; int64_t p[4]; bool isA[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { p[k] = c0 + lane + 64 * k; if (p[k] < n) v[k] = ld128(&beg[p[k]]); isA[k] = p[k] < n && (uint32_t)((v[k].x >> shift) & 255) == dA; }
+		for (int k = 0; k < 4; ++k) { p[k] = c0 + lane + 64 * k; v[k] = ld128(&beg[p[k] < n ? p[k] : n - 1]); }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { rs_pin(v[k]); isA[k] = (p[k] < n) & ((uint32_t)((v[k].x >> shift) & 255) == dA); }
+		// (ranks first, then all eight index lookups together, then the stores: a lookup under `if (misplaced)` is a round trip of its own)
+		uint32_t tq[4], uq[4], qv[4], iv[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const bool on = p[k] < n, inA = p[k] < (int64_t)cA;
-			const bool mis = on && (inA ? !isA[k] : isA[k]);
+			const bool mis = on & (inA ? !isA[k] : isA[k]);
 			const unsigned long long bm = __ballot(mis);
 			const int64_t blk = c0 + 64 * k;
 			const unsigned long long sideA = blk + 64 <= (int64_t)cA ? ~0ULL : blk >= (int64_t)cA ? 0ULL : ((1ULL << (cA - blk)) - 1);
+			tq[k] = tA + (uint32_t)__popcll(bm & sideA & lt);                   // B records of region A in front of p
+			uq[k] = tB + (uint32_t)__popcll(bm & ~sideA & lt);                  // A records of region B in front of p
+			tA += (uint32_t)__popcll(bm & sideA); tB += (uint32_t)__popcll(bm & ~sideA);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t t1 = tq[k] ? tq[k] - 1 : 0;
+			qv[k] = idx[(uint32_t)n - 1 - (t1 < (uint32_t)n ? t1 : (uint32_t)n - 1)];
+			iv[k] = idx[uq[k] < (uint32_t)n ? uq[k] : (uint32_t)n - 1];
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { rs_pin(qv[k]); rs_pin(iv[k]); }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool on = p[k] < n, inA = p[k] < (int64_t)cA;
 			if (on) {
 				uint32_t dst;
-				if (inA) {
-					if (isA[k]) dst = (uint32_t)p[k];
-					else { const uint32_t t = tA + (uint32_t)__popcll(bm & sideA & lt); dst = t == 0 ? cA : Qat(t - 1) + 1; }
-				} else {
-					const uint32_t u = tB + (uint32_t)__popcll(bm & ~sideA & lt);      // A records of region B in front of p
-					if (isA[k]) dst = idx[u];                                          // the u-th of them goes to i_u
-					else dst = u < m ? (uint32_t)p[k] + 1 : (uint32_t)p[k];
-				}
+				if (inA) dst = isA[k] ? (uint32_t)p[k] : (tq[k] == 0 ? cA : qv[k] + 1);
+				else dst = isA[k] ? iv[k] : (uq[k] < m ? (uint32_t)p[k] + 1 : (uint32_t)p[k]);   // the u-th A record of region B goes to i_u
 				tmp[dst] = v[k];
 			}
-			tA += (uint32_t)__popcll(bm & sideA); tB += (uint32_t)__popcll(bm & ~sideA);
 		}
 	}
 	rs_fence_wg();
@@ -317,7 +337,9 @@ __device__ inline bool rs_level_two(u128 *beg, int64_t n, int shift, uint32_t dA
 	for (int64_t c0 = 0; c0 < n; c0 += 256) {
 		u128 v[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const int64_t p = c0 + lane + 64 * k; if (p < n) v[k] = ld128(&tmp[p]); }
+		for (int k = 0; k < 4; ++k) { const int64_t p = c0 + lane + 64 * k; v[k] = ld128(&tmp[p < n ? p : n - 1]); }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rs_pin(v[k]);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { const int64_t p = c0 + lane + 64 * k; if (p < n) beg[p] = v[k]; }
 	}
@@ -338,7 +360,7 @@ __device__ inline void rs_level_sim(u128 *beg, int64_t n, int shift, RsLds &L, i
 	for (int64_t i0 = 0; i0 < n; i0 += 256) {
 		uint32_t dg[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; dg[k] = i < n ? (uint32_t)((beg[i].x >> shift) & 255) : 0u; }
+		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; dg[k] = (uint32_t)((beg[i < n ? i : n - 1].x >> shift) & 255); }
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; if (i < n) dig[i] = (uint8_t)dg[k]; }
 	}
@@ -408,19 +430,27 @@ __device__ inline void rs_level_sim(u128 *beg, int64_t n, int shift, RsLds &L, i
 	if (lane == 0) { L.prof[2] += 1; L.prof[3] += n_log; }
 	// the records follow: final[dst] = original[src]
 	for (uint32_t e0 = 0; e0 < n_log; e0 += 256) {
-		u128 v[4]; uint32_t e[4];
+		u128 v[4]; uint32_t e[4], src[4];
 #pragma unroll
-		for (int c = 0; c < 4; ++c) { e[c] = e0 + (uint32_t)lane + 64u * c; if (e[c] < n_log) v[c] = ld128(&beg[lg[e[c]].y]); }
+		for (int c = 0; c < 4; ++c) { e[c] = e0 + (uint32_t)lane + 64u * c; src[c] = lg[e[c] < n_log ? e[c] : n_log - 1].y; }
+#pragma unroll
+		for (int c = 0; c < 4; ++c) rs_pin(src[c]);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) v[c] = ld128(&beg[src[c]]);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) rs_pin(v[c]);
 #pragma unroll
 		for (int c = 0; c < 4; ++c) if (e[c] < n_log) tmp[e[c]] = v[c];
 	}
 	rs_fence_wg();
 	for (uint32_t e0 = 0; e0 < n_log; e0 += 256) {
-		u128 v[4]; uint32_t e[4];
+		u128 v[4]; uint32_t e[4], dst[4];
 #pragma unroll
-		for (int c = 0; c < 4; ++c) { e[c] = e0 + (uint32_t)lane + 64u * c; if (e[c] < n_log) v[c] = ld128(&tmp[e[c]]); }
+		for (int c = 0; c < 4; ++c) { e[c] = e0 + (uint32_t)lane + 64u * c; v[c] = ld128(&tmp[e[c] < n_log ? e[c] : n_log - 1]); dst[c] = lg[e[c] < n_log ? e[c] : n_log - 1].x; }
 #pragma unroll
-		for (int c = 0; c < 4; ++c) if (e[c] < n_log) beg[lg[e[c]].x] = v[c];
+		for (int c = 0; c < 4; ++c) { rs_pin(v[c]); rs_pin(dst[c]); }
+#pragma unroll
+		for (int c = 0; c < 4; ++c) if (e[c] < n_log) beg[dst[c]] = v[c];
 	}
 	rs_fence_wg();
 }
@@ -434,7 +464,7 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 	for (int64_t i0 = 0; i0 < n; i0 += 256) {                   // backward pass over the array only pay when runs are long)
 		uint32_t dg[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; dg[k] = i < n ? (uint32_t)((beg[i].x >> shift) & 255) : 256u; }
+		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; const uint32_t d = (uint32_t)((beg[i < n ? i : n - 1].x >> shift) & 255); dg[k] = i < n ? d : 256u; }
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			if (dg[k] < 256u) atomicAdd(&L.head[dg[k]], 1u);
@@ -467,20 +497,27 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 	const uint64_t run_min = (lg && tmp) ? (uint64_t)L.run_min : 64ull;      // mean digit run from which the run-length walk beats the walk on digits
 	if (rend && n >= 4096 && (uint64_t)n >= run_min * n_druns) {
 		// digit runs of the original order, back to front: rend[p] = first position after p whose digit differs
-		uint32_t nb = 0, carry_end = (uint32_t)n;
-		for (int64_t c0 = (n - 1) & ~63LL; c0 >= 0; c0 -= 64) {
-			const int64_t p = c0 + lane;
-			const uint32_t dg = p < n ? (uint32_t)((beg[p].x >> shift) & 255) : 256u;
-			const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)257, (int)dg, 0x130, 0xf, 0xf, false);   // wave_shl:1, lane 63 sees "no neighbour"
-			// digit of position c0+64 (the first of the chunk handled before this one) decides whether lane 63 ends a run
-			const bool last_of_run = p < n && (lane == 63 ? (p + 1 >= n || (uint32_t)((beg[p + 1 < n ? p + 1 : p].x >> shift) & 255) != dg) : nx != dg);
-			const unsigned long long bm = __ballot(last_of_run);
-			nb += (uint32_t)__popcll(bm);
-			const unsigned long long up = bm >> lane;                  // run ends at or after this lane
-			const uint32_t e = up ? (uint32_t)(p + (__ffsll((long long)up) - 1) + 1) : carry_end;
-			if (p < n) rend[p] = e;
-			// the run that reaches beyond this chunk's start continues into the chunk below: its end is the end of lane 0's run
-			carry_end = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
+		// (256 records per trip with their four loads in flight -- unconditional, clamped indices: a load under `p < n ?` becomes a branch with
+		// its own wait -- and the digit right above a chunk carried down instead of loaded again)
+		uint32_t nb = 0, carry_end = (uint32_t)n, next_first = 257u;
+		for (int64_t g0 = (n - 1) & ~255LL; g0 >= 0; g0 -= 256) {
+			uint32_t dg[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const int64_t p = g0 + 64 * k + lane; const uint32_t d = (uint32_t)((beg[p < n ? p : n - 1].x >> shift) & 255); dg[k] = p < n ? d : 256u; }
+#pragma unroll
+			for (int k = 3; k >= 0; --k) {
+				const int64_t p = g0 + 64 * k + lane;
+				const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)next_first, (int)dg[k], 0x130, 0xf, 0xf, false);   // wave_shl:1, lane 63 sees the record above the chunk
+				const bool last_of_run = p < n && nx != dg[k];
+				const unsigned long long bm = __ballot(last_of_run);
+				nb += (uint32_t)__popcll(bm);
+				const unsigned long long up = bm >> lane;              // run ends at or after this lane
+				const uint32_t e = up ? (uint32_t)(p + (__ffsll((long long)up) - 1) + 1) : carry_end;
+				if (p < n) rend[p] = e;
+				// the run that reaches beyond this chunk's start continues into the chunk below: its end is the end of lane 0's run
+				carry_end = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
+				next_first = (uint32_t)__builtin_amdgcn_readlane((int)dg[k], 0);
+			}
 		}
 		rs_fence_wg();
 		if ((uint64_t)n >= run_min * nb) {                          // digit runs of 64+ records on average: below that the token walk through the LDS windows is faster
@@ -560,7 +597,9 @@ __device__ inline bool rs_level_wave(u128 *beg, int64_t n, int shift, RsLds &L, 
 							for (uint32_t hi = p; hi > hd0; ) {
 								u128 v[4]; uint32_t q[4];
 #pragma unroll
-								for (int k = 0; k < 4; ++k) { q[k] = hi - (uint32_t)lane - 64u * k; if ((int64_t)hi - lane - 64 * k > (int64_t)hd0) v[k] = ld128(&beg[q[k] - 1]); }
+								for (int k = 0; k < 4; ++k) { q[k] = hi - (uint32_t)lane - 64u * k; v[k] = ld128(&beg[(int64_t)hi - lane - 64 * k > (int64_t)hd0 ? q[k] - 1 : hd0]); }
+#pragma unroll
+									for (int k = 0; k < 4; ++k) rs_pin(v[k]);
 #pragma unroll
 								for (int k = 0; k < 4; ++k) if ((int64_t)hi - lane - 64 * k > (int64_t)hd0) beg[q[k]] = v[k];
 								hi = hi - hd0 > 256 ? hi - 256 : hd0;
@@ -755,7 +794,13 @@ __device__ inline void rs_runs_wave(u128 *beg, int64_t n, int hi_shift, RsLds &L
 __device__ inline uint64_t rs_varying_bits(const u128 *beg, int64_t n, int lane)
 {
 	uint64_t o = 0, a = ~0ULL;
-	for (int64_t i = lane; i < n; i += 64) { const uint64_t x = beg[i].x; o |= x; a &= x; }
+	for (int64_t i0 = 0; i0 < n; i0 += 256) {                   // (unconditional loads, clamped: four in flight)
+		uint64_t x[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t i = i0 + lane + 64 * k; x[k] = beg[i < n ? i : n - 1].x; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { o |= x[k]; a &= x[k]; }
+	}
 	uint32_t olo = (uint32_t)o, ohi = (uint32_t)(o >> 32), alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
