@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--leaf-only", action="store_true", help="diagnosis: only the waves of height 1")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work per core (0 disables)")
+    ap.add_argument("--schedule", choices=("ready", "waves"), default=os.environ.get("PGA_BENCH_SCHEDULE", "ready"),
+                    help="ready: a find_matches call starts when the calls it depends on are done (pangraph_amd/schedule.py); waves: level-synchronous, one batch per wave")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("PGA_BENCH_SLOTS", 3)), help="batches in flight (ready-set schedule)")
+    ap.add_argument("--cap-gbp", type=float, default=float(os.environ.get("PGA_BENCH_CAP_GBP", 1.2)), help="largest batch of the ready-set schedule")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the one-off timings of the SURVEY 8(f) rows (guide tree, map_variations) reported next to the headline")
     args = ap.parse_args()
 
@@ -277,7 +281,88 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     n_threads = max(2, usable_cpus() // max(1, local_world))
 
-    def step():
+    def add_stats(agg, st):
+        if agg["stats"] is None:
+            agg["stats"] = {k: (list(v) if isinstance(v, list) else v) for k, v in st.items()}
+        else:
+            for k, v in st.items():
+                if isinstance(v, list):
+                    agg["stats"][k] = [a + b for a, b in zip(agg["stats"][k], v)]
+                else:
+                    agg["stats"][k] += v
+
+    # ---- ready-set schedule: the find_matches calls of the build with their true dependencies -------------------------------
+    import threading
+    from pangraph_amd import schedule as sched
+    tasks = sched.build_tasks(pop) if not args.leaf_only else [t for t in sched.build_tasks(pop) if pop.nodes[t.node].height == 1]
+    if args.leaf_only:
+        for i, t in enumerate(tasks):
+            t.deps = [] if t.round == 0 else [i - 1]
+            t.tid = i
+        sched.finish(tasks)
+    owner, _ = sched.partition_subtrees(pop, tasks, world) if world > 1 and not args.leaf_only else ([0] * len(tasks), None)
+    for t in tasks:
+        if owner[t.tid] in (rank, -1) or world == 1:
+            t.prepare()
+    slot_threads = max(2, n_threads // max(1, min(args.slots, 2)))
+
+    def step_ready():
+        from pangraph_amd.dist import MATCH_DTYPE, gather_blobs
+        agg = {"create_s": 0.0, "align_s": 0.0, "gather_s": 0.0, "n_matches": 0, "stats": None, "per_wave": [], "batches": []}
+        lock = threading.Lock()
+        recs, pools, pool_len = [], [], [0]
+
+        def run_batch(ts):
+            tb = sched.TaskBatch(ts)
+            t0 = time.perf_counter()
+            rb = batch.ResidentBatch(tb)                          # hand-over: inside the timed region
+            t1 = time.perf_counter()
+            res = rb.align(sensitivity=10, want_raw=world > 1, n_threads=slot_threads)
+            t2 = time.perf_counter()
+            rb.close()
+            return res, t1 - t0, t2 - t1
+
+        def on_result(ts, out, ta, tb_):
+            res, c, a = out
+            with lock:
+                agg["create_s"] += c; agg["align_s"] += a
+                st = res.stats
+                agg["n_matches"] += int(st["n_matches"])
+                add_stats(agg, st)
+                agg["batches"].append((ta, tb_, len(ts), sum(t.bases for t in ts), int(st["n_matches"])))
+                if world > 1:                                      # records keep the GLOBAL task id as their group
+                    m = np.array(res.raw_matches, copy=True).view(MATCH_DTYPE)
+                    cg = np.array(res.raw_cigars, copy=True).view(np.uint32)
+                    if len(m):
+                        m["group"] = np.asarray([t.tid for t in ts], dtype=np.int32)[m["group"]]
+                        m["cigar_off"] += np.uint64(pool_len[0])
+                    recs.append(m); pools.append(cg); pool_len[0] += len(cg)
+            res.close()
+
+        if world == 1:
+            sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, on_result=on_result)
+            return agg
+        # phase 1: this rank's subtrees, no communication; one gather; phase 2: the merges above the cut on rank 0
+        mine_ids = {t.tid for t in tasks if owner[t.tid] == rank}
+        if mine_ids:
+            sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=mine_ids, on_result=on_result)
+        t0 = time.perf_counter()
+        m = np.concatenate(recs) if recs else np.zeros(0, MATCH_DTYPE)
+        cg = np.concatenate(pools) if pools else np.zeros(0, np.uint32)
+        pm = gather_blobs(m.view(np.uint8), cdev, dst=0, as_bytes=False)
+        pc = gather_blobs(cg.view(np.uint8), cdev, dst=0, as_bytes=False)
+        agg["gather_s"] += time.perf_counter() - t0
+        if rank == 0:
+            n_gathered = sum(t.numel() for t in pm) // MATCH_DTYPE.itemsize
+            top = {t.tid for t in tasks if owner[t.tid] == -1}
+            n_before = agg["n_matches"]
+            if top:
+                sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=top,
+                                    done={t.tid for t in tasks if owner[t.tid] != -1}, on_result=on_result)
+            agg["n_matches"] = n_gathered + (agg["n_matches"] - n_before)
+        return agg
+
+    def step_waves():
         agg = {"create_s": 0.0, "align_s": 0.0, "gather_s": 0.0, "n_matches": 0, "stats": None, "per_wave": []}
         for w, pb in enumerate(mine):
             t0 = time.perf_counter()
@@ -302,16 +387,11 @@ def main():
                 if world == 1:
                     agg["n_matches"] += int(st["n_matches"])
                 agg["per_wave"].append((waves[w][0], pb.total_bases, t1 - t0, t2 - t1, st["n_matches"]))
-                if agg["stats"] is None:
-                    agg["stats"] = {k: (list(v) if isinstance(v, list) else v) for k, v in st.items()}
-                else:
-                    for k, v in st.items():
-                        if isinstance(v, list):
-                            agg["stats"][k] = [a + b for a, b in zip(agg["stats"][k], v)]
-                        else:
-                            agg["stats"][k] += v
+                add_stats(agg, st)
                 res.close()
         return agg
+
+    step = step_ready if args.schedule == "ready" else step_waves
 
     for _ in range(args.warmup):
         step()
@@ -368,10 +448,15 @@ def main():
                                f"(tree heights 1..{len(waves) // 2} x self-merge rounds 0,1), {sum(len(g) for _, g, _ in waves)} find_matches calls, "
                                f"U = {units / 1e9:.2f} Gbp per step (asm10, -c -X -s 90)" + (" [LEAF LEVEL ONLY]" if args.leaf_only else ""),
                    "genomes": args.genomes, "genome_length": args.length, "seed": args.seed, "waves": len(waves),
-                   "timed_region": "per wave: pga_batch_create (H2D + encoding) + pga_batch_align + match-list gather",
-                   "parallelism": f"groups of every wave sharded over {world} rank(s) by base count, match-list gather to rank 0 per wave"},
-        "resident_gbp_s": units / max(last["align_s"], 1e-9) / 1e9 if world == 1 else None,
-        "rank0_seconds_per_step": {"hand_over": last["create_s"], "align": last["align_s"], "gather": last["gather_s"]},
+                   "timed_region": "per batch: pga_batch_create (H2D + encoding) + pga_batch_align; + match-list gather",
+                   "schedule": (f"ready set: every find_matches call starts when the calls it depends on are done (children's last round, own previous round); "
+                                f"{args.slots} batches in flight, <= {args.cap_gbp} Gbp each" if args.schedule == "ready" else "level-synchronous waves, one batch per wave"),
+                   "parallelism": (f"guide tree cut into subtrees dealt to {world} rank(s) by base count, no data-path collective, one match-list gather to rank 0, "
+                                   f"merges above the cut on rank 0" if args.schedule == "ready" else
+                                   f"groups of every wave sharded over {world} rank(s) by base count, match-list gather to rank 0 per wave")},
+        "resident_gbp_s": units / max(last["align_s"], 1e-9) / 1e9 if world == 1 and args.schedule == "waves" else None,
+        "rank0_seconds_per_step": {"hand_over": last["create_s"], "align": last["align_s"], "gather": last["gather_s"],
+                                   "note": "summed over the batches in flight at the same time (ready-set schedule): not a decomposition of ms_per_step"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(kname), "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run)",
                      "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
@@ -386,6 +471,7 @@ def main():
         "n_matches_gathered": last["n_matches"],
         "aligned_span_gbp_s_rank0": st["aligned_span"] * args.steps / dt / 1e9,      # secondary: sum of (qe - qs) of rank 0's matches per second
         "waves_rank0": [{"wave": w, "Mbp": b / 1e6, "hand_over_s": round(c, 4), "align_s": round(a, 4), "matches": int(m)} for w, b, c, a, m in last["per_wave"]],
+        "batches_rank0": [{"t0": round(a, 4), "t1": round(b, 4), "calls": n, "Mbp": round(bs / 1e6, 1), "matches": m} for a, b, n, bs, m in sorted(last.get("batches", []))],
         "workload_generation_s": t_gen,
     }
     if rank == 0:

@@ -49,8 +49,11 @@ typedef struct {                 /* stage wall times (s) and work counters of a 
 	 * [0] k_sketch_tiles  [1] k_chain_fast (+k_chain_segments)  [2] k_bt_list + k_bt_walk  [3] k_extd2_fast (register tiles)
 	 * [4] k_extd2_wide<256>  [5] k_ll_i16  [6] k_rs_init + k_rs_pass + k_rs_small (sort replay)  [7] k_gapfill_band (corridor gap fills)
 	 * [8] k_extd2_wide<512>  [9] k_extd2_wide<1024>  [10] index build (device sorts + CSR kernels)  [11] seeding kernels + anchor sort
-	 * [12] k_approx_strips (large unbanded gap fills over several workgroups)  [13..15] unused.
-	 * kern_cells: DP cells evaluated by the DP kernels ([3] [4] [5] [7] [8] [9] [12]), 0 elsewhere */
+	 * [12] k_approx_strips (large unbanded gap fills over several workgroups)  [13] k_extd2_lanes (banded problems, rows in registers)
+	 * [14..15] unused.  kern_cells: DP cells evaluated by the DP kernels ([3] [4] [5] [7] [8] [9] [12] [13]), 0 elsewhere.
+	 * The struct is read through pga_result_stats() only and is sized by PGA_STATS_VERSION: version 2 (round 2) grew the arrays from 10 to
+	 * 16 entries and added kern_cells -- a consumer compiled against version 1 must be rebuilt. */
+#define PGA_STATS_VERSION 2
 	double kern_ms[16], kern_launches[16], kern_alg_bytes[16], kern_cells[16];
 	double aligned_span;         /* sum of (qry_end - qry_start) over the emitted matches (secondary metric) */
 } pga_stats_t;
@@ -110,6 +113,9 @@ int pga_result_filter(const pga_result_t *res, const pga_filter_params_t *fp, pg
  * order, join t (0-based) creates node n + t with children merges[2t] and merges[2t+1] (first the node that stood earlier in the
  * reference's node list); the last join is the root.  pga_guide_tree does both without moving the matrix through the host
  * (dist may be NULL).  A sequence without any minimizer is an error, as in the reference (it panics, mash_distance.rs:19-20).
+ * No limit on n other than the n x n matrix in device memory (up to 2048 sequences the joining state lives in LDS, above that in
+ * device memory).  pga_guide_tree_nj requires a SYMMETRIC matrix (what mash_distance produces) and returns -1 otherwise: the
+ * reference's Q uses row sums and column sums, which the kernel takes from one pass.
  * Returns 0, or -1 with the message in pga_last_error(). */
 int pga_mash_distance(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist);
 int pga_guide_tree_nj(int32_t n, const double *dist, int32_t *merges);
@@ -126,7 +132,8 @@ int pga_stage_mash_sketch(int32_t n, const char *const *seqs, const uint32_t *le
  * One job per member sequence; ref and qry are upper-case IUPAC letters (not NUL-terminated); jobs that share a consensus should
  * pass the same pointer (it is uploaded once).  The caller keeps Edit::apply, reverse_complement and BandParameters::from_edits
  * (reweave.rs:53-75).  Per job: status 0, or the reference's error -- 1 the query is shorter than min_length (align.rs:42-46),
- * 2 a letter to_nuc rejects (alphabet/nuc.rs:99-121), 3 the traceback left the band (the reference panics).  Substitutions in
+ * 2 a letter to_nuc rejects (alphabet/nuc.rs:99-121) or a literal '-' in ref / qry (to_nuc accepts it, the edit extraction of the reference would
+ * read it as an alignment gap; block sequences never contain one, so it is rejected instead of reproduced), 3 the traceback left the band (the reference panics).  Substitutions in
  * reference order, deletions as the reference pushes them (internal ones ascending, then the leading, then the trailing one),
  * insertions ascending with pangraph's position convention (map_variations.rs:71-74).  The four arrays are freed with pga_free().
  * Returns 0, or -1 with the message in pga_last_error(). */
@@ -147,6 +154,7 @@ typedef struct {
 int pga_map_variations(int64_t n_jobs, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t *params, pga_mapvar_res_t *res,
                        pga_sub_t **subs, pga_del_t **dels, pga_ins_t **inss, char **ins_seq);
 void pga_free(void *p);
+int pga_stats_version(void);     /* == PGA_STATS_VERSION of the header the library was built with */
 #ifdef __cplusplus
 }
 #endif

@@ -90,7 +90,8 @@ struct PgaIdx {
 	std::map<std::string, int> by_name;
 	std::mutex mtx;
 	bool have_results = false, indexed = false; mm_mapopt_t res_opt;
-	std::string failure;             // first error of the batch behind this index: sticky, the batch is attempted once
+	std::string failure;             // first error of the batch behind this index: sticky for the options it happened with (failure_opt)
+	mm_mapopt_t failure_opt;
 	std::vector<std::vector<Reg>> results;
 	Timers tm;
 	hipStream_t st = 0;              // the part's own (non-blocking) stream
@@ -322,10 +323,21 @@ extern "C" mm_reg1_t *mm_map(const mm_idx_t *mi, int l_seq, const char *seq, int
 		const int qid = it->second;
 		if (!seqs_same_bases(ix->S, qid, seq, l_seq)) throw std::runtime_error("pga: mm_map() query bases differ from the indexed sequence of the same name");
 		std::lock_guard<std::mutex> lk(ix->mtx);
-		if (!ix->failure.empty()) return mm_map_fail(ix, ix->failure, n_regs);
+		// a failure sticks to the OPTIONS it happened with (the N rayon callers of one find_matches do not re-run a failing batch N times);
+		// a call with other options gets a fresh attempt
+		if (!ix->failure.empty() && same_opt(ix->failure_opt, *opt)) return mm_map_fail(ix, ix->failure, n_regs);
+		ix->failure.clear();
 		if (!ix->have_results || !same_opt(ix->res_opt, *opt)) {
-			try { run_batch(*ix, *opt, 0); }
-			catch (std::exception &e) { ix->failure = e.what(); if (ix->failure.empty()) ix->failure = "unknown error"; return mm_map_fail(ix, ix->failure, n_regs); }
+			for (int attempt = 0; ; ++attempt) {
+				try { run_batch(*ix, *opt, 0); break; }
+				catch (std::exception &e) {
+					std::string msg = e.what(); if (msg.empty()) msg = "unknown error";
+					// device out of memory is not a property of the batch: give the allocator's idle blocks back and try once more
+					if (attempt == 0 && (msg.find("out of memory") != std::string::npos || msg.find("hipErrorOutOfMemory") != std::string::npos)) { dev_trim(); continue; }
+					ix->failure = msg; ix->failure_opt = *opt;
+					return mm_map_fail(ix, ix->failure, n_regs);
+				}
+			}
 		}
 		return regs_to_c(ix->results[qid], n_regs);
 	} catch (std::exception &e) { return mm_map_fail(ix, e.what(), n_regs); }
@@ -534,6 +546,7 @@ extern "C" const char *pga_last_error(void) { return g_err.c_str(); }
 extern "C" int pga_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int pga_set_device(int dev) { if (hipSetDevice(dev) != hipSuccess) { set_err("hipSetDevice failed"); return -1; } return 0; }
 extern "C" void pga_free(void *p) { free(p); }
+extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
 
 // ---------------------------------------------------------------- stage taps (parity tests)
 template <class T> static T *dup_out(const std::vector<T> &v) { T *p = (T*)malloc((v.size() ? v.size() : 1) * sizeof(T)); if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T)); return p; }

@@ -46,7 +46,9 @@ struct MvOut { int32_t status, score, attempts, hit; uint32_t n_subs, n_dels, n_
 struct MvCursors { unsigned long long subs, dels, inss, ib; };
 struct MvCaps { unsigned long long subs, dels, inss, ib; };
 
-// nuc.rs:10-30 / :99-121: the sixteen letters in enum order; anything else is an error of the job
+// nuc.rs:10-30 / :99-121: the sixteen letters in enum order; anything else is an error of the job.  The gap letter '-' is REJECTED too
+// (status 2): to_nuc accepts it, but find_nuc_changes / insertions_strip then read a literal '-' of the input as an alignment gap
+// (is_gap()), which the run-based edit extraction here does not reproduce -- and pangraph's block sequences never hold one.
 __global__ void k_mv_encode(const char *__restrict__ ascii, uint64_t n, uint8_t *__restrict__ codes)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -55,7 +57,7 @@ __global__ void k_mv_encode(const char *__restrict__ ascii, uint64_t n, uint8_t 
 		case 'T': c = 0; break; case 'A': c = 1; break; case 'W': c = 2; break; case 'C': c = 3; break;
 		case 'Y': c = 4; break; case 'M': c = 5; break; case 'H': c = 6; break; case 'G': c = 7; break;
 		case 'K': c = 8; break; case 'R': c = 9; break; case 'D': c = 10; break; case 'S': c = 11; break;
-		case 'B': c = 12; break; case 'V': c = 13; break; case 'N': c = 14; break; case '-': c = 15; break;
+		case 'B': c = 12; break; case 'V': c = 13; break; case 'N': c = 14; break;
 		default: c = MV_BAD;
 		}
 		codes[i] = c;

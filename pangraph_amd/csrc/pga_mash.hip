@@ -19,6 +19,7 @@
 //                    The f64 sums follow ndarray 0.16.1's orders (see oracle/pgo_mash.c): a row's eight-accumulator unrolled sum
 //                    and its left-to-right sum come out of one pass over the row; argmin = first minimum in row-major order.
 #include "pga_common.h"
+#include <type_traits>
 #include <rocprim/rocprim.hpp>
 #include <stdexcept>
 #include <string>
@@ -306,15 +307,24 @@ static void mash_distance_dev(const SeqSet &S, int k, int w, DBuf<double> &D, hi
 // ---- neighbor joining: one workgroup, the matrix in place ----
 #define NJ_NT 1024
 #define NJ_MAX 2048
+// BIG = false: n <= NJ_MAX, the per-index state lives in LDS.  BIG = true: any n -- the same loop with that state in device memory
+// (`scratch`: n words of alive, n of node, 2n doubles), still one workgroup: the joins are sequential and a join of n > 2048 rows has
+// enough work per step (n*n Q entries) for 1024 threads; the reference (tree/neighbor_joining.rs:16-103) has no limit, so neither has this.
+template <bool BIG>
 __global__ __launch_bounds__(NJ_NT)
-void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__restrict__ status)
+void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__restrict__ status, unsigned char *__restrict__ scratch)
 {
-	__shared__ uint16_t alive[NJ_MAX];        // physical index of logical row/column
-	__shared__ int32_t node[NJ_MAX];          // tree node of logical index
-	__shared__ double s0[NJ_MAX], s1[NJ_MAX]; // per logical index: left-to-right sum (= the column sum of the symmetric matrix) and unrolled sum of its row
+	using alive_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
+	__shared__ uint16_t alive_s[BIG ? 1 : NJ_MAX];        // physical index of logical row/column
+	__shared__ int32_t node_s[BIG ? 1 : NJ_MAX];          // tree node of logical index
+	__shared__ double s0_s[BIG ? 1 : NJ_MAX], s1_s[BIG ? 1 : NJ_MAX]; // per logical index: left-to-right sum (= the column sum of the symmetric matrix) and unrolled sum of its row
 	__shared__ double rq[NJ_NT]; __shared__ unsigned long long ri[NJ_NT];
+	double *s0 = BIG ? reinterpret_cast<double*>(scratch) : s0_s;
+	double *s1 = BIG ? reinterpret_cast<double*>(scratch) + n : s1_s;
+	int32_t *node = BIG ? reinterpret_cast<int32_t*>(scratch + (size_t)16 * n) : node_s;
+	alive_t *alive = BIG ? reinterpret_cast<alive_t*>(scratch + (size_t)20 * n) : reinterpret_cast<alive_t*>(alive_s);
 	const int tid = threadIdx.x;
-	for (int i = tid; i < n; i += NJ_NT) alive[i] = (uint16_t)i, node[i] = i;
+	for (int i = tid; i < n; i += NJ_NT) alive[i] = (alive_t)i, node[i] = i;
 	__syncthreads();
 	int m = n, t = 0;
 	while (m > 2) {
@@ -377,7 +387,7 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 		if (tid == 0) { D[(size_t)pi * n + pi] = 0.0; merges[2 * t] = node[i]; merges[2 * t + 1] = node[j]; node[i] = n + t; }
 		__syncthreads();
 		// remove logical index j
-		uint16_t av = 0; int32_t nv = 0;
+		alive_t av = 0; int32_t nv = 0;
 		for (int base = j; base < m - 1; base += NJ_NT) {
 			const int c = base + tid;
 			if (c < m - 1) { av = alive[c + 1]; nv = node[c + 1]; }
@@ -386,7 +396,8 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 			__syncthreads();
 		}
 		--m; ++t;
-		__threadfence_block();
+		if (BIG) __threadfence();
+		else __threadfence_block();
 		__syncthreads();
 	}
 	if (tid == 0) { merges[2 * t] = node[0]; merges[2 * t + 1] = node[1]; *status = 0; }
@@ -396,10 +407,13 @@ static void nj_dev(int n, double *d_D, std::vector<int32_t> &merges, hipStream_t
 {
 	merges.assign((size_t)std::max(0, n - 1) * 2, 0);
 	if (n < 2) return;
-	if (n > NJ_MAX) throw std::runtime_error("pga: neighbor joining over more than 2048 sequences is not supported");
 	DBuf<int32_t> d_m((size_t)(n - 1) * 2); DBuf<int> d_s(1);
 	{ const int one = 1; PGA_HIP(hipMemcpyAsync(d_s.p, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
-	hipLaunchKernelGGL(k_nj, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p);
+	DBuf<unsigned char> scratch;
+	if (n > NJ_MAX) {
+		scratch.alloc((size_t)24 * n + 64);
+		hipLaunchKernelGGL(k_nj<true>, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p, scratch.p);
+	} else hipLaunchKernelGGL(k_nj<false>, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p, (unsigned char*)nullptr);
 	PGA_HIP(hipGetLastError());
 	if (d_s.download(st)[0] != 0) throw std::runtime_error("pga: neighbor joining found no pair to join (the distance matrix holds NaN or infinity)");
 	merges = d_m.download(st);
@@ -438,6 +452,11 @@ void mash_distance_host(int n, const char *const *seqs, const uint32_t *lens, in
 void nj_host(int n, const double *dist, int32_t *merges)
 {
 	if (n < 2) return;
+	// k_nj takes ndarray's sum_axis(Axis(0)) (column sums) from the row pass, which is the same number only for a symmetric matrix --
+	// what mash_distance produces (mash_distance.rs:56-63 fills both halves).  A caller's own matrix is checked instead of trusted.
+	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j)
+		if (!(dist[(size_t)i * n + j] == dist[(size_t)j * n + i]))
+			throw std::runtime_error("pga_guide_tree_nj: the distance matrix is not symmetric at (" + std::to_string(i) + ", " + std::to_string(j) + ")");
 	DBuf<double> D; D.upload(dist, (size_t)n * n, 0);
 	std::vector<int32_t> m; nj_dev(n, D.p, m, 0);
 	memcpy(merges, m.data(), m.size() * sizeof(int32_t));

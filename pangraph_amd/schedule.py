@@ -1,0 +1,270 @@
+"""Ready-set scheduling of a whole build over the native batch entry (include/pga_align.h).
+
+The reference walks the guide tree in post-order, one merge after the other (packages/pangraph/src/commands/build/build_run.rs:111-128);
+every merge runs the self-merge loop, i.e. `find_matches` on the joined child graphs (round 0), again on the merged graph (round 1), until
+nothing matches (packages/pangraph/src/pangraph/graph_merging.rs:26-69,95-128).  The only true dependencies are
+
+    (v, round 0)  needs the final round of both children of v        (leaves need nothing)
+    (v, round r)  needs (v, round r - 1)
+
+A level-synchronous host (the WAVES of pangraph_amd/levels.py) adds 42 barriers to that: every wave waits for its slowest whole-genome
+query while most of the device idles.  Here a `find_matches` call (a TASK: one group of the batch entry) becomes ready the moment its
+dependencies are done; up to `slots` batches are in flight at a time, each made of the ready tasks of that moment (largest remaining
+path to the root first, at most `cap` bases per batch so that a large ready set is spread over the slots instead of queueing behind
+one call).  The batches are ordinary pga_batch_create / pga_batch_align calls from different host threads: the library gives every call
+its own stream and device-memory arena.  Results do not depend on how tasks are batched (groups are independent problems).
+
+Multi-GPU (`world` > 1): the tree is cut into subtrees (`partition_subtrees`), every rank builds its subtrees with its own ready-set
+scheduler and no communication, the match lists are gathered once, and the merges above the cut run on rank 0 (they need the graphs of
+subtrees that live on different ranks).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class Task:
+    tid: int
+    node: int                  # guide-tree node whose merge this call belongs to
+    round: int                 # self-merge round
+    seqs: list                 # 1-D uint8 arrays (views)
+    names: List[str]
+    deps: List[int]
+    prio: float = 0.0          # estimated cost of the dependency chain from this task to the root (larger = earlier)
+    bases: int = 0
+    users: List[int] = field(default_factory=list)
+    # flat C views, filled by prepare()
+    ptr: Optional[np.ndarray] = None
+    lens: Optional[np.ndarray] = None
+    nptr: Optional[np.ndarray] = None
+    _keep: Optional[list] = None
+
+    def prepare(self):
+        if self.ptr is not None:
+            return
+        for a in self.seqs:
+            if a.dtype.itemsize != 1 or a.ndim != 1 or (len(a) and a.strides[0] != 1):
+                raise ValueError("sequence arrays must be contiguous 1-D uint8")
+        nb = [n.encode() for n in self.names]
+        self._keep = nb
+        self.ptr = np.fromiter((a.ctypes.data for a in self.seqs), dtype=np.uint64, count=len(self.seqs))
+        self.lens = np.fromiter((len(a) for a in self.seqs), dtype=np.uint32, count=len(self.seqs))
+        self.nptr = np.fromiter((C.cast(C.c_char_p(b), C.c_void_p).value for b in nb), dtype=np.uint64, count=len(nb))
+
+
+def cost_estimate(bases: int, n_seqs: int) -> float:
+    """seconds a task takes alone on the device (rough: a whole-genome pair is bound by its dependency chains, a block set by throughput)"""
+    big = bases / max(1, n_seqs)
+    return 0.02 + bases * 2.5e-10 + (0.25 if big > 1e6 else 0.0)
+
+
+def build_tasks(pop, min_block: int = 100, rounds: int = 2) -> List[Task]:
+    """the find_matches calls of a simulated build (pangraph_amd.levels.Population) with their dependencies"""
+    blocks = pop.clade_blocks(min_block)
+    tasks: List[Task] = []
+    last: Dict[int, int] = {}            # node -> tid of its final round
+    for nd in reversed(pop.nodes):       # children have larger ids than their parent
+        if not nd.children:
+            continue
+        c1, c2 = nd.children
+        deps = [last[c] for c in (c1, c2) if c in last]
+        t0 = Task(len(tasks), nd.id, 0, blocks[c1][0] + blocks[c2][0], blocks[c1][1] + blocks[c2][1], deps)
+        tasks.append(t0)
+        prev = t0
+        for r in range(1, rounds):
+            t = Task(len(tasks), nd.id, r, blocks[nd.id][0], blocks[nd.id][1], [prev.tid])
+            tasks.append(t)
+            prev = t
+        last[nd.id] = prev.tid
+    finish(tasks)
+    return tasks
+
+
+def finish(tasks: List[Task]) -> None:
+    """users, base counts and priorities (longest remaining path, by estimated cost)"""
+    for t in tasks:
+        t.users = []
+        t.bases = int(sum(len(a) for a in t.seqs))
+    for t in tasks:
+        for d in t.deps:
+            tasks[d].users.append(t.tid)
+    order = topo_order(tasks)
+    for tid in reversed(order):
+        t = tasks[tid]
+        t.prio = cost_estimate(t.bases, len(t.seqs)) + max((tasks[u].prio for u in t.users), default=0.0)
+
+
+def topo_order(tasks: List[Task]) -> List[int]:
+    indeg = [len(t.deps) for t in tasks]
+    ready = [t.tid for t in tasks if not t.deps]
+    out = []
+    while ready:
+        x = ready.pop()
+        out.append(x)
+        for u in tasks[x].users:
+            indeg[u] -= 1
+            if indeg[u] == 0:
+                ready.append(u)
+    if len(out) != len(tasks):
+        raise ValueError("dependency cycle")
+    return out
+
+
+class TaskBatch:
+    """The flat C arrays pga_batch_create wants, for a list of tasks (one group per task); no copy of the bases."""
+
+    def __init__(self, tasks: Sequence[Task]):
+        for t in tasks:
+            t.prepare()
+        self.tasks = list(tasks)
+        self.n_groups = len(tasks)
+        self._ptr = np.concatenate([t.ptr for t in tasks]) if tasks else np.zeros(0, np.uint64)
+        self._lens = np.concatenate([t.lens for t in tasks]) if tasks else np.zeros(0, np.uint32)
+        self._nptr = np.concatenate([t.nptr for t in tasks]) if tasks else np.zeros(0, np.uint64)
+        self._off = np.zeros(self.n_groups + 1, dtype=np.int64)
+        self._off[1:] = np.cumsum([len(t.seqs) for t in tasks])
+        self.seqs = self._ptr.ctypes.data_as(C.POINTER(C.c_char_p))
+        self.cnames = self._nptr.ctypes.data_as(C.POINTER(C.c_char_p))
+        self.lens = self._lens.ctypes.data_as(C.POINTER(C.c_uint32))
+        self.off = self._off.ctypes.data_as(C.POINTER(C.c_int64))
+        self.total_bases = int(sum(t.bases for t in tasks))
+
+    @property
+    def names(self):
+        return [n for t in self.tasks for n in t.names]
+
+
+def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], slots: int = 3, cap_bases: float = 1.2e9,
+                  min_batch_bases: float = 0.0, done: Optional[set] = None, only: Optional[set] = None,
+                  on_result: Optional[Callable[[List[Task], object, float, float], None]] = None):
+    """Runs `tasks` (all of them, or the subset `only`) in dependency order; `run_batch(list of tasks)` is called from up to `slots` host
+    threads.  `done`: tids that count as finished from the start (results that arrived from elsewhere).  Returns the batch log
+    [(t_start, t_end, n_tasks, bases)] relative to the start."""
+    want = set(range(len(tasks))) if only is None else set(only)
+    fin = set(done or ())
+    indeg = {}
+    for tid in want:
+        indeg[tid] = sum(1 for d in tasks[tid].deps if d not in fin)
+        for d in tasks[tid].deps:
+            if d not in fin and d not in want:
+                raise ValueError(f"task {tid} depends on {d}, which is neither done nor scheduled")
+    ready = [tid for tid in want if indeg[tid] == 0]
+    left = len(want)
+    in_flight = 0
+    cv = threading.Condition()
+    log, errs = [], []
+    t_origin = time.perf_counter()
+
+    def take():
+        nonlocal in_flight
+        # largest remaining path first; stop at the cap (one oversized task still goes alone)
+        ready.sort(key=lambda tid: -tasks[tid].prio)
+        total = sum(tasks[tid].bases for tid in ready)
+        free = max(1, slots - in_flight)
+        cap = max(min(cap_bases, total / free if free > 1 else cap_bases), min_batch_bases, 1.0)
+        got, b = [], 0
+        rest = []
+        for tid in ready:
+            if not got or b + tasks[tid].bases <= cap:
+                got.append(tid); b += tasks[tid].bases
+            else:
+                rest.append(tid)
+        ready[:] = rest
+        in_flight += 1
+        return got
+
+    def worker():
+        nonlocal left, in_flight
+        while True:
+            with cv:
+                while not ready and left > 0 and not errs:
+                    cv.wait()
+                if left <= 0 or errs:
+                    return
+                ids = take()
+            t0 = time.perf_counter()
+            try:
+                res = run_batch([tasks[i] for i in ids])
+                t1 = time.perf_counter()
+                if on_result is not None:
+                    on_result([tasks[i] for i in ids], res, t0 - t_origin, t1 - t_origin)
+            except BaseException as e:   # noqa: BLE001
+                with cv:
+                    errs.append(e)
+                    in_flight -= 1
+                    cv.notify_all()
+                return
+            with cv:
+                log.append((t0 - t_origin, t1 - t_origin, len(ids), sum(tasks[i].bases for i in ids)))
+                in_flight -= 1
+                for i in ids:
+                    fin.add(i)
+                    left -= 1
+                    for u in tasks[i].users:
+                        if u in indeg:
+                            indeg[u] -= 1
+                            if indeg[u] == 0:
+                                ready.append(u)
+                cv.notify_all()
+
+    th = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, slots))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return sorted(log)
+
+
+# ---- multi-GPU: subtrees -------------------------------------------------------------------------------------------------------------
+def partition_subtrees(pop, tasks: List[Task], world: int, per_rank: int = 4):
+    """Cuts the guide tree into at least world * per_rank subtrees (splitting the heaviest one at its root until there are enough), deals
+    them to the ranks heaviest first (LPT on base counts) and returns (owner per task: rank, or -1 for the merges above the cut that run on
+    rank 0 after the gather; list of subtree roots per rank).  Deterministic: every rank computes the same plan without talking."""
+    if world <= 1:
+        return [0] * len(tasks), [[0]]
+    node_tasks: Dict[int, List[int]] = {}
+    for t in tasks:
+        node_tasks.setdefault(t.node, []).append(t.tid)
+    weight: Dict[int, float] = {}
+    for nd in reversed(pop.nodes):
+        w = sum(tasks[i].bases for i in node_tasks.get(nd.id, []))
+        for c in nd.children:
+            w += weight[c]
+        weight[nd.id] = w
+    roots = [0]
+    top = set()                                   # internal nodes above the cut
+    while len(roots) < world * per_rank:
+        cand = [r for r in roots if pop.nodes[r].children]
+        if not cand:
+            break
+        r = max(cand, key=lambda x: (weight[x], -x))
+        roots.remove(r)
+        top.add(r)
+        roots += list(pop.nodes[r].children)
+    roots = [r for r in roots if pop.nodes[r].children]     # a bare leaf holds no merge
+    order = sorted(roots, key=lambda r: (-weight[r], r))
+    load = [0.0] * world
+    per = [[] for _ in range(world)]
+    for r in order:
+        k = min(range(world), key=lambda i: (load[i], i))
+        per[k].append(r)
+        load[k] += weight[r]
+    owner_of_node: Dict[int, int] = {}
+    for k, rs in enumerate(per):
+        for r in rs:
+            stack = [r]
+            while stack:
+                x = stack.pop()
+                owner_of_node[x] = k
+                stack += list(pop.nodes[x].children)
+    owner = [(-1 if t.node in top else owner_of_node[t.node]) for t in tasks]
+    return owner, per

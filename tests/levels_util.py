@@ -95,3 +95,18 @@ def high_occ_groups(seed=5):
     for gi, g in enumerate(groups):
         names.append([str(splitmix64(seed * 31 + gi * 100003 + i)) for i in range(len(g))])
     return [[a.tobytes().decode() for a in g] for g in groups], names
+
+
+def records_to_lists(rec, pool, names):
+    """packed pga_match_t records (pangraph_amd.dist.MATCH_DTYPE) + CIGAR pool of a whole wave -> per group, the plain lists of
+    util.rows_to_lists (the 17 observable fields in the reference's order), so that gathered match lists can be digested like PafRows"""
+    ops = "MIDNSHP=XB"
+    out = [[] for _ in names]
+    for r in rec:
+        g = int(r["group"])
+        o, n = int(r["cigar_off"]), int(r["n_cigar"])
+        cg = "".join(f"{int(c) >> 4}{ops[int(c) & 0xf]}" for c in pool[o:o + n])
+        out[g].append([names[g][int(r["qry"])], int(r["qry_len"]), int(r["qry_start"]), int(r["qry_end"]), "-" if r["reverse"] else "+",
+                       names[g][int(r["ref"])], int(r["ref_len"]), int(r["ref_start"]), int(r["ref_end"]), int(r["matches"]), int(r["length"]),
+                       int(r["quality"]), int(r["align"]), repr(float(r["divergence"])), cg, int(r["n_ambi"]), int(r["inv"])])
+    return out

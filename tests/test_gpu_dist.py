@@ -69,3 +69,61 @@ def test_two_ranks_one_device_gather_equals_single_rank():
         assert p.exitcode == 0
     assert ok is True, n
     assert n > 20
+
+
+def _worker_c4(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from pangraph_amd import batch
+        from pangraph_amd.dist import gather_matches, shard_groups_balanced
+        from pangraph_amd.levels import Population
+        from levels_util import digest, records_to_lists
+        from util import load_golden
+        batch.set_device(0)
+        e = load_golden("builds_expected.json.gz")["c4"]
+        p = e["params"]
+        waves = Population(p["seed"], p["n"], p["length"]).build_waves()
+        bad, n_rec, n_groups = [], 0, 0
+        if len(waves) != len(e["waves"]):
+            bad.append(("waves", len(waves), len(e["waves"])))
+        for (label, groups, names), ew in zip(waves, e["waves"]):
+            plan = shard_groups_balanced([sum(len(s) for s in g) for g in groups], world)
+            ids = plan[rank]
+            z = np.zeros(0, np.uint8)
+            res = batch.ResidentBatch(batch.PreparedBatch([groups[i] for i in ids], [names[i] for i in ids])).align(sensitivity=10, want_raw=True) if ids else None
+            got = gather_matches(res.raw_matches if res else z, res.raw_cigars if res else z, ids, plan, torch.device("cpu"), dst=0)
+            if rank == 0:
+                rows = records_to_lists(got[0], got[1], names)
+                for g, (r, x) in enumerate(zip(rows, ew["groups"])):
+                    if (len(r), digest(r)) != (x["n"], x["sha256"]):
+                        bad.append((label, g, len(r), x["n"]))
+                n_rec += sum(len(r) for r in rows)
+                n_groups += len(groups)
+        if rank == 0:
+            q.put((not bad, (bad[:5], n_groups, n_rec)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        if rank == 0:
+            q.put((False, repr(e)))
+        raise
+
+
+def test_c4_every_wave_two_ranks_gather_vs_reference_digests():
+    """config C4 ("klebs-like": 16 x 5.3 Mbp, seed 3; BASELINE.json configs[3]): every wave of the build sharded over TWO ranks (gloo) that
+    share the one device of the box, match lists gathered to rank 0 (pangraph_amd.dist.gather_matches, the exchange step of SURVEY 8e) and
+    digested per group against what the compiled reference returned in the build container (tests/golden/make_golden_builds.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker_c4, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok, info = q.get(timeout=900)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok is True, info
+    assert info[1] == 30 and info[2] > 1000, info

@@ -79,6 +79,26 @@ def test_c3_full_size_every_wave_vs_reference(gpu_lib, ref_lib):
             assert a == b, (label, g, len(a), len(b))
 
 
+def test_c5_every_wave(gpu_lib):
+    """config C5 = the BASELINE configuration (1000 x 5 Mbp, seed 20260928): all 42 waves, all 1998 find_matches calls of the build
+    through pga_batch_create + pga_batch_align, per group against the digests the compiled reference produced in the build container
+    (tests/golden/make_golden_builds.py -> builds_expected.json.gz).  graph_merging.rs:95-128 is the call pattern."""
+    e = load_golden("builds_expected.json.gz")["c5"]
+    p = e["params"]
+    waves = Population(p["seed"], p["n"], p["length"]).build_waves()
+    assert len(waves) == len(e["waves"]) == 42
+    n_groups = n_rec = 0
+    for (label, groups, names), ew in zip(waves, e["waves"]):
+        assert label == ew["label"] and [len(g) for g in groups] == ew["n_blocks"], label
+        assert [int(sum(len(s) for s in g)) for g in groups] == ew["bases"], label
+        got = product_align_groups(groups, names, sensitivity=10)
+        bad = [g for g, (r, x) in enumerate(zip(got, ew["groups"])) if (len(r), digest(r)) != (x["n"], x["sha256"])]
+        assert not bad, (label, bad[:5], len(bad))
+        n_groups += len(groups)
+        n_rec += sum(len(r) for r in got)
+    assert n_groups == 1998 and n_rec == sum(x["n"] for w in e["waves"] for x in w["groups"])
+
+
 def test_sort_replay_tap_adversarial(gpu_lib, ref_lib):
     """the run-length walk and the token walk of the sort replay (pga_sort_wave.h) against radix_sort_128x itself"""
     dll = gpu_lib.dll
