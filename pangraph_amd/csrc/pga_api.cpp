@@ -437,6 +437,7 @@ extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, co
 }
 
 // ---- resident batches: upload once, align (possibly many times) with the bases already in HBM ----
+struct BatchesInFlight { BatchesInFlight() { batch_call_enter(); } ~BatchesInFlight() { batch_call_leave(); } };
 struct pga_batch_s { std::vector<std::unique_ptr<PgaIdx>> parts; std::vector<int> g0; std::vector<std::vector<int64_t>> goff; int w = 0, k = 0; uint64_t bases = 0; };
 
 extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out)
@@ -490,6 +491,7 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 		memset(&R->st, 0, sizeof(R->st));
 		double t_all = now_s();
 		const int n_parts = (int)B->parts.size();
+		BatchesInFlight in_flight;                 // calls of other host threads count as concurrent parts (ready-set schedules keep several batches in flight)
 		int threads_each = params->n_threads > 0 ? params->n_threads : usable_cpus();
 		threads_each = std::max(1, threads_each / std::max(1, std::min(n_parts, 3)));
 		std::vector<std::string> errs((size_t)n_parts);

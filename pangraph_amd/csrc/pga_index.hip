@@ -78,8 +78,36 @@ __global__ void k_groups_g(const uint64_t *__restrict__ kx, const uint32_t *__re
 	grp_of_mz[orig[i]] = g;
 }
 
-// Sort minimizers by (group, x) keeping y ascending inside a key: a stable sort on x, then -- when the batch
-// holds several groups -- a stable sort on the group id (LSD order).
+// composite sort key: group id above the 2k hash bits (minimizers arrive in (group, sequence, position) order: rid is at hand)
+__global__ void k_split_ck(const u128 *__restrict__ mz, uint64_t n, const uint32_t *__restrict__ grp_of_seq, int hash_bits, uint64_t *__restrict__ ck, uint64_t *__restrict__ vy, uint32_t *__restrict__ orig)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u128 m = mz[i];
+	const uint64_t mask = hash_bits >= 64 ? ~0ULL : (1ULL << hash_bits) - 1;
+	ck[i] = (uint64_t)grp_of_seq[m.y >> 32] << hash_bits | ((m.x >> 8) & mask);
+	vy[i] = m.y; orig[i] = (uint32_t)i;
+}
+__global__ void k_head_flags_ck(const uint64_t *__restrict__ ck, uint64_t n, uint32_t *__restrict__ flag)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flag[i] = (i == 0 || ck[i] != ck[i - 1]) ? 1u : 0u;
+}
+__global__ void k_groups_ck(const uint64_t *__restrict__ ck, int hash_bits, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ gid_incl, const uint32_t *__restrict__ orig, const uint64_t *__restrict__ vy, uint64_t n,
+                            uint64_t *__restrict__ key, uint32_t *__restrict__ occ_off, uint32_t *__restrict__ key_grp, uint32_t *__restrict__ grp_of_mz, uint64_t *__restrict__ occ)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t g = gid_incl[i] - 1;
+	const uint64_t c = ck[i];
+	if (flag[i]) { key[g] = c & (hash_bits >= 64 ? ~0ULL : (1ULL << hash_bits) - 1); occ_off[g] = (uint32_t)i; key_grp[g] = hash_bits >= 64 ? 0u : (uint32_t)(c >> hash_bits); }
+	const uint32_t o = orig[i];
+	grp_of_mz[o] = g;
+	occ[i] = vy[o];
+}
+
+// Sort minimizers by (group, x) keeping y ascending inside a key.  ONE stable sort over the composite key group << 2k | hash when it fits
+// 64 bits (always with pangraph's k <= 28 and fewer than 2^8 ... 2^26 groups); otherwise a stable sort on x, then one on the group id.
 void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I, DBuf<uint32_t> &grp_of_mz, hipStream_t st)
 {
 	I.w = w, I.k = k; I.n_occ = M.n; I.n_keys = 0;
@@ -89,6 +117,38 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 	if (n == 0) { I.key.alloc(1); I.occ_off.alloc(1); I.occ_off.zero(st); I.key_grp.alloc(1); return; }
 	if (n >= (1ULL << 32)) throw std::runtime_error("pga: more than 2^32 minimizers in one batch");
 	const unsigned nb = (unsigned)((n + 255) / 256);
+	{
+		int gbits = 0; while ((1LL << gbits) < S.n_grp) ++gbits;
+		const int hash_bits = std::min(64, 2 * k);
+		if (hash_bits + gbits <= 64 && !getenv("PGA_INDEX_TWO_SORTS")) {
+			DBuf<uint64_t> ck(n), ck2(n), vy(n);
+			DBuf<uint32_t> orig(n), orig2(n);
+			hipLaunchKernelGGL(k_split_ck, dim3(nb), dim3(256), 0, st, M.mz.p, n, S.d_grp_of_seq.p, hash_bits, ck.p, vy.p, orig.p);
+			size_t tmp_bytes = 0;
+			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, hash_bits + gbits, st));
+			DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
+			PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, hash_bits + gbits, st));
+			DBuf<uint32_t> flag(n), gid(n);
+			hipLaunchKernelGGL(k_head_flags_ck, dim3(nb), dim3(256), 0, st, ck2.p, n, flag.p);
+			size_t tmp2 = 0;
+			PGA_HIP(rocprim::inclusive_scan(nullptr, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
+			DBuf<uint8_t> tmpb(tmp2 ? tmp2 : 1);
+			PGA_HIP(rocprim::inclusive_scan(tmpb.p, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
+			uint32_t n_keys = 0;
+			PGA_HIP(hipMemcpyAsync(&n_keys, gid.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+			PGA_HIP(hipStreamSynchronize(st));
+			I.n_keys = n_keys;
+			I.key.alloc(n_keys);
+			I.occ_off.alloc((size_t)n_keys + 1);
+			I.key_grp.alloc(n_keys);
+			hipLaunchKernelGGL(k_groups_ck, dim3(nb), dim3(256), 0, st, ck2.p, hash_bits, flag.p, gid.p, orig2.p, vy.p, n, I.key.p, I.occ_off.p, I.key_grp.p, grp_of_mz.p, I.occ.p);
+			uint32_t n32 = (uint32_t)n;
+			PGA_HIP(hipMemcpyAsync(I.occ_off.p + n_keys, &n32, 4, hipMemcpyHostToDevice, st));
+			PGA_HIP(hipGetLastError());
+			PGA_HIP(hipStreamSynchronize(st));
+			return;
+		}
+	}
 	DBuf<uint64_t> kx(n), kx2(n), vy(n);
 	DBuf<uint32_t> orig(n), orig2(n), gk;
 	hipLaunchKernelGGL(k_split, dim3(nb), dim3(256), 0, st, M.mz.p, n, kx.p, vy.p);

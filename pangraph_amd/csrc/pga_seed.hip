@@ -168,11 +168,14 @@ __device__ __forceinline__ bool skip_seed(const SkipCtx &C, uint64_t r, uint32_t
 	return false;
 }
 
-template <bool WRITE>
+// Anchors of every seed in ONE walk over its occurrence list (map.c:168-204): seed j writes at ub_off[j] -- the offsets of an upper
+// bound (every occurrence kept) -- and records how many it kept; k_anchor_pack then packs the kept ones, already split into x / y for the
+// sort.  (Counting first and writing second walked every occurrence list twice: the lists are scattered 8-byte reads, one cache line per
+// seed and pass -- 0.48 TB of fetches per build for 8 GB of anchors.)
 __global__ void k_anchors(const u128 *__restrict__ mz, const uint32_t *__restrict__ kept_idx, uint64_t n_kept,
                           const uint32_t *__restrict__ sd_n, const uint32_t *__restrict__ sd_occ, const uint32_t *__restrict__ sd_qpos, const uint8_t *__restrict__ sd_flag,
                           const uint64_t *__restrict__ occ, SkipCtx C, int32_t k_span,
-                          uint32_t *__restrict__ cnt, const uint64_t *__restrict__ a_off, u128 *__restrict__ a)
+                          uint32_t *__restrict__ cnt, const uint64_t *__restrict__ ub_off, u128 *__restrict__ ub)
 {
 	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n_kept) return;
@@ -182,30 +185,39 @@ __global__ void k_anchors(const u128 *__restrict__ mz, const uint32_t *__restric
 		const uint32_t i = kept_idx ? kept_idx[j] : (uint32_t)j;
 		const uint32_t qid = (uint32_t)(mz[i].y >> 32), qlen = C.seq_len[qid], q_pos = sd_qpos[j], n = sd_n[j];
 		const uint64_t *cr = occ + sd_occ[j];
-		u128 *out = WRITE ? a + a_off[j] : nullptr;
+		u128 *out = ub + ub_off[j];
 		for (uint32_t t = 0; t < n; ++t) {
 			uint64_t r = cr[t];
 			bool is_self;
 			if (skip_seed(C, r, q_pos, qid, qlen, &is_self)) continue;
-			if (WRITE) {
-				u128 p;
-				const uint64_t rpos = (uint32_t)r >> 1;
-				r -= (uint64_t)C.grp_base[qid] << 32;                     // target id relative to the group, as in a per-group index
-				if ((r & 1) == (q_pos & 1)) {
-					p.x = (r & 0xffffffff00000000ULL) | rpos;
-					p.y = (uint64_t)k_span << 32 | (q_pos >> 1);
-				} else {
-					p.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
-					p.y = (uint64_t)k_span << 32 | (uint32_t)(qlen - ((q_pos >> 1) + 1 - (uint32_t)k_span) - 1);
-				}
-				if (fl & 1) p.y |= SEED_TANDEM;
-				if (is_self) p.y |= SEED_SELF;
-				out[c] = p;
+			u128 p;
+			const uint64_t rpos = (uint32_t)r >> 1;
+			r -= (uint64_t)C.grp_base[qid] << 32;                     // target id relative to the group, as in a per-group index
+			if ((r & 1) == (q_pos & 1)) {
+				p.x = (r & 0xffffffff00000000ULL) | rpos;
+				p.y = (uint64_t)k_span << 32 | (q_pos >> 1);
+			} else {
+				p.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+				p.y = (uint64_t)k_span << 32 | (uint32_t)(qlen - ((q_pos >> 1) + 1 - (uint32_t)k_span) - 1);
 			}
+			if (fl & 1) p.y |= SEED_TANDEM;
+			if (is_self) p.y |= SEED_SELF;
+			out[c] = p;
 			++c;
 		}
 	}
-	if (!WRITE) cnt[j] = c;
+	cnt[j] = c;
+}
+// the kept anchors of seed j, from its slots of the upper-bound layout to their final places (x and y apart: what the sort wants)
+__global__ void k_anchor_pack(uint64_t n_kept, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ ub_off, const u128 *__restrict__ ub, const uint64_t *__restrict__ a_off,
+                              uint64_t *__restrict__ x, uint64_t *__restrict__ y)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_kept) return;
+	const uint32_t c = cnt[j];
+	const u128 *in = ub + ub_off[j];
+	const uint64_t o = a_off[j];
+	for (uint32_t t = 0; t < c; ++t) { const u128 v = in[t]; x[o + t] = v.x; y[o + t] = v.y; }
 }
 
 __global__ void k_query_anchor_off(const uint64_t *__restrict__ a_off, const uint64_t *__restrict__ seq_off2, int n_seq, uint64_t n_kept, uint64_t total, uint64_t *__restrict__ q_aoff)
@@ -262,12 +274,12 @@ __global__ void k_tie_flags(const uint64_t *__restrict__ xs, const uint64_t *__r
 	}
 }
 // queries whose anchors hold equal keys restart from the raw order
-__global__ void k_copy_tied(int n_seq, const uint32_t *__restrict__ q_tie, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a_unsorted, u128 *__restrict__ a_sorted)
+__global__ void k_copy_tied(int n_seq, const uint32_t *__restrict__ q_tie, const uint64_t *__restrict__ q_aoff, const uint64_t *__restrict__ x_unsorted, const uint64_t *__restrict__ y_unsorted, u128 *__restrict__ a_sorted)
 {
 	const int q = blockIdx.x;
 	if (q >= n_seq || !q_tie[q]) return;
 	const uint64_t b = q_aoff[q], e = q_aoff[q + 1];
-	for (uint64_t i = b + (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < e; i += (uint64_t)gridDim.y * blockDim.x) a_sorted[i] = a_unsorted[i];
+	for (uint64_t i = b + (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < e; i += (uint64_t)gridDim.y * blockDim.x) { u128 v; v.x = x_unsorted[i]; v.y = y_unsorted[i]; a_sorted[i] = v; }
 }
 
 // ---- host orchestration ----
@@ -339,12 +351,25 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	hipLaunchKernelGGL(k_seed_select, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, st, n_seq, seq_off2.p, S.d_len.p, q_high.p,
 	                   sd_n.p, sd_qpos.p, sd_flag.p, P, (int32_t)I.k, rep_len.p);
 
-	// 3. anchors: count, scan, write
+	// 3. anchors: one walk over the occurrence lists into an upper-bound layout, scan of the kept counts, pack
 	SkipCtx C{opt.flag, d_name_rank.p, S.d_len.p, S.d_grp_base.p};
 	DBuf<uint32_t> cnt(n_kept + 1); cnt.zero(st);
-	DBuf<uint64_t> a_off(n_kept + 1);
-	hipLaunchKernelGGL((k_anchors<false>), dim3(nbk), dim3(256), 0, st, M.mz.p, kept_p, n_kept, sd_n.p, sd_occ.p, sd_qpos.p, sd_flag.p, I.occ.p, C,
-	                   (int32_t)I.k, cnt.p, (const uint64_t*)nullptr, (u128*)nullptr);
+	DBuf<uint64_t> a_off(n_kept + 1), ub_off(n_kept + 1);
+	{
+		struct Ub { const uint32_t *n; const uint8_t *fl; uint64_t n_kept; };
+		Ub u{sd_n.p, sd_flag.p, n_kept};
+		auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), [u] __device__ (uint64_t j) { return j < u.n_kept && !(u.fl[j] & 2) ? (uint64_t)u.n[j] : (uint64_t)0; });
+		size_t tb = 0;
+		PGA_HIP(rocprim::exclusive_scan(nullptr, tb, it, ub_off.p, (uint64_t)0, n_kept + 1, rocprim::plus<uint64_t>(), st));
+		DBuf<uint8_t> tmp(tb ? tb : 1);
+		PGA_HIP(rocprim::exclusive_scan(tmp.p, tb, it, ub_off.p, (uint64_t)0, n_kept + 1, rocprim::plus<uint64_t>(), st));
+	}
+	uint64_t n_ub = 0;
+	PGA_HIP(hipMemcpyAsync(&n_ub, ub_off.p + n_kept, 8, hipMemcpyDeviceToHost, st));
+	PGA_HIP(hipStreamSynchronize(st));
+	DBuf<u128> ub(n_ub ? n_ub : 1);
+	hipLaunchKernelGGL(k_anchors, dim3(nbk), dim3(256), 0, st, M.mz.p, kept_p, n_kept, sd_n.p, sd_occ.p, sd_qpos.p, sd_flag.p, I.occ.p, C,
+	                   (int32_t)I.k, cnt.p, ub_off.p, ub.p);
 	excl_scan(cnt.p, a_off.p, n_kept + 1, st);
 	uint64_t n_a = 0;
 	PGA_HIP(hipMemcpyAsync(&n_a, a_off.p + n_kept, 8, hipMemcpyDeviceToHost, st));
@@ -355,15 +380,12 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	O.h_q_aoff = O.q_aoff.download(st);
 	O.a.alloc(n_a ? n_a : 1);
 	if (n_a == 0) return;
-	DBuf<u128> a_raw(n_a);
-	hipLaunchKernelGGL((k_anchors<true>), dim3(nbk), dim3(256), 0, st, M.mz.p, kept_p, n_kept, sd_n.p, sd_occ.p, sd_qpos.p, sd_flag.p, I.occ.p, C,
-	                   (int32_t)I.k, (uint32_t*)nullptr, a_off.p, a_raw.p);
 
 	// 4. sort each query's anchors by x.  Parallel stable segmented sort first; queries that contain equal keys
 	//    are then re-sorted from the raw order by the sequential replay of radix_sort_128x (pga_sort_exact.h).
 	const unsigned nba = (unsigned)((n_a + 255) / 256);
 	DBuf<uint64_t> x0(n_a), y0(n_a), x1(n_a), y1(n_a);
-	hipLaunchKernelGGL(k_split128, dim3(nba), dim3(256), 0, st, a_raw.p, n_a, x0.p, y0.p);
+	hipLaunchKernelGGL(k_anchor_pack, dim3(nbk), dim3(256), 0, st, n_kept, cnt.p, ub_off.p, ub.p, a_off.p, x0.p, y0.p);
 	{
 		// anchors are already grouped by query, so a device-wide stable sort by x followed by a stable sort by the
 		// query id (LSD order) equals a per-query sort, without the one-block-per-segment cost of a segmented sort
@@ -397,19 +419,8 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	}
 	hipLaunchKernelGGL(k_join128, dim3(nba), dim3(256), 0, st, x1.p, y1.p, n_a, O.a.p);
 	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
-	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, a_raw.p, q_tie.p);
-	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, a_raw.p, O.a.p);
-	if (const char *dump = getenv("PGA_DUMP_ANCHORS")) {
-		// diagnosis: the raw anchors of the first large query with equal keys, as the replay will see them
-		std::vector<uint32_t> tf = q_tie.download(st);
-		for (int q = 0; q < n_seq; ++q) if (tf[(size_t)q] && O.h_q_aoff[(size_t)q + 1] - O.h_q_aoff[(size_t)q] >= 400000) {
-			const uint64_t b = O.h_q_aoff[(size_t)q], m = O.h_q_aoff[(size_t)q + 1] - b;
-			std::vector<u128> h((size_t)m);
-			PGA_HIP(hipMemcpy(h.data(), a_raw.p + b, (size_t)m * sizeof(u128), hipMemcpyDeviceToHost));
-			if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), sizeof(u128), (size_t)m, f); fclose(f); fprintf(stderr, "[pga] dumped %llu raw anchors of query %d to %s\n", (unsigned long long)m, q, dump); }
-			break;
-		}
-	}
+	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, (const u128*)nullptr, q_tie.p);
+	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, x0.p, y0.p, O.a.p);
 	// the stable sort above doubles as a hint for the replay: buckets without equal keys are copied from it instead of being walked
 	DBuf<uint32_t> dupc(n_a);
 	{

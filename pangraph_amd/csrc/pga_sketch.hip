@@ -65,8 +65,11 @@ static thread_local int t_thread_budget = 0;
 void set_thread_budget(int n) { t_thread_budget = n; }
 int thread_budget() { return t_thread_budget > 0 ? t_thread_budget : usable_cpus(); }
 static thread_local int t_part_conc = 1;
+static std::atomic<int> g_batch_calls(0);      // pga_batch_align calls in flight in this process (ready-set schedules keep several going)
 void set_part_concurrency(int n) { t_part_conc = n > 0 ? n : 1; }
-int part_concurrency() { return t_part_conc; }
+int part_concurrency() { const int g = g_batch_calls.load(std::memory_order_relaxed); return t_part_conc > g ? t_part_conc : g; }
+void batch_call_enter() { g_batch_calls.fetch_add(1); }
+void batch_call_leave() { g_batch_calls.fetch_sub(1); }
 
 static inline uint8_t nt4_host(uint8_t r)
 {

@@ -6,6 +6,7 @@
 // critical path of a sort falls from "all levels, one wave" to "the longest run of each level".
 #include "pga_common.h"
 #include "pga_sort_wave.h"
+#include "pga_sort_big.h"
 #include "pga_pipeline.h"
 #include <cstdio>
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ void rs_push2(RsRun *out, uint32_t *n_out, RsRun *out
 // one wave per array: small arrays are finished here, the others enter the run queue at their first non-trivial level
 __global__ __launch_bounds__(64)
 void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int64_t *__restrict__ len, int n_seg, const uint32_t *__restrict__ flag, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
-               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap)
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, RsRun *__restrict__ out_b, uint32_t *__restrict__ n_out_b, uint32_t cap_b)
 {
 	__shared__ RsLds L;
 	const int s = blockIdx.x, lane = threadIdx.x;
@@ -46,7 +47,136 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 	const uint64_t vary = rs_varying_bits(a + b, n, lane);
 	if (vary == 0) return;
 	const int shift = (63 - __clzll((long long)vary)) & ~7;
-	rs_push2(out, n_out, out_s, n_out_s, cap, b, (uint32_t)n, shift, vary, lane);
+	if (out_b && n >= RSB_MIN) rs_push(out_b, n_out_b, cap_b, b, (uint32_t)n, shift, vary, lane);
+	else rs_push2(out, n_out, out_s, n_out_s, cap, b, (uint32_t)n, shift, vary, lane);
+}
+
+// ---- runs of RSB_MIN records or more: a workgroup per run (pga_sort_big.h) ----
+__global__ __launch_bounds__(RSB_NT)
+void k_rs_pass_big(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out_b, uint32_t *__restrict__ n_out_b, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
+                   RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t cap_b, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, uint8_t *__restrict__ dig_all,
+                   RsHint hint, u128 *__restrict__ tmp_all, uint2 *__restrict__ lg_all, uint4 *__restrict__ blg_all, int run_min, int pass_no)
+{
+	__shared__ RsBigLds S;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	if (tid == 0) S.L.run_min = run_min;
+	const uint32_t n_runs = *n_in < cap_b ? *n_in : cap_b;
+	for (;;) {
+		if (tid == 0) S.ctl[0] = atomicAdd(work, 1u);
+		__syncthreads();
+		const uint32_t r = S.ctl[0];
+		__syncthreads();
+		if (r >= n_runs) break;
+		const RsRun R = in[r];
+		if (tid == 0) { S.L.prof[0] = S.L.prof[1] = S.L.prof[2] = S.L.prof[3] = 0; for (int z = 0; z < 8; ++z) S.wp[z] = 0; }
+		const unsigned long long tk0 = wall_clock64();
+		unsigned long long t_walk = 0;
+		uint64_t cur_start = R.start; int64_t n = R.len;
+		int shift = R.shift;
+		for (;;) {
+			u128 *beg = a + cur_start;
+			uint8_t *dig = dig_all + cur_start;
+			uint32_t *rend = rend_all + cur_start;
+			// the first level at or below `shift` that splits the run
+			const unsigned long long th0 = wall_clock64();
+			while (shift >= 0) {
+				rsb_hist(beg, n, shift, dig, S, tid);
+				if (S.ctl[1] > 1) break;
+				__syncthreads();
+				shift = rs_next_level(R.vary, shift - 8);
+			}
+			if (shift < 0) break;
+			const uint32_t n_ne = S.ctl[1];
+			unsigned long long nonempty[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) nonempty[k] = __ballot(S.bcnt[lane + 64 * k] > 0);
+			const unsigned long long tl0 = wall_clock64();
+			bool moved = false;
+			if (n_ne == 2 && n >= 1024) {
+				// two non-empty buckets: the closed form of pga_sort_wave.h (one wave: three passes with running counts)
+				if (wave == 0) {
+					int dA = -1; uint32_t cA = 0;
+#pragma unroll
+					for (int k = 3; k >= 0; --k) if (nonempty[k]) { const int l = __ffsll((long long)nonempty[k]) - 1; dA = l + 64 * k; }
+					cA = S.bcnt[dA];
+					const bool ok = rs_level_two(beg, n, shift, (uint32_t)dA, cA, tmp_all + cur_start, rend, lane);
+					if (lane == 0) S.ctl[2] = ok ? 1u : 0u;
+				}
+				rs_fence_wg();
+				__syncthreads();
+				moved = S.ctl[2] != 0;
+				__syncthreads();
+			}
+			if (prof && tid == 0) atomicAdd(&prof[64 + 8 * pass_no + 0], tl0 - th0);
+			if (!moved) {
+				// digit runs of the original order: long ones -> the run walk (over the resident run table when it fits LDS, else over
+				// 64-digit windows and the run ends in memory); short ones -> the walk on digit windows
+				rsb_run_count(dig, n, S, tid);
+				const uint32_t nb = S.ctl[3];
+				const bool by_runs = (uint64_t)n >= (uint64_t)run_min * nb;
+				const bool table = by_runs && nb <= RSB_RT_MAX && n < (1LL << 24);
+				if (table) rsb_run_table(dig, n, rend, S, tid);
+				else if (by_runs) rsb_rend(dig, n, rend, S, tid);
+				const unsigned long long tw0 = wall_clock64();
+				if (prof && tid == 0) atomicAdd(&prof[64 + 8 * pass_no + 1], tw0 - tl0);
+				if (wave == 0) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) { const int b = lane + 64 * k; S.L.head[b] = S.bstart[b]; S.L.tail[b] = S.bstart[b] + S.bcnt[b]; }
+					rs_fence_wave();
+					RsLog G{lg_all + cur_start, blg_all + (cur_start >> 1), 0u, 0u, 0u};
+					if (by_runs) rsb_walk_runs(dig, rend, table ? nb : 0u, S.L, S.hw, lane, nonempty, G, S.wp);
+					else rsb_walk_digits(dig, S.L, lane, nonempty, n_ne, G);
+					if (lane == 0) { S.ctl[4] = G.n1; S.ctl[5] = G.n2; S.ctl[6] = G.tot; }
+				}
+				rs_fence_wg();
+				__syncthreads();
+				const unsigned long long ta0 = wall_clock64();
+				rsb_apply(beg, tmp_all + cur_start, lg_all + cur_start, blg_all + (cur_start >> 1), S.ctl[4], S.ctl[5], S.ctl[6], tid);
+				if (prof && tid == 0) { atomicAdd(&prof[64 + 8 * pass_no + 2], ta0 - tw0); atomicAdd(&prof[64 + 8 * pass_no + 3], wall_clock64() - ta0); }
+			}
+			t_walk += wall_clock64() - tl0;
+			if (shift <= 0) break;                                // nothing below the last byte
+			const int next = rs_next_level(R.vary, shift - 8);
+			if (next < 0) break;                                  // the keys of a bucket agree in every lower byte: nothing left to order
+			// the largest bucket of the level: the workgroup goes on with it when it holds half of the run (see k_rs_pass)
+			if (wave == 0) {
+				uint32_t big_len = 0, big_off = 0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t c = S.bcnt[lane + 64 * k], o = S.bstart[lane + 64 * k];
+					const uint32_t m = wave_max_u32(c);
+					if (m > big_len) { const unsigned long long bm = __ballot(c == m); const int l = __ffsll((long long)bm) - 1; big_len = m; big_off = (uint32_t)__builtin_amdgcn_readlane((int)o, l); }
+				}
+				if (lane == 0) { S.ctl[7] = big_len; S.ctl[8] = big_off; S.ctl[9] = ((uint64_t)big_len * 2 >= (uint64_t)n && big_len > 4096) ? 1u : 0u; S.ctl[10] = 0u; }
+			}
+			__syncthreads();
+			const uint32_t big_len = S.ctl[7], big_off = S.ctl[8]; const bool follow = S.ctl[9] != 0;
+			for (int b = wave; b < 256; b += RSB_NW) {
+				const uint32_t c = S.bcnt[b], o = S.bstart[b];
+				if (c <= 1) continue;
+				const uint64_t g0 = cur_start + o;
+				if (c <= 64) { rsb_stable64(a + g0, c, lane); continue; }             // ksort.h:142
+				if (hint.dupc && hint.dupc[g0 + c - 1] == hint.dupc[g0]) {
+					// no two equal keys in this bucket: its final order is the sorted order
+					for (uint32_t i = (uint32_t)lane; i < c; i += 64) { u128 v; v.x = hint.sx[g0 + i]; v.y = hint.sy[g0 + i]; a[g0 + i] = v; }
+					continue;
+				}
+				if (follow && o == big_off && c == big_len) { if (lane == 0) S.ctl[10] = 1u; continue; }
+				if (c >= RSB_MIN) rs_push(out_b, n_out_b, cap_b, g0, c, next, R.vary, lane);
+				else rs_push2(out, n_out, out_s, n_out_s, cap, g0, c, next, R.vary, lane);
+			}
+			rs_fence_wg();
+			__syncthreads();
+			const bool go_on = S.ctl[10] != 0;
+			__syncthreads();
+			if (!go_on) break;
+			cur_start += big_off; n = big_len; shift = next;
+		}
+		if (prof && tid == 0) { for (int z = 0; z < 8; ++z) atomicAdd(&prof[64 + 8 * pass_no + 4 + z], S.wp[z]); }
+		if (prof && tid == 0) { const unsigned long long tk2 = wall_clock64(); atomicAdd(&prof[0], t_walk); atomicMax(&prof[1], t_walk); atomicAdd(&prof[32], S.L.prof[0]); atomicAdd(&prof[33], S.L.prof[1]); atomicAdd(&prof[34], S.L.prof[2]); atomicAdd(&prof[35], S.L.prof[3]);
+		                         atomicAdd(&prof[2], tk2 - tk0 - t_walk); atomicMax(&prof[3], tk2 - tk0 - t_walk); }
+		__syncthreads();
+	}
 }
 
 // persistent waves over the run queue of this pass
@@ -315,19 +445,26 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	EventTimer et(st);
 	const uint32_t cap = (uint32_t)std::min<uint64_t>(n_total / 65 + (uint64_t)n_seg + 64, 0x7fffffffu);
 	DBuf<RsRun> q0(cap), q1(cap), qs(cap);    // two generations of large runs, and the runs small enough for the LDS sorter
-	DBuf<uint32_t> ctr(2 * 9 + 2);            // per pass: queue length and work counter
+	DBuf<uint32_t> ctr(2 * 9 + 2 + 2 * 9);    // per pass: queue length and work counter; [20..38): the same for the queue of BIG runs
 	ctr.zero(st);
-	hipLaunchKernelGGL(k_rs_init, dim3((unsigned)n_seg), dim3(64), 0, st, a, d_off, d_len, n_seg, d_flag, q0.p, ctr.p + 0, qs.p, ctr.p + 18, cap);
+	// runs of RSB_MIN records or more go to the workgroup kernel (pga_sort_big.h); PGA_RS_NO_BIG=1 keeps everything on single waves
+	static const bool use_big = getenv("PGA_RS_NO_BIG") == nullptr && getenv("PGA_NO_RUNWALK") == nullptr && getenv("PGA_NO_TWOBUCKET") == nullptr && getenv("PGA_NO_DIGITWALK") == nullptr && getenv("PGA_RS_ASYNC") == nullptr;
+	const uint32_t cap_b = use_big ? (uint32_t)std::min<uint64_t>(n_total / RSB_MIN + 2, cap) : 1u;
+	DBuf<RsRun> qb0(cap_b), qb1(cap_b);
+	hipLaunchKernelGGL(k_rs_init, dim3((unsigned)n_seg), dim3(64), 0, st, a, d_off, d_len, n_seg, d_flag, q0.p, ctr.p + 0, qs.p, ctr.p + 18, cap, use_big ? qb0.p : (RsRun*)nullptr, ctr.p + 20, cap_b);
 	const unsigned grid = 2048;
 	RsRun *qin = q0.p, *qout = q1.p;
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
-	DBuf<unsigned long long> dprof(64); dprof.zero(st);
+	DBuf<unsigned long long> dprof(64 + 12 * 8); dprof.zero(st);   // [0, 64): both kernels, slots 4 * pass + {0..3, 32..35}; from 64 on: twelve slots per pass of the workgroup kernel
 	DBuf<uint32_t> rend;
 	if (!getenv("PGA_NO_RUNWALK")) rend.alloc(n_total);
 	DBuf<u128> tmp2;                        // the out-of-place image of the two-bucket levels
 	if (rend.p && !getenv("PGA_NO_TWOBUCKET")) tmp2.alloc(n_total);
 	DBuf<uint2> lg;                          // the digit walk's record of moves (destination slot, source slot)
 	if (tmp2.p && !getenv("PGA_NO_DIGITWALK")) lg.alloc(n_total);
+	DBuf<uint8_t> digb; DBuf<uint4> blg;     // workgroup kernel: the digit bytes of a level, the log of moved stretches
+	if (use_big) { digb.alloc(n_total + 64); blg.alloc(n_total / 2 + 64); }
+	RsRun *qbin = qb0.p, *qbout = qb1.p;
 	double pass_ms[9] = {0};
 	static const int run_min = getenv("PGA_RS_RUN_MIN") ? std::max(1, atoi(getenv("PGA_RS_RUN_MIN"))) : 64;
 	if (verbose) { pass_ms[8] = et.stop(); }
@@ -345,6 +482,9 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	} else
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
+		// (a queue that overflowed cap_b is caught below: big runs are at most n_total / RSB_MIN)
+		if (use_big) hipLaunchKernelGGL(k_rs_pass_big, dim3(std::min<unsigned>(512u, cap_b)), dim3(RSB_NT), 0, st, a, qbin, ctr.p + 20 + 2 * pass, qbout, ctr.p + 20 + 2 * (pass + 1), qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, cap_b, ctr.p + 20 + 2 * pass + 1,
+		                                verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, digb.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p, blg.p, run_min, pass);
 		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p, run_min);
 		if (verbose) {
 			pass_ms[pass] = ep.stop();
@@ -359,9 +499,13 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 				std::vector<unsigned long long> pr = dprof.download(st);
 				fprintf(stderr, "[pga]     pass %d: %.1f ms; walks: sum %.1f ms, longest %.2f ms; bucket splitting: sum %.1f ms, longest %.2f ms\n", pass, pass_ms[pass], pr[4 * pass] * 1e-5, pr[4 * pass + 1] * 1e-5, pr[4 * pass + 2] * 1e-5, pr[4 * pass + 3] * 1e-5);
 				fprintf(stderr, "[pga]       run-length walk: %llu bulk events moving %llu cycles, %llu token cycles of %llu steps\n", pr[4 * pass + 32], pr[4 * pass + 33], pr[4 * pass + 34], pr[4 * pass + 35]);
+				const unsigned long long *pb = pr.data() + 64 + 12 * pass;
+				if (use_big) fprintf(stderr, "[pga]       workgroup kernel, summed over its runs: histogram %.2f ms, run ends %.2f ms, walk %.2f ms, apply %.2f ms; in the walk: %llu home skips %.2f ms, lean cycles %.2f ms, rotations %.2f ms (%llu stops; following %.2f ms, logging %.2f ms), token walks %.2f ms\n", pb[0] * 1e-5, pb[1] * 1e-5, pb[2] * 1e-5, pb[3] * 1e-5,
+				                     pb[8], pb[4] * 1e-5, pb[5] * 1e-5, pb[6] * 1e-5, pb[9], pb[10] * 1e-5, pb[11] * 1e-5, pb[7] * 1e-5);
 			}
 		}
 		std::swap(qin, qout);
+		std::swap(qbin, qbout);
 	}
 	// the small runs were final the moment they were queued: one launch sorts them all
 	EventTimer es(st);
@@ -374,6 +518,7 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	if (!sync_passes) async_overflow = Qd.download(st)[0].overflow != 0;
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   sort replay: %llu records in %d arrays, %.3f ms; runs per pass: %u %u %u %u %u %u %u %u; ms: init %.1f, passes %.1f %.1f %.1f %.1f %.1f; %u small runs %.1f ms\n", (unsigned long long)n_total, n_seg, ms, h[0], h[2], h[4], h[6], h[8], h[10], h[12], h[14], pass_ms[8], pass_ms[0], pass_ms[1], pass_ms[2], pass_ms[3], pass_ms[4], h[18], ms_small);
 	for (int pass = 0; pass <= 8; ++pass) if (h[2 * pass] > cap) throw std::runtime_error("pga: run queue overflow in the sort replay");
+	for (int pass = 0; pass <= 8; ++pass) if (use_big && h[20 + 2 * pass] > cap_b) throw std::runtime_error("pga: big-run queue overflow in the sort replay");
 	if (h[18] > cap || async_overflow) throw std::runtime_error("pga: run queue overflow in the sort replay");
 }
 

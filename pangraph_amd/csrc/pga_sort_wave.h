@@ -414,7 +414,7 @@ __device__ inline void rs_level_sim(u128 *beg, int64_t n, int shift, RsLds &L, i
 					const uint32_t wbk = cover(k, pos, ws);
 					const uint32_t dd = (uint32_t)dwin[ws + (pos - wbk)];
 					if (lane == 0) { lg[n_log] = make_uint2(pos, src); L.head[k] = pos + 1; }
-					rs_fence_wave();
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS only: a wavefront fence would also wait for the log's global store, every step)
 					++n_log;
 					src = pos; k = dd;
 				} while (k != i);
