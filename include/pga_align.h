@@ -154,6 +154,37 @@ typedef struct {
 int pga_map_variations(int64_t n_jobs, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t *params, pga_mapvar_res_t *res,
                        pga_sub_t **subs, pga_del_t **dels, pga_ins_t **inss, char **ins_seq);
 void pga_free(void *p);
+
+/* ---- reconsensus of the blocks a merge updated ----
+ * pga_reconsensus replaces, for all updated blocks at once, analyze_blocks_for_reconsensus and the per-block work of reconsensus_graph
+ * (packages/pangraph/src/reconsensus/reconsensus.rs:32-126): find_majority_edits (pangraph/pangraph_block.rs:191-256: an edit shared by more
+ * than depth / 2 members), then per block either nothing (kind 0), apply_substitutions_to_block (kind 1: the consensus letters change, every
+ * member's substitutions are reconciled, edits.rs:196-238) or edit_consensus_and_realign (kind 2, pangraph_block.rs:295-332: the majority
+ * edits applied to the consensus, every member's sequence rebuilt with Edit::apply and re-aligned by map_variations with the band of
+ * BandParameters::from_edits).  Counting, Edit::apply, reconciliation and the re-alignment run on the device; sequences built there feed the
+ * aligner without leaving it.  detach_unaligned_nodes and the node / path maps (reconsensus.rs:76-88) stay with the caller.
+ * Input: the members of block b are the next blocks[b].n_members entries of members[] (the reference's BTreeMap order), the edits of a
+ * member the next n_subs / n_dels / n_inss entries of subs / dels / inss (insertion letters: ins_seq[seq_off .. seq_off + len)).
+ * Output (freed with pga_rc_free): per block its kind, its consensus afterwards and its majority edits; per member (input order) its edits
+ * against that consensus as a pga_mapvar_res_t (offsets into out->subs / dels / inss; kind 0: the input edits).  A negative kind is the
+ * reference's error for that block (-2 a majority letter equals the consensus letter, -3 empty consensus, -4 no aligned position,
+ * -5 a member holds a substitution and a deletion, or two substitutions, at one position); member status 7: no aligned position
+ * (map_variations.rs:32), otherwise the codes of pga_map_variations.  Returns 0, or -1 with the message in pga_last_error(). */
+typedef struct { const char *consensus; uint32_t cons_len, n_members; } pga_rc_block_t;
+typedef struct { uint32_t n_subs, n_dels, n_inss; } pga_rc_member_t;
+typedef struct {
+	int32_t kind; uint32_t cons_len; uint64_t cons_off;                  /* consensus afterwards: out->cons[cons_off .. cons_off + cons_len) */
+	uint32_t n_subs, n_dels, n_inss; uint64_t sub_off, del_off, ins_off; /* majority edits: out->m_subs / m_dels / m_inss (letters in out->m_ins_seq) */
+} pga_rc_block_res_t;
+typedef struct {
+	pga_rc_block_res_t *blocks; pga_mapvar_res_t *members;
+	pga_sub_t *subs; pga_del_t *dels; pga_ins_t *inss; char *ins_seq;
+	pga_sub_t *m_subs; pga_del_t *m_dels; pga_ins_t *m_inss; char *m_ins_seq;
+	char *cons;
+} pga_rc_out_t;
+int pga_reconsensus(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_rc_member_t *members, const pga_sub_t *subs, const pga_del_t *dels,
+                    const pga_ins_t *inss, const char *ins_seq, const pga_mapvar_params_t *params, pga_rc_out_t *out);
+void pga_rc_free(pga_rc_out_t *out);
 int pga_stats_version(void);     /* == PGA_STATS_VERSION of the header the library was built with */
 #ifdef __cplusplus
 }

@@ -715,6 +715,26 @@ extern "C" int pga_map_variations(int64_t n_jobs, const pga_mapvar_job_t *jobs, 
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 
+// ---------------------------------------------------------------- reconsensus (pga_reconsensus.hip)
+namespace pga {
+void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_rc_member_t *members, const pga_sub_t *subs, const pga_del_t *dels, const pga_ins_t *inss, const char *ins_seq,
+                      const pga_mapvar_params_t &prm, pga_rc_out_t *out);
+}
+extern "C" void pga_rc_free(pga_rc_out_t *o)
+{
+	if (!o) return;
+	free(o->blocks); free(o->members); free(o->subs); free(o->dels); free(o->inss); free(o->ins_seq); free(o->m_subs); free(o->m_dels); free(o->m_inss); free(o->m_ins_seq); free(o->cons);
+	memset(o, 0, sizeof(*o));
+}
+extern "C" int pga_reconsensus(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_rc_member_t *members, const pga_sub_t *subs, const pga_del_t *dels,
+                               const pga_ins_t *inss, const char *ins_seq, const pga_mapvar_params_t *params, pga_rc_out_t *out)
+{
+	if (!out) { set_err("pga_reconsensus: null output"); return -1; }
+	memset(out, 0, sizeof(*out));
+	try { require_device(); reconsensus_host(n_blocks, blocks, members, subs, dels, inss, ins_seq, *params, out); return 0; }
+	catch (std::exception &e) { pga_rc_free(out); set_err(e.what()); return -1; }
+}
+
 extern "C" int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *xy)
 {
 	try {

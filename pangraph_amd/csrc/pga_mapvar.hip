@@ -42,6 +42,7 @@ enum { MV_MATCH = 1, MV_REF_GAP_MATRIX = 2, MV_QRY_GAP_MATRIX = 4, MV_REF_GAP_EX
 
 struct MvParams { int32_t match, mismatch, gap_open, ext, left_free, right_free, left_align, min_length, max_attempts; };
 struct MvJob { uint64_t ref_off, qry_off; uint32_t ref_len, qry_len; int32_t ms; uint32_t bw, attempt, orig; };
+struct MvDevJob { uint64_t ref_off, qry_off; uint32_t ref_len, qry_len; int32_t mean_shift; uint32_t band_width; };   // sequences already in device memory (pga_reconsensus)
 struct MvOut { int32_t status, score, attempts, hit; uint32_t n_subs, n_dels, n_inss, n_ib; uint64_t sub_off, del_off, ins_off, ib_off; };
 struct MvCursors { unsigned long long subs, dels, inss, ib; };
 struct MvCaps { unsigned long long subs, dels, inss, ib; };
@@ -467,6 +468,9 @@ static inline int mv_pack_seg(const MvJob &J)
 }
 static inline int mv_ring_class(const MvJob &J) { const int ps = mv_pack_seg(J); if (ps) return ps; const long long w = mv_ring_cols(J); return w <= 128 ? 128 : w <= 512 ? 512 : w <= 2048 ? 2048 : 0; }
 
+static void mv_run_rounds(std::vector<MvJob> &pending, const uint8_t *d_codes_p, const pga_mapvar_params_t &prm, pga_mapvar_res_t *res,
+                          std::vector<pga_sub_t> &h_subs, std::vector<pga_del_t> &h_dels, std::vector<pga_ins_t> &h_inss, std::vector<char> &h_seq, hipStream_t st);
+
 void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapvar_params_t &prm, pga_mapvar_res_t *res,
                          std::vector<pga_sub_t> &h_subs, std::vector<pga_del_t> &h_dels, std::vector<pga_ins_t> &h_inss, std::vector<char> &h_seq)
 {
@@ -516,6 +520,36 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 	d_ascii.upload(stage.data(), cat_size, st);
 	d_codes.alloc(cat_size + 64);
 	if (cat_size) k_mv_encode<<<(unsigned)std::min<size_t>((cat_size + 255) / 256, 65535), 256, 0, st>>>(d_ascii.p, cat_size, d_codes.p);
+	mv_run_rounds(pending, d_codes.p, prm, res, h_subs, h_dels, h_inss, h_seq, st);
+}
+
+// The same with the letters already in device memory (reconsensus builds the new consensus and the member sequences there): jobs address
+// d_ascii[ref_off .. + ref_len) / d_ascii[qry_off .. + qry_len); band_width is the caller's (extra_band_width is added here as above).
+void map_variations_dev(int64_t n, const MvDevJob *jobs, const char *d_ascii, uint64_t cat_size, const pga_mapvar_params_t &prm, pga_mapvar_res_t *res,
+                        std::vector<pga_sub_t> &h_subs, std::vector<pga_del_t> &h_dels, std::vector<pga_ins_t> &h_inss, std::vector<char> &h_seq, hipStream_t st)
+{
+	if (prm.penalty_gap_open < 0 || prm.penalty_gap_extend < 0 || prm.score_match < 0 || prm.penalty_mismatch < 0) throw std::runtime_error("pga_map_variations: negative score parameter");
+	if (prm.max_alignment_attempts < 1) throw std::runtime_error("pga_map_variations: max_alignment_attempts must be at least 1");
+	std::vector<MvJob> pending((size_t)n);
+	for (int64_t i = 0; i < n; ++i) {
+		const MvDevJob &j = jobs[i];
+		if (j.ref_len >= (1u << 30) || j.qry_len >= (1u << 30)) throw std::runtime_error("pga_map_variations: sequence longer than 2^30");
+		if ((uint64_t)std::min(prm.penalty_gap_extend, prm.penalty_gap_open) * ((uint64_t)j.qry_len + 1) >= (1ULL << 29)) throw std::runtime_error("pga_map_variations: gap extension penalty times query length overflows the score type");
+		MvJob &J = pending[(size_t)i];
+		J.ref_off = j.ref_off; J.qry_off = j.qry_off; J.ref_len = j.ref_len; J.qry_len = j.qry_len; J.ms = j.mean_shift;
+		const uint64_t cap = (uint64_t)j.ref_len + j.qry_len + (uint64_t)std::llabs((long long)j.mean_shift) + 2;
+		J.bw = (uint32_t)std::min<uint64_t>((uint64_t)j.band_width + (uint64_t)std::max(prm.extra_band_width, 0), cap);
+		J.attempt = 1; J.orig = (uint32_t)i;
+	}
+	DBuf<uint8_t> d_codes(cat_size + 64);
+	if (cat_size) k_mv_encode<<<(unsigned)std::min<size_t>((cat_size + 255) / 256, 65535), 256, 0, st>>>(d_ascii, cat_size, d_codes.p);
+	mv_run_rounds(pending, d_codes.p, prm, res, h_subs, h_dels, h_inss, h_seq, st);
+}
+
+static void mv_run_rounds(std::vector<MvJob> &pending, const uint8_t *d_codes_p, const pga_mapvar_params_t &prm, pga_mapvar_res_t *res,
+                          std::vector<pga_sub_t> &h_subs, std::vector<pga_del_t> &h_dels, std::vector<pga_ins_t> &h_inss, std::vector<char> &h_seq, hipStream_t st)
+{
+	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	const MvParams P{prm.score_match, prm.penalty_mismatch, prm.penalty_gap_open, prm.penalty_gap_extend, prm.left_terminal_gaps_free != 0, prm.right_terminal_gaps_free != 0,
 	                 prm.gap_align_left != 0, prm.min_length, prm.max_alignment_attempts};
 	const char *eb = getenv("PGA_MAPVAR_SLAB_GB");
@@ -563,8 +597,8 @@ void map_variations_host(int64_t n, const pga_mapvar_job_t *jobs, const pga_mapv
 			int32_t *gr = nullptr;
 			if (cls == 0) { keep_rings.emplace_back(n_slots * (size_t)ring_n * 3); gr = keep_rings.back().p; }
 			if (verbose) fprintf(stderr, "[pga]   map_variations round %d: %zu jobs, %s %d, slab %.1f KB x %zu waves\n", round, nj, pack > 1 ? "segments of" : "ring", cls ? cls : ring_n, slab_bytes / 1024.0, n_slots);
-#define MV_LAUNCH(R) k_mapvar<R><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes.p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, gr, ring_n, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
-#define MV_LAUNCH_P(SG) k_mapvar_packed<SG><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes.p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
+#define MV_LAUNCH(R) k_mapvar<R><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes_p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, gr, ring_n, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
+#define MV_LAUNCH_P(SG) k_mapvar_packed<SG><<<(unsigned)n_slots, 64, 0, st>>>(d_jobs.p + s0, (int)nj, P, d_codes_p, keep_ctr.back().p, keep_slabs.back().p, slab_bytes, d_out.p + s0, d_cur.p, caps, d_subs.p, d_dels.p, d_inss.p, d_seq.p)
 			if (cls == 16) MV_LAUNCH_P(16); else if (cls == 32) MV_LAUNCH_P(32);
 			else if (cls == 128) MV_LAUNCH(128); else if (cls == 512) MV_LAUNCH(512); else if (cls == 2048) MV_LAUNCH(2048); else MV_LAUNCH(0);
 #undef MV_LAUNCH
