@@ -338,62 +338,6 @@ static void trim_chain_ends(const Reg &r, const Anchors &A, int bw, int min_matc
 	}
 }
 
-// striped int16 local alignment (ksw2_ll_sse.c:37-152), evaluated lane by lane (derivation: oracle/pgo_ksw.c); only for the rare
-// windows the device kernel does not take (pga_ll.hip holds PGA_LL_MAX_LEN bases)
-static inline int16_t adds16(int a, int b) { int s = a + b; return (int16_t)(s > 32767 ? 32767 : s < -32768 ? -32768 : s); }
-static inline int16_t subsu16(int16_t a, int16_t b) { uint16_t x = (uint16_t)a, y = (uint16_t)b; return (int16_t)(x > y ? x - y : 0); }
-static inline int16_t max16(int16_t a, int16_t b) { return a > b ? a : b; }
-static int ll_i16(int qlen, const uint8_t *query, const int8_t *mat, int tlen, const uint8_t *target, int gapo, int gape, int *qe, int *te)
-{
-	const int m = 5, slen = (qlen + 7) / 8, qlen8 = slen * 8;
-	int gmax = 0;
-	std::vector<int16_t> prof((size_t)m * qlen8), H0v((size_t)qlen8, 0), H1v((size_t)qlen8, 0), E((size_t)qlen8, 0), Hmax((size_t)qlen8, 0);
-	int16_t *H0 = H0v.data(), *H1 = H1v.data();
-	const int16_t gapoe = (int16_t)(gapo + gape), ge = (int16_t)gape;
-	for (int a = 0; a < m; ++a) for (int j = 0; j < slen; ++j) for (int l = 0; l < 8; ++l) {
-		int pos = j + l * slen; prof[((size_t)a * slen + j) * 8 + l] = pos >= qlen ? 0 : mat[a * m + query[pos]];
-	}
-	*qe = *te = -1;
-	for (int i = 0; i < tlen; ++i) {
-		int16_t f[8], h[8], mx[8], e[8];
-		const int16_t *S = prof.data() + (size_t)target[i] * slen * 8;
-		bool done = false;
-		for (int l = 0; l < 8; ++l) f[l] = 0, mx[l] = 0;
-		h[0] = 0; for (int l = 1; l < 8; ++l) h[l] = H0[(slen - 1) * 8 + l - 1];
-		for (int j = 0; j < slen; ++j) for (int l = 0; l < 8; ++l) {
-			int16_t hh = adds16(h[l], S[j * 8 + l]);
-			e[l] = E[j * 8 + l];
-			hh = max16(hh, e[l]); hh = max16(hh, f[l]);
-			mx[l] = max16(mx[l], hh);
-			H1[j * 8 + l] = hh;
-			hh = subsu16(hh, gapoe);
-			e[l] = max16(subsu16(e[l], ge), hh); E[j * 8 + l] = e[l];
-			f[l] = max16(subsu16(f[l], ge), hh);
-			h[l] = H0[j * 8 + l];
-		}
-		for (int k = 0; k < 8 && !done; ++k) {
-			for (int l = 7; l > 0; --l) f[l] = f[l - 1];
-			f[0] = 0;
-			for (int j = 0; j < slen; ++j) {
-				bool any = false;
-				for (int l = 0; l < 8; ++l) {
-					int16_t hh = max16(H1[j * 8 + l], f[l]);
-					H1[j * 8 + l] = hh;
-					hh = subsu16(hh, gapoe);
-					f[l] = subsu16(f[l], ge);
-					if (f[l] > hh) any = true;
-				}
-				if (!any) { done = true; break; }
-			}
-		}
-		int imax = 0; for (int l = 0; l < 8; ++l) if (mx[l] > imax) imax = mx[l];
-		if (imax >= gmax) { gmax = imax, *te = i; memcpy(Hmax.data(), H1, (size_t)qlen8 * 2); }
-		std::swap(H0, H1);
-	}
-	for (int i = 0; i < qlen8; ++i) if ((int)(uint16_t)Hmax[i] == gmax) *qe = i / 8 + i % 8 * slen;
-	return gmax;
-}
-
 static inline bool ll_on_device(const mm_mapopt_t &opt, int q_len, int t_len)
 {
 	const int q8 = (q_len + 7) / 8 * 8;
@@ -621,19 +565,13 @@ struct Driver {
 	int second_pass(QueryCtx &Q, const RegTask &T, const Seg &sg, int zdrop) { return request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, zdrop, 0); }
 	int zcode_of(const Seg &sg, int ll_score) const { return (ll_score >= opt.min_chain_score * opt.a && ll_score >= opt.min_dp_max) ? 2 : (sg.max_zdrop > opt.zdrop ? 1 : 0); }
 
-	// the rare local alignment the device kernel does not take: both windows come back from the device
-	int ll_on_host(QueryCtx &Q, int q_strand, int32_t q_start, int q_len, int rid, int32_t t_start, int t_len, bool reversed, int *q_end, int *t_end)
+	// A local alignment (ksw_ll_i16) over windows the device kernel does not hold.  Unreachable from pangraph's options -- both windows are
+	// bounded by max_gap = 10 000 under every asm preset (align.c:81-82, 845-855; PGA_LL_MAX_LEN = 10 240) -- so it is refused, loudly,
+	// instead of being computed somewhere else: this library has no host path for base work.
+	int ll_on_host(QueryCtx &, int, int32_t, int q_len, int, int32_t, int t_len, bool, int *, int *)
 	{
-		std::vector<uint8_t> tw, qw, raw;
-		post_fetch(S.d_nt4.p, S.off[(size_t)(Q.base + rid)] + (uint64_t)t_start, (size_t)t_len, tw, st);
-		if (!q_strand) post_fetch(S.d_nt4.p, S.off[(size_t)Q.qid] + (uint64_t)q_start, (size_t)q_len, qw, st);
-		else {
-			post_fetch(S.d_nt4.p, S.off[(size_t)Q.qid] + (uint64_t)(Q.qlen - q_start - q_len), (size_t)q_len, raw, st);
-			qw.resize(raw.size());
-			for (int i = 0; i < q_len; ++i) { const uint8_t c = raw[(size_t)(q_len - 1 - i)]; qw[(size_t)i] = c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; }
-		}
-		if (reversed) { std::reverse(qw.begin(), qw.end()); std::reverse(tw.begin(), tw.end()); }
-		return ll_i16(q_len, qw.data(), mat, t_len, tw.data(), opt.q, opt.e, q_end, t_end);
+		throw std::runtime_error("pga: ksw_ll_i16 over windows of " + std::to_string(q_len) + " x " + std::to_string(t_len) + " bases: the device kernel holds " + std::to_string(PGA_LL_MAX_LEN) +
+		                         " (max_gap above 10000 is outside pangraph's presets)");
 	}
 
 	void ask_finish(QueryCtx &Q, RegTask &T, int rid, int32_t t_start, int32_t q_start, int q_rev)
@@ -828,7 +766,7 @@ struct RoundRunner {
 		});
 		PinVec<int32_t> m;
 		const double t0 = wall_s();
-		post_identity(S.d_nt4.p, pr, D.probe_m_max, m, st);
+		post_identity(S.bases(), pr, D.probe_m_max, m, st);
 		std::atomic<size_t> n_yes(0);
 		parallel_for(n_q, n_threads, [&](size_t k) {
 			QueryCtx &q = Q[(size_t)qs[k]]; size_t o = off[k], w = 0, yes = 0;
@@ -864,7 +802,7 @@ struct RoundRunner {
 		pools.emplace_back();
 		PinVec<uint32_t> &cg = pools.back();
 		const double t_dp = wall_s();
-		dp_run(S.d_nt4.p, jb, P, rs, cg, st, tm);
+		dp_run(S.bases(), jb, P, rs, cg, st, tm);
 		if (verbose) fprintf(stderr, "[pga]   set %d round %d: %zu DP problems in %.3f s\n", set_id, round, jb.size(), wall_s() - t_dp);
 		if (tm) { tm->dp_jobs += (double)jb.size(); for (double c : cells_of) tm->dp_cells += c; }
 		const uint32_t *base = cg.data();
@@ -958,7 +896,7 @@ struct RoundRunner {
 		const double t0 = wall_s();
 		if (!walks.empty()) {
 			std::vector<PostWalkRes> wr;
-			post_zdrop_walk(S.d_nt4.p, walks, wcig, P, wr, st);
+			post_zdrop_walk(S.bases(), walks, wcig, P, wr, st);
 			for (size_t i = 0; i < wask.size(); ++i) {
 				Seg &sg = wask[i].T->segs[wask[i].seg];
 				sg.max_zdrop = wr[i].max_zdrop, sg.wt0 = wr[i].t0, sg.wt1 = wr[i].t1, sg.wq0 = wr[i].q0, sg.wq1 = wr[i].q1; sg.walk = 2;
@@ -968,7 +906,7 @@ struct RoundRunner {
 			PinVec<uint32_t> ops; ops.resize(fin_ops);
 			parallel_for(ftask.size(), n_threads, [&](size_t i) { const auto &c = ftask[i]->r.cigar; if (!c.empty()) memcpy(ops.data() + fins[i].cig_off, c.data(), c.size() * 4); });
 			std::vector<PostFinRes> fr;
-			post_cigar_finish(S.d_nt4.p, fins, ops, P, fr, st);
+			post_cigar_finish(S.bases(), fins, ops, P, fr, st);
 			parallel_for(ftask.size(), n_threads, [&](size_t i) {
 				RegTask &T = *ftask[i]; Reg &r = T.r; const PostFinRes &f = fr[i];
 				r.cigar.assign(ops.data() + fins[i].cig_off, ops.data() + fins[i].cig_off + f.n_cigar);

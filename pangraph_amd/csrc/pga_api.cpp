@@ -98,7 +98,7 @@ struct PgaIdx {
 	int arena = 0;                   // device-memory arena of the index, leased for its lifetime (pga_mem.cpp)
 	PgaIdx() : arena(dev_lease_arena()) {}
 	~PgaIdx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } release_buffers(); dev_release_arena(arena); }
-	void release_buffers() { S.d_nt4.release(); S.d_pk2.release(); S.d_nmask.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
+	void release_buffers() { S.d_pk2.release(); S.d_nmask.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
 		I.key.release(); I.occ_off.release(); I.occ.release(); I.key_grp.release(); grp.release(); d_name_rank.release(); d_mid_occ.release(); }
 };
 
@@ -602,7 +602,7 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 {
 	try {
 		require_device();
-		// lay the explicit sequences out as one nt4 array: query i then target i
+		// lay the explicit sequences (base codes 0..4) out one behind the other, query i then target i, and pack them as the resident store is packed
 		std::vector<uint8_t> buf; std::vector<DpJob> jobs((size_t)n_jobs);
 		for (int i = 0; i < n_jobs; ++i) {
 			DpJob &j = jobs[i]; memset(&j, 0, sizeof(j));
@@ -610,14 +610,17 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 			j.t_off = buf.size(); buf.insert(buf.end(), t[i], t[i] + tlen[i]);
 			j.qlen_full = qlen[i], j.qs = 0, j.qlen = qlen[i], j.tlen = tlen[i], j.w = w[i], j.zdrop = zdrop[i], j.end_bonus = end_bonus[i], j.flag = flag[i];
 		}
-		buf.resize(buf.size() + 64, 4);
-		DBuf<uint8_t> d; d.upload(buf, 0);
+		buf.resize((buf.size() + 15) / 16 * 16 + 128, 4);
+		std::vector<uint32_t> pk(buf.size() / 16, 0u); std::vector<uint16_t> nm(buf.size() / 16, 0);
+		for (size_t i = 0; i < buf.size(); ++i) { const uint8_t c = buf[i]; if (c > 3) nm[i >> 4] |= (uint16_t)(1u << (i & 15)); else pk[i >> 4] |= (uint32_t)c << (2 * (i & 15)); }
+		DBuf<uint32_t> d_pk; d_pk.upload(pk, 0); DBuf<uint16_t> d_nm; d_nm.upload(nm, 0);
+		const PkBases d{d_pk.p, d_nm.p};
 		a = a < 0 ? -a : a; b = b > 0 ? -b : b; sc_ambi = sc_ambi > 0 ? -sc_ambi : sc_ambi;
 		DpParams P{gapo, gape, gapo2, gape2, a, b, sc_ambi};
 		std::vector<DpJob> run; std::vector<int> idx;
 		for (int i = 0; i < n_jobs; ++i) if (qlen[i] > 0 && tlen[i] > 0) run.push_back(jobs[i]), idx.push_back(i);
 		std::vector<DpRes> res; PinVec<uint32_t> cg;
-		dp_run(d.p, run, P, res, cg, 0);
+		dp_run(d, run, P, res, cg, 0);
 		std::vector<uint32_t> all;
 		for (int i = 0; i < n_jobs; ++i) { int32_t *e = ez + 12 * i; e[0] = 0; e[1] = e[2] = -1; e[3] = -0x40000000; e[4] = -1; e[5] = -0x40000000; e[6] = -1; e[7] = -0x40000000; e[8] = e[9] = e[10] = e[11] = 0; cigar_off[i] = 0; }
 		for (size_t r = 0; r < res.size(); ++r) {

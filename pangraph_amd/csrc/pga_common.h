@@ -87,16 +87,29 @@ template <class T> static inline void download_to(PinVec<T> &h, const T *d, size
 }
 
 // ---- the sequence set of one batch, resident in HBM ----
+
+// The resident sequence store (pga_sketch.hip: k_encode_pk): 2 bits per base, sixteen bases per 32-bit word, plus one "not ACGT" bit per
+// base -- every kernel of the path reads bases from it (0..3 = ACGT, 4 = anything else: the codes of sketch.c:9-26).
+struct PkBases {
+	const uint32_t *pk2; const uint16_t *nmask;
+	__device__ __forceinline__ int at(uint64_t pos) const
+	{
+		const uint64_t w = pos >> 4; const uint32_t sft = (uint32_t)pos & 15u;
+		const uint32_t b = pk2[w], n = nmask[w];
+		return ((n >> sft) & 1u) ? 4 : (int)((b >> (2u * sft)) & 3u);
+	}
+};
+
 struct SeqSet {
 	int n_seq = 0;
 	uint64_t total = 0;                 // sum of lengths
-	std::vector<uint64_t> off;          // n_seq+1 offsets into nt4
+	std::vector<uint64_t> off;          // n_seq+1 offsets into the concatenation of all sequences (base positions of the packed store)
 	std::vector<uint32_t> len;
 	std::vector<std::string> name;
 	std::vector<uint8_t> probe;         // 64 base codes per sequence at evenly spaced positions (mm_map's identity check); the host keeps no other copy of the bases
-	DBuf<uint8_t> d_nt4;                // 1 byte per base: 0..3 ACGT, 4 other (sketch.c:9-26 table)
 	DBuf<uint32_t> d_pk2;               // the packed store: 2 bits per base, sixteen bases per word (word i = bases 16i .. 16i+15 of the concatenation)
 	DBuf<uint16_t> d_nmask;             // ... and one bit per base: 1 = not ACGT
+	PkBases bases() const { return PkBases{d_pk2.p, d_nmask.p}; }
 	DBuf<uint64_t> d_off;
 	DBuf<uint32_t> d_len;
 	// groups: independent all-vs-all problems sharing the batch (one group == one find_matches call)

@@ -5,7 +5,7 @@
 namespace pga {
 
 // One ksw_extd2 call (reference: align.c:316-344 mm_align_pair).  Sequences are NOT copied: a problem names
-// windows of the resident nt4 array; reversal (left extension, align.c:711-713) and reverse-complement
+// windows of the resident packed store (PkBases); reversal (left extension, align.c:711-713) and reverse-complement
 // (align.c:970-975) are index transforms applied by the kernel when it reads a base.
 struct DpJob {
 	uint64_t t_off;      // offset of the target window's first base (forward coordinates)
@@ -33,6 +33,6 @@ struct DpRes {           // ksw_extz_t (ksw2.h:31-40)
 struct DpParams { int32_t q, e, q2, e2, sc_mch, sc_mis, sc_ambi; }; // sc_* are matrix entries mat[0], mat[1], mat[24]
 
 size_t dp_slab_bytes(int qlen, int tlen, int w);
-void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm = nullptr);
+void dp_run(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm = nullptr);
 
 } // namespace pga

@@ -36,18 +36,18 @@ namespace pga {
 __device__ __forceinline__ int sx8(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
 
 struct SeqView {
-	const uint8_t *t_base, *q_base;   // target window start / query sequence start in the resident nt4 array
+	PkBases nt; uint64_t t_base, q_base;   // the packed store; target window start / query sequence start in it
 	int32_t qlen_full, qs, qlen, tlen;
 	bool q_rev, seq_rev;
 	__device__ __forceinline__ int target(int i) const { // 0 beyond the window (the reference's zero padding)
 		if (i >= tlen) return 0;
-		return t_base[seq_rev ? tlen - 1 - i : i];
+		return nt.at(t_base + (uint64_t)(seq_rev ? tlen - 1 - i : i));
 	}
 	__device__ __forceinline__ int query(int j) const {
 		if (j < 0 || j >= qlen) return 0;
 		int pj = qs + (seq_rev ? qlen - 1 - j : j);
-		if (!q_rev) return q_base[pj];
-		int c = q_base[qlen_full - 1 - pj];
+		if (!q_rev) return nt.at(q_base + (uint64_t)(pj));
+		int c = nt.at(q_base + (uint64_t)(qlen_full - 1 - pj));
 		return c < 4 ? 3 - c : 4;
 	}
 };
@@ -76,7 +76,7 @@ __device__ __forceinline__ long long wave_max64(long long v)
 #define LDS_T 2048   // problems with tlen16 <= LDS_T keep their rows in LDS
 
 __global__ __launch_bounds__(64)
-void k_extd2(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+void k_extd2(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, DpParams P,
              uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes,
              DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
@@ -94,7 +94,7 @@ void k_extd2(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__r
 		if (jid >= n_jobs) break;
 		const DpJob J = jobs[jid];
 		SeqView V;
-		V.t_base = nt4 + J.t_off, V.q_base = nt4 + J.q_off, V.qlen_full = J.qlen_full, V.qs = J.qs, V.qlen = J.qlen, V.tlen = J.tlen;
+		V.nt = bases, V.t_base = J.t_off, V.q_base = J.q_off, V.qlen_full = J.qlen_full, V.qs = J.qs, V.qlen = J.qlen, V.tlen = J.tlen;
 		V.q_rev = J.q_rev, V.seq_rev = J.seq_rev;
 		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
 		int w = J.w;
@@ -331,11 +331,11 @@ size_t dp_slab_bytes(int qlen, int tlen, int w)
 	return (b + 255) & ~(size_t)255;
 }
 
-void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact);
-void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 // Problem classes (each is one persistent launch):
@@ -363,25 +363,25 @@ static inline int wide_ring(const DpJob &j)
 }
 static inline int wide_seqcap(const DpJob &j) { return ((j.qlen > j.tlen ? j.qlen : j.tlen) + 15) / 16 * 16; }
 size_t ll_lds_bytes(int t_cap);
-void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter,
+void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter,
                    unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st);
 
 #define BAND_MAXLEN 1024
 size_t band_slab_bytes(int max_diag);
-void launch_gapfill_band(unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_gapfill_band(unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                          DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 bool strips_eligible(const DpJob &j, const DpParams &P);
 size_t strips_slab_bytes(const DpJob &j);
 int strips_count(const DpJob &j);
 size_t strips_bnd_words(const DpJob &j);
-void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, const uint8_t *nt4, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
+void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                           uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 bool lanes_eligible(const DpJob &j, int nt);
 size_t lanes_cig_bytes(int q_cap, int t_cap);
 size_t lanes_chunk_bytes();
-void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
+void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
 static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
@@ -417,7 +417,7 @@ template <class F> static void host_parallel(size_t n, F f)
 	for (auto &t : th) t.join();
 }
 
-static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band);
+static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band);
 
 // Launch lanes: four priority streams (lane 0, the million-tile classes, at the lower priority) and four grow-only scratch slabs per SET.
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
@@ -461,9 +461,9 @@ struct LaneLease {
 	LaneLease(const LaneLease&) = delete; LaneLease &operator=(const LaneLease&) = delete;
 };
 
-void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
+void dp_run(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
-	dp_run_impl(d_nt4, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr);
+	dp_run_impl(d_bases, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr);
 	// problems the corridor kernel could not prove exact: full matrix, results spliced in (their CIGARs go behind the pool)
 	std::vector<uint32_t> redo;
 	for (size_t i = 0; i < res.size(); ++i) if (res[i].n_cigar == -9) redo.push_back((uint32_t)i);
@@ -472,14 +472,14 @@ void dp_run(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams
 	std::vector<DpJob> jb(redo.size());
 	for (size_t k = 0; k < redo.size(); ++k) jb[k] = jobs[redo[k]];
 	std::vector<DpRes> r2; PinVec<uint32_t> c2;
-	dp_run_impl(d_nt4, jb, P, r2, c2, st, tm, false);
+	dp_run_impl(d_bases, jb, P, r2, c2, st, tm, false);
 	const size_t base = cigars.size();
 	cigars.resize(base + c2.size());
 	if (c2.size()) memcpy(cigars.data() + base, c2.data(), c2.size() * sizeof(uint32_t));
 	for (size_t k = 0; k < redo.size(); ++k) { res[redo[k]] = r2[k]; res[redo[k]].cigar_off += base; }
 }
 
-static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band)
+static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band)
 {
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
@@ -638,17 +638,17 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			X.d_blk_job.upload(bj, cs); X.d_blk_strip.upload(bs, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs);
 			X.d_bnd.alloc((size_t)b_acc + 1); X.d_bnd.zero(cs);
 			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
-			launch_approx_strips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_nt4, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_approx_strips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
 			int t_cap = 16;
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
-			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
-		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
+		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 10 || c == 11) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_extd2_lanes(c == 11 ? 1024 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_extd2_lanes(c == 11 ? 1024 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
@@ -664,8 +664,8 @@ static void dp_run_impl(const uint8_t *d_nt4, const std::vector<DpJob> &jobs, co
 			if (getenv("PGA_WIDE_NT")) nt = atoi(getenv("PGA_WIDE_NT"));
 			else if (c == 3) nt = 512;
 			X.nt = nt;
-			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_nt4, P, X.d_cnt.p, slab_p, slab_max[c],
+			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c],
 		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipEventRecord(X.e1, cs));

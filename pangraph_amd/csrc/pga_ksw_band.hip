@@ -37,7 +37,7 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t last) { return _
 __device__ __forceinline__ int band_gap(int n, int q, int e, int q2, int e2) { if (n <= 0) return 0; const int a = q + e * n, b = q2 + e2 * n; return a < b ? a : b; }
 
 __global__ __launch_bounds__(64)
-void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, DpParams P,
                     uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes,
                     DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
@@ -61,12 +61,12 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
 		const int qlen = on ? J.qlen : 0, tlen = on ? J.tlen : 0;
 		// sequences into LDS (orientation resolved here)
 		{
-			const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
-			for (int i = gl; i < tlen; i += 32) s_t[g][i] = t_base[J.seq_rev ? tlen - 1 - i : i];
+			const uint64_t t_base = J.t_off, q_base = J.q_off;          // base positions in the packed store
+			for (int i = gl; i < tlen; i += 32) s_t[g][i] = bases.at(t_base + (uint64_t)(J.seq_rev ? tlen - 1 - i : i));
 			for (int jx = gl; jx < qlen; jx += 32) {
 				const int pj = J.qs + (J.seq_rev ? qlen - 1 - jx : jx);
 				int c;
-				if (!J.q_rev) c = q_base[pj]; else { c = q_base[J.qlen_full - 1 - pj]; c = c < 4 ? 3 - c : 4; }
+				if (!J.q_rev) c = bases.at(q_base + (uint64_t)(pj)); else { c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj)); c = c < 4 ? 3 - c : 4; }
 				s_q[g][jx] = (uint8_t)c;
 			}
 		}
@@ -228,10 +228,10 @@ void k_gapfill_band(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8
 
 size_t band_slab_bytes(int max_diag) { return ((size_t)2 * max_diag * 32 + 255) & ~(size_t)255; }
 
-void launch_gapfill_band(unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_gapfill_band(unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                          DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_gapfill_band, dim3(n_waves), dim3(64), 0, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, res, pool, cursor, pool_cap);
+	hipLaunchKernelGGL(k_gapfill_band, dim3(n_waves), dim3(64), 0, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

@@ -44,7 +44,7 @@ __device__ __forceinline__ long long wave_max64f(long long v)
 
 template <int C>
 __global__ __launch_bounds__(64)
-void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, DpParams P,
                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes,
                   DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
@@ -67,7 +67,7 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		jid = (uint32_t)__shfl((int)jid, 0);
 		if (jid >= n_jobs) break;
 		const DpJob J = jobs[jid];
-		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
+		const uint64_t t_base = J.t_off, q_base = J.q_off;          // base positions in the packed store
 		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
 		const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
 		const int w = J.w;
@@ -76,12 +76,12 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		uint8_t *pmat = slab;
 		uint32_t *cig_tmp = (uint32_t*)(pmat + (((size_t)(qlen + tlen - 1) * n_col + 15) & ~(size_t)15));
 
-		auto target_at = [&](int i) -> int { return i < tlen ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 0; };
+		auto target_at = [&](int i) -> int { return i < tlen ? (int)bases.at(t_base + (uint64_t)(J.seq_rev ? tlen - 1 - i : i)) : 0; };
 		auto query_at = [&](int j) -> int {
 			if (j < 0 || j >= qlen) return 0;
 			int pj = J.qs + (J.seq_rev ? qlen - 1 - j : j);
-			if (!J.q_rev) return q_base[pj];
-			int c = q_base[J.qlen_full - 1 - pj];
+			if (!J.q_rev) return bases.at(q_base + (uint64_t)(pj));
+			int c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj));
 			return c < 4 ? 3 - c : 4;
 		};
 
@@ -450,11 +450,11 @@ void k_extd2_fast(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 	}
 }
 
-void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_extd2_fast(int C, unsigned n_waves, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
-	if (C <= 4) hipLaunchKernelGGL((k_extd2_fast<4>), dim3(n_waves), dim3(64), 0, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, res, pool, cursor, pool_cap);
-	else hipLaunchKernelGGL((k_extd2_fast<8>), dim3(n_waves), dim3(64), 0, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, res, pool, cursor, pool_cap);
+	if (C <= 4) hipLaunchKernelGGL((k_extd2_fast<4>), dim3(n_waves), dim3(64), 0, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, res, pool, cursor, pool_cap);
+	else hipLaunchKernelGGL((k_extd2_fast<8>), dim3(n_waves), dim3(64), 0, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

@@ -68,7 +68,7 @@ struct __attribute__((aligned(16))) LaneRec {      // what a wave publishes per 
 
 template <int NT>
 __global__ __launch_bounds__(NT)
-void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, DpParams P,
                    uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t cig_bytes, uint32_t n_chunks_arg, int q_cap,
                    DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
@@ -111,7 +111,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 		const uint32_t jid = s_job;
 		if (jid >= n_jobs) break;
 		const DpJob J = jobs[jid];
-		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
+		const uint64_t t_base = J.t_off, q_base = J.q_off;          // base positions in the packed store
 		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
 		const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
 		int w = J.w;
@@ -119,11 +119,11 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_
 		const int T = (tlen + 15) / 16 * 16;
 		int n_col = qlen < tlen ? qlen : tlen;
 		n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
-		auto target_at = [&](int i) -> uint32_t { return (i >= 0 && i < tlen) ? (uint32_t)t_base[J.seq_rev ? tlen - 1 - i : i] : 0u; };
+		auto target_at = [&](int i) -> uint32_t { return (i >= 0 && i < tlen) ? (uint32_t)bases.at(t_base + (uint64_t)(J.seq_rev ? tlen - 1 - i : i)) : 0u; };
 		auto query_at = [&](int j) -> int {
 			int pj = J.qs + (J.seq_rev ? qlen - 1 - j : j);
-			if (!J.q_rev) return q_base[pj];
-			int c = q_base[J.qlen_full - 1 - pj];
+			if (!J.q_rev) return bases.at(q_base + (uint64_t)(pj));
+			int c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj));
 			return c < 4 ? 3 - c : 4;
 		};
 		for (int j = tid; j < qlen; j += NT) qq[j] = (uint8_t)query_at(j);
@@ -551,20 +551,20 @@ bool lanes_eligible(const DpJob &j, int nt)
 size_t lanes_cig_bytes(int q_cap, int t_cap) { return (4 * ((size_t)q_cap + t_cap + 8) + 255) & ~(size_t)255; }
 size_t lanes_chunk_bytes() { return LANES_CHUNK; }
 
-template <int NT> static void launch_lanes_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab,
+template <int NT> static void launch_lanes_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab,
                                               size_t cig_bytes, uint32_t n_chunks, int q_cap, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
 {
 	static bool attr_set = false;
 	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_lanes<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
-	hipLaunchKernelGGL(k_extd2_lanes<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, cig_bytes, n_chunks, q_cap, res, pool, cursor, pool_cap);
+	hipLaunchKernelGGL(k_extd2_lanes<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, bases, P, counter, slab, cig_bytes, n_chunks, q_cap, res, pool, cursor, pool_cap);
 }
 
-void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
+void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
 	const size_t lds = (((size_t)q_cap + 15) & ~(size_t)15) + (((size_t)t_cap + 15) & ~(size_t)15) + 16;
-	if (nt >= 1024) launch_lanes_nt<1024>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
-	else launch_lanes_nt<256>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
+	if (nt >= 1024) launch_lanes_nt<1024>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
+	else launch_lanes_nt<256>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

@@ -37,7 +37,7 @@ __device__ __forceinline__ void st_range(int r, int qlen, int tlen, int &st0, in
 }
 
 __global__ __launch_bounds__(ST_NTL)
-void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_job, const uint32_t *__restrict__ blk_strip, const uint8_t *__restrict__ nt4, DpParams P,
+void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_job, const uint32_t *__restrict__ blk_strip, PkBases bases, DpParams P,
                      uint8_t *__restrict__ slab_all, const uint64_t *__restrict__ slab_off, uint32_t *__restrict__ bnd_all, const uint64_t *__restrict__ bnd_off,
                      uint32_t *__restrict__ done_ctr, DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
@@ -58,7 +58,7 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t jl = blk_job[blockIdx.x], k = blk_strip[blockIdx.x];
 	const DpJob J = jobs[jl];
-	const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
+	const uint64_t t_base = J.t_off, q_base = J.q_off;          // base positions in the packed store
 	const int qlen = J.qlen, tlen = J.tlen;
 	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
 	if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t, t = e, e = e2, e2 = t; }
@@ -84,12 +84,12 @@ void k_approx_strips(const DpJob *__restrict__ jobs, const uint32_t *__restrict_
 	uint32_t *keys = keys_all + (size_t)k * Ld;
 	int32_t *hen_arr = (int32_t*)(keys_all + (size_t)n_strips * Ld), *hst_arr = hen_arr + Ld;
 	uint32_t *hb_all = (uint32_t*)(hst_arr + Ld);
-	auto target_at = [&](int i) -> int { return i < tlen ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 0; };
+	auto target_at = [&](int i) -> int { return i < tlen ? (int)bases.at(t_base + (uint64_t)(J.seq_rev ? tlen - 1 - i : i)) : 0; };
 	auto query_at = [&](int j) -> int {
 		if (j < 0 || j >= qlen) return 0;
 		const int pj = J.qs + (J.seq_rev ? qlen - 1 - j : j);
-		if (!J.q_rev) return q_base[pj];
-		const int c = q_base[J.qlen_full - 1 - pj];
+		if (!J.q_rev) return bases.at(q_base + (uint64_t)(pj));
+		const int c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj));
 		return c < 4 ? 3 - c : 4;
 	};
 	for (int t = tid; t < ST_S + 16; t += ST_NTL) {
@@ -443,10 +443,10 @@ size_t strips_bnd_words(const DpJob &j)
 	return (ns > 1 ? ns - 1 : 0) * L + ((j.flag & 0x08) ? 0 : ns * L + 2 * L + ns + 8);      // exact mode: keys, H of the first / last column per diagonal, hand-off words
 }
 
-void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, const uint8_t *nt4, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
+void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                           uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_approx_strips, dim3(n_blocks), dim3(ST_NTL), 0, st, jobs, blk_job, blk_strip, nt4, P, slab, slab_off, bnd, bnd_off, done_ctr, res, pool, cursor, pool_cap);
+	hipLaunchKernelGGL(k_approx_strips, dim3(n_blocks), dim3(ST_NTL), 0, st, jobs, blk_job, blk_strip, bases, P, slab, slab_off, bnd, bnd_off, done_ctr, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

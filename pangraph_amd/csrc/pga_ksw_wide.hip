@@ -48,7 +48,7 @@ __device__ int g_wide_no_fused = 0;   // PGA_NO_FUSED_APPROX=1 (A/B): the unband
 
 template <int WIDE_NT>
 __global__ __launch_bounds__(WIDE_NT)
-void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P,
+void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, DpParams P,
                   uint32_t *__restrict__ job_counter, uint8_t *__restrict__ slab_all, size_t slab_bytes, int r_cap, int seq_cap, int exact_rows,
                   DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
@@ -77,7 +77,7 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		const uint32_t jid = s_job;
 		if (jid >= n_jobs) break;
 		const DpJob J = jobs[jid];
-		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
+		const uint64_t t_base = J.t_off, q_base = J.q_off;          // base positions in the packed store
 		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
 		const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
 		int w = J.w;
@@ -85,12 +85,12 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 		const int T = (tlen + 15) / 16 * 16;
 		int n_col = qlen < tlen ? qlen : tlen;
 		n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
-		auto target_at = [&](int i) -> int { return i < tlen ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 0; };
+		auto target_at = [&](int i) -> int { return i < tlen ? (int)bases.at(t_base + (uint64_t)(J.seq_rev ? tlen - 1 - i : i)) : 0; };
 		auto query_at = [&](int j) -> int {
 			if (j < 0 || j >= qlen) return 0;
 			int pj = J.qs + (J.seq_rev ? qlen - 1 - j : j);
-			if (!J.q_rev) return q_base[pj];
-			int c = q_base[J.qlen_full - 1 - pj];
+			if (!J.q_rev) return bases.at(q_base + (uint64_t)(pj));
+			int c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj));
 			return c < 4 ? 3 - c : 4;
 		};
 		// LDS rows: ring of R columns (R == T when the whole target fits the launch's ring capacity)
@@ -499,25 +499,25 @@ void k_extd2_wide(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t
 
 size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact) { return (size_t)r_cap * 10 + (exact ? (size_t)r_cap * 4 : 0) + (seq_cap > 0 ? 2 * (size_t)seq_cap + 128 : 0); }
 
-template <int NT> static void launch_wide_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab,
+template <int NT> static void launch_wide_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab,
                                              size_t slab_bytes, int r_cap, int seq_cap, int exact, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
 {
 	static bool attr_set = false;
 	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_MAX)); attr_set = true; }
-	hipLaunchKernelGGL(k_extd2_wide<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact, res, pool, cursor, pool_cap);
+	hipLaunchKernelGGL(k_extd2_wide<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, r_cap, seq_cap, exact, res, pool, cursor, pool_cap);
 }
 
 // n_threads: 256 for many problems (several workgroups per CU), 512 / 1024 when a class holds few, large problems:
 // a workgroup that has a CU to itself needs the extra waves to hide its LDS latency
-void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
+void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap, bool exact, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, size_t slab_bytes,
                        DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
 	const size_t lds = wide_lds_bytes(r_cap, seq_cap, exact);
 	static const bool no_fused = [] { const bool off = getenv("PGA_NO_FUSED_APPROX") != nullptr; if (off) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_no_fused), &one, sizeof(int)); } return off; }();
 	(void)no_fused;
-	if (n_threads >= 1024) launch_wide_nt<1024>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
-	else if (n_threads >= 512) launch_wide_nt<512>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
-	else launch_wide_nt<256>(n_blocks, lds, st, jobs, n_jobs, nt4, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
+	if (n_threads >= 1024) launch_wide_nt<1024>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
+	else if (n_threads >= 512) launch_wide_nt<512>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
+	else launch_wide_nt<256>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, r_cap, seq_cap, exact ? 1 : 0, res, pool, cursor, pool_cap);
 }
 
 } // namespace pga

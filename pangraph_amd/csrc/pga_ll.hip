@@ -27,7 +27,7 @@ namespace pga {
 #define LL_RMAX 10          // rows per thread: PGA_LL_MAX_LEN / LL_NT
 
 __global__ __launch_bounds__(LL_NT)
-void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__restrict__ nt4, DpParams P, uint32_t *__restrict__ job_counter,
+void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, DpParams P, uint32_t *__restrict__ job_counter,
               unsigned long long *__restrict__ rowkey_all, size_t rowkey_stride, int t_cap, DpRes *__restrict__ res)
 {
 	extern __shared__ __align__(16) uint8_t dyn[];            // the query, padded to a multiple of 8 columns (t_cap bytes)
@@ -47,7 +47,7 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 		const uint32_t jid = s_job;
 		if (jid >= n_jobs) break;
 		const DpJob J = jobs[jid];
-		const uint8_t *t_base = nt4 + J.t_off, *q_base = nt4 + J.q_off;
+		const uint64_t t_base = J.t_off, q_base = J.q_off;          // base positions in the packed store
 		const int qlen = J.qlen, tlen = J.tlen;
 		const int slen = (qlen + 7) / 8, qlen8 = slen * 8;
 		const int R = (tlen + LL_NT - 1) / LL_NT;              // rows per thread (uniform)
@@ -57,8 +57,8 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 			int c = 4;
 			if (j < qlen) {
 				const int pj = J.qs + (J.seq_rev ? qlen - 1 - j : j);
-				if (!J.q_rev) c = q_base[pj];
-				else { c = q_base[J.qlen_full - 1 - pj]; c = c < 4 ? 3 - c : 4; }
+				if (!J.q_rev) c = bases.at(q_base + (uint64_t)(pj));
+				else { c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj)); c = c < 4 ? 3 - c : 4; }
 			}
 			qb[j] = (uint8_t)(j < qlen ? c : 5);                // 5: padding column, score 0
 		}
@@ -67,7 +67,7 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 #pragma unroll
 		for (int k = 0; k < LL_RMAX; ++k) {
 			const int i = i0 + k;
-			const int a = (k < R && i < tlen) ? (int)t_base[J.seq_rev ? tlen - 1 - i : i] : 4;
+			const int a = (k < R && i < tlen) ? (int)bases.at(t_base + (uint64_t)(J.seq_rev ? tlen - 1 - i : i)) : 4;
 			ta[k] = a; tm[k] = a == 4 ? sc_N : sc_mis; Hl[k] = 0; Fl[k] = 0;
 		}
 		if (tid < 2 * (LL_NT / 64)) { (&s_xh[0][0])[tid] = 0; (&s_xe[0][0])[tid] = 0; }
@@ -136,12 +136,12 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, const uint8_t *__
 
 size_t ll_lds_bytes(int t_cap) { return (size_t)t_cap + 64; }
 
-void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, const uint8_t *nt4, const DpParams &P, uint32_t *counter,
+void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter,
                    unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st)
 {
 	static bool attr_set = false;
 	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_ll_i16, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
-	hipLaunchKernelGGL(k_ll_i16, dim3(n_blocks), dim3(LL_NT), ll_lds_bytes(t_cap), st, jobs, n_jobs, nt4, P, counter, rowkey, rowkey_stride, t_cap, res);
+	hipLaunchKernelGGL(k_ll_i16, dim3(n_blocks), dim3(LL_NT), ll_lds_bytes(t_cap), st, jobs, n_jobs, bases, P, counter, rowkey, rowkey_stride, t_cap, res);
 }
 
 } // namespace pga

@@ -51,7 +51,7 @@ struct MashChunk { uint32_t rid; uint32_t start; };
 // modes 0 and 1).  RING: uint32_t when a hash and the strand bit fit 32 bits (k <= 15: half the LDS, twice the waves per CU).
 template <int MODE, class RING>
 __global__ __launch_bounds__(64)
-void k_mash_chunks(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, const MashChunk *__restrict__ chunks, uint32_t n_chunks,
+void k_mash_chunks(PkBases bases, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, const MashChunk *__restrict__ chunks, uint32_t n_chunks,
                    int k, int w, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ off, uint64_t *__restrict__ val, uint64_t *__restrict__ pos, uint32_t stage_cap)
 {
 	extern __shared__ uint64_t ring_raw[];
@@ -64,7 +64,7 @@ void k_mash_chunks(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__
 	if (c >= n_chunks) return;
 	const MashChunk ch = chunks[c];
 	const uint32_t len = seq_len[ch.rid];
-	const uint8_t *s = nt4 + seq_off[ch.rid];
+	const uint64_t s0 = seq_off[ch.rid];                               // the sequence's first base in the packed store
 	const uint64_t id = ch.rid;
 	const uint64_t mask = (1ULL << (2 * k)) - 1, shift = 2 * (uint64_t)(k - 1);
 	const uint32_t end = ch.start + MASH_CHUNK < len ? ch.start + MASH_CHUNK : len;
@@ -88,7 +88,7 @@ void k_mash_chunks(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__
 	};
 	for (uint32_t p = q0; p < end; ++p) {
 		const bool live = p >= ch.start;
-		const int cde = s[p];
+		const int cde = bases.at(s0 + (uint64_t)p);
 		uint64_t nv = MASH_MAX, np = MASH_MAX;               // (stored values carry the strand in bit 63; MAX stays MAX)
 		uint64_t st_bit = 0;
 		if (cde >= 4) l = 0;
@@ -173,7 +173,7 @@ static void mash_sketch_all(const SeqSet &S, int k, int w, MashSketch &M, hipStr
 	}
 	auto launch = [&](int mode, uint32_t *cnt, const uint64_t *off, uint64_t *val, uint64_t *pos, uint32_t cap) {
 		const dim3 g((nc + 63) / 64), b(64);
-#define PGA_MASH_GO(M, R) hipLaunchKernelGGL((k_mash_chunks<M, R>), g, b, lds, st, S.d_nt4.p, S.d_off.p, S.d_len.p, d_ch.p, nc, k, w, cnt, off, val, pos, cap)
+#define PGA_MASH_GO(M, R) hipLaunchKernelGGL((k_mash_chunks<M, R>), g, b, lds, st, S.bases(), S.d_off.p, S.d_len.p, d_ch.p, nc, k, w, cnt, off, val, pos, cap)
 		if (small) { if (mode == 0) PGA_MASH_GO(0, uint32_t); else if (mode == 1) PGA_MASH_GO(1, uint32_t); else PGA_MASH_GO(2, uint32_t); }
 		else { if (mode == 0) PGA_MASH_GO(0, uint64_t); else if (mode == 1) PGA_MASH_GO(1, uint64_t); else PGA_MASH_GO(2, uint64_t); }
 #undef PGA_MASH_GO

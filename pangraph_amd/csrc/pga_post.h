@@ -14,10 +14,9 @@ struct PostFin { uint64_t t_off, q_off; int32_t qlen_full, q_start, q_rev; uint3
 struct PostFinRes { uint32_t n_cigar; int32_t qshift, tshift, blen, mlen, n_ambi, dp_max, n_gapo, n_gap, q_span, t_span; };
 
 // out[i] = number of mismatches of probe i, or -1 if the windows hold an ambiguous base or differ in more than m_max positions
-void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_max, PinVec<int32_t> &out, hipStream_t st);
-void post_zdrop_walk(const uint8_t *d_nt4, const std::vector<PostWalk> &reqs, const std::vector<uint32_t> &cig, const DpParams &P, std::vector<PostWalkRes> &out, hipStream_t st);
+void post_identity(PkBases d_bases, const PinVec<PostProbe> &probes, int m_max, PinVec<int32_t> &out, hipStream_t st);
+void post_zdrop_walk(PkBases d_bases, const std::vector<PostWalk> &reqs, const std::vector<uint32_t> &cig, const DpParams &P, std::vector<PostWalkRes> &out, hipStream_t st);
 // cig holds the operation lists of all requests back to back; on return request i's final list is cig[cig_off .. cig_off + out[i].n_cigar)
-void post_cigar_finish(const uint8_t *d_nt4, const std::vector<PostFin> &reqs, PinVec<uint32_t> &cig, const DpParams &P, std::vector<PostFinRes> &out, hipStream_t st);
-void post_fetch(const uint8_t *d_nt4, uint64_t off, size_t n, std::vector<uint8_t> &out, hipStream_t st);
+void post_cigar_finish(PkBases d_bases, const std::vector<PostFin> &reqs, PinVec<uint32_t> &cig, const DpParams &P, std::vector<PostFinRes> &out, hipStream_t st);
 
 } // namespace pga

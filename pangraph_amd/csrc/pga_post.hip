@@ -19,13 +19,13 @@
 
 namespace pga {
 
-__device__ __forceinline__ int post_tbase(const uint8_t *__restrict__ nt4, uint64_t t_off, int i) { return nt4[t_off + (uint64_t)i]; }
+__device__ __forceinline__ int post_tbase(PkBases bases, uint64_t t_off, int i) { return bases.at(t_off + (uint64_t)i); }
 // base j of the aligned query strand, window starting at q_start on that strand (reverse strand = complement read backwards, align.c:970-975)
-__device__ __forceinline__ int post_qbase(const uint8_t *__restrict__ nt4, uint64_t q_off, int qlen_full, int q_start, int q_rev, int j)
+__device__ __forceinline__ int post_qbase(PkBases bases, uint64_t q_off, int qlen_full, int q_start, int q_rev, int j)
 {
 	const int pj = q_start + j;
-	if (!q_rev) return nt4[q_off + (uint64_t)pj];
-	const int c = nt4[q_off + (uint64_t)(qlen_full - 1 - pj)];
+	if (!q_rev) return bases.at(q_off + (uint64_t)pj);
+	const int c = bases.at(q_off + (uint64_t)(qlen_full - 1 - pj));
 	return c < 4 ? 3 - c : 4;
 }
 
@@ -33,20 +33,20 @@ __device__ __forceinline__ int post_qbase(const uint8_t *__restrict__ nt4, uint6
 // One WAVE per probe at a time (grid-stride): the lanes read 64 consecutive bases of both windows per step (coalesced; a lane per
 // probe would pull a whole cache line for every byte), the mismatch count is a ballot + popcount, the early exit is uniform.
 __global__ __launch_bounds__(256)
-void k_seg_identity(const PostProbe *__restrict__ pr, uint32_t n, const uint8_t *__restrict__ nt4, int m_max, int32_t *__restrict__ out)
+void k_seg_identity(const PostProbe *__restrict__ pr, uint32_t n, PkBases bases, int m_max, int32_t *__restrict__ out)
 {
 	const int lane = threadIdx.x & 63;
 	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
 	for (uint32_t i = wave; i < n; i += n_waves) {
 		const PostProbe P = pr[i];
-		const uint8_t *t = nt4 + P.t_off;
-		const uint8_t *q = P.q_rev ? nt4 + P.q_off + (uint64_t)(P.qlen_full - 1 - P.qs) : nt4 + P.q_off + (uint64_t)P.qs;
+		const uint64_t t = P.t_off;
+		const uint64_t q = P.q_rev ? P.q_off + (uint64_t)(P.qlen_full - 1 - P.qs) : P.q_off + (uint64_t)P.qs;
 		int m = 0;
 		for (int b = 0; b < P.n; b += 64) {
 			const int k = b + lane;
 			bool bad = false, diff = false;
 			if (k < P.n) {
-				const int x = t[k], y = P.q_rev ? q[-k] : q[k];
+				const int x = bases.at(t + (uint64_t)k), y = bases.at(P.q_rev ? q - (uint64_t)k : q + (uint64_t)k);
 				bad = (x | y) > 3;
 				diff = P.q_rev ? x != 3 - y : x != y;
 			}
@@ -58,7 +58,7 @@ void k_seg_identity(const PostProbe *__restrict__ pr, uint32_t n, const uint8_t 
 	}
 }
 
-void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_max, PinVec<int32_t> &out, hipStream_t st)
+void post_identity(PkBases d_bases, const PinVec<PostProbe> &probes, int m_max, PinVec<int32_t> &out, hipStream_t st)
 {
 	const size_t n = probes.size();
 	out.resize(n);
@@ -66,7 +66,7 @@ void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_
 	DBuf<PostProbe> d; d.alloc(n);
 	DBuf<int32_t> r; r.alloc(n);
 	PGA_HIP(hipMemcpyAsync(d.p, probes.data(), n * sizeof(PostProbe), hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, st, d.p, (uint32_t)n, d_nt4, m_max, r.p);
+	hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, st, d.p, (uint32_t)n, d_bases, m_max, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipStreamSynchronize(st));
@@ -76,7 +76,7 @@ void post_identity(const uint8_t *d_nt4, const PinVec<PostProbe> &probes, int m_
 // One thread per request.  Scores: match run positions add mat[t][q]; a gap of any kind subtracts q + e*len (align.c:64-72); after
 // every step the tracker compares with the best prefix so far, discounting the diagonal offset at e per base (align.c:32-45).
 __global__ __launch_bounds__(64)
-void k_zdrop_walk(const PostWalk *__restrict__ rq, uint32_t n, const uint32_t *__restrict__ cig, const uint8_t *__restrict__ nt4,
+void k_zdrop_walk(const PostWalk *__restrict__ rq, uint32_t n, const uint32_t *__restrict__ cig, PkBases bases,
                   int sc_mch, int sc_mis, int sc_ambi, int gap_q, int gap_e, PostWalkRes *__restrict__ out)
 {
 	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,7 +95,7 @@ void k_zdrop_walk(const PostWalk *__restrict__ rq, uint32_t n, const uint32_t *_
 		const uint32_t op = cg[k] & 0xf; const int len = (int)(cg[k] >> 4);
 		if (op == 0) {
 			for (int l = 0; l < len; ++l) {
-				const int tb = post_tbase(nt4, W.t_off, ti + l), qb = post_qbase(nt4, W.q_off, W.qlen_full, W.qs, W.q_rev, qj + l);
+				const int tb = post_tbase(bases, W.t_off, ti + l), qb = post_qbase(bases, W.q_off, W.qlen_full, W.qs, W.q_rev, qj + l);
 				score += (tb > 3 || qb > 3) ? sc_ambi : tb == qb ? sc_mch : sc_mis;
 				track(ti + l, qj + l);
 			}
@@ -110,7 +110,7 @@ void k_zdrop_walk(const PostWalk *__restrict__ rq, uint32_t n, const uint32_t *_
 	out[id] = R;
 }
 
-void post_zdrop_walk(const uint8_t *d_nt4, const std::vector<PostWalk> &reqs, const std::vector<uint32_t> &cig, const DpParams &P, std::vector<PostWalkRes> &out, hipStream_t st)
+void post_zdrop_walk(PkBases d_bases, const std::vector<PostWalk> &reqs, const std::vector<uint32_t> &cig, const DpParams &P, std::vector<PostWalkRes> &out, hipStream_t st)
 {
 	const size_t n = reqs.size();
 	out.resize(n);
@@ -119,7 +119,7 @@ void post_zdrop_walk(const uint8_t *d_nt4, const std::vector<PostWalk> &reqs, co
 	DBuf<uint32_t> c; c.alloc(cig.size() ? cig.size() : 1);
 	if (!cig.empty()) PGA_HIP(hipMemcpyAsync(c.p, cig.data(), cig.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 	DBuf<PostWalkRes> r; r.alloc(n);
-	hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_nt4, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
+	hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostWalkRes), hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipStreamSynchronize(st));
@@ -149,7 +149,7 @@ __device__ __forceinline__ int32_t wave_prefix_min_incl(int32_t v)
 // 64 positions at a time), mixed I/D stretches are merged, empty operations dropped, a leading indel is cut off and reported as a
 // shift of the region start.  Stage 2 (mm_update_extra): blen / mlen / n_ambi and the clamped running score.
 __global__ __launch_bounds__(64)
-void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__restrict__ cig_all, const uint8_t *__restrict__ nt4,
+void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__restrict__ cig_all, PkBases bases,
                     int sc_mch, int sc_mis, int sc_ambi, int gap_q, int gap_e, PostFinRes *__restrict__ out)
 {
 	__shared__ uint32_t s_ops[FIN_LDS_OPS];
@@ -178,8 +178,8 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 							const int l = b + lane;
 							bool same = false;
 							if (l < room) {
-								const int x = op == 1 ? post_qbase(nt4, F.q_off, F.qlen_full, F.q_start, F.q_rev, o - 1 - l) : post_tbase(nt4, F.t_off, o - 1 - l);
-								const int y = op == 1 ? post_qbase(nt4, F.q_off, F.qlen_full, F.q_start, F.q_rev, o + len - 1 - l) : post_tbase(nt4, F.t_off, o + len - 1 - l);
+								const int x = op == 1 ? post_qbase(bases, F.q_off, F.qlen_full, F.q_start, F.q_rev, o - 1 - l) : post_tbase(bases, F.t_off, o - 1 - l);
+								const int y = op == 1 ? post_qbase(bases, F.q_off, F.qlen_full, F.q_start, F.q_rev, o + len - 1 - l) : post_tbase(bases, F.t_off, o + len - 1 - l);
 								same = x == y;
 							}
 							const unsigned long long eq = __ballot(same);
@@ -267,7 +267,7 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 				for (; b + 512 <= len; b += 512) {
 					int tb[8], qb[8];
 #pragma unroll
-					for (int u = 0; u < 8; ++u) { tb[u] = post_tbase(nt4, t0, toff + b + 64 * u + lane); qb[u] = post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + b + 64 * u + lane); }
+					for (int u = 0; u < 8; ++u) { tb[u] = post_tbase(bases, t0, toff + b + 64 * u + lane); qb[u] = post_qbase(bases, F.q_off, F.qlen_full, q0, F.q_rev, qoff + b + 64 * u + lane); }
 					bool clean = true;
 #pragma unroll
 					for (int u = 0; u < 8; ++u) clean &= tb[u] == qb[u] && tb[u] <= 3;
@@ -278,7 +278,7 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 				for (; b < len; b += 64) {
 					const int l = b + lane; const bool on = l < len;
 					int tb = 0, qb = 0;
-					if (on) { tb = post_tbase(nt4, t0, toff + l); qb = post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l); }
+					if (on) { tb = post_tbase(bases, t0, toff + l); qb = post_qbase(bases, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l); }
 					block(tb, qb, on, len - b < 64 ? len - b : 64);
 				}
 				blen += len - ambi, mlen += len - (ambi + diff), n_ambi += ambi;
@@ -287,7 +287,7 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 				int ambi = 0;
 				for (int b = 0; b < len; b += 64) {
 					const int l = b + lane;
-					const bool a = l < len && (op == 1 ? post_qbase(nt4, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l) : post_tbase(nt4, t0, toff + l)) > 3;
+					const bool a = l < len && (op == 1 ? post_qbase(bases, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l) : post_tbase(bases, t0, toff + l)) > 3;
 					ambi += __popcll(__ballot(a));
 				}
 				blen += len - ambi, n_ambi += ambi; ++n_gapo, n_gap += len;
@@ -313,7 +313,7 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 	}
 }
 
-void post_cigar_finish(const uint8_t *d_nt4, const std::vector<PostFin> &reqs, PinVec<uint32_t> &cig, const DpParams &P, std::vector<PostFinRes> &out, hipStream_t st)
+void post_cigar_finish(PkBases d_bases, const std::vector<PostFin> &reqs, PinVec<uint32_t> &cig, const DpParams &P, std::vector<PostFinRes> &out, hipStream_t st)
 {
 	const size_t n = reqs.size();
 	out.resize(n);
@@ -323,7 +323,7 @@ void post_cigar_finish(const uint8_t *d_nt4, const std::vector<PostFin> &reqs, P
 	if (cig.size()) PGA_HIP(hipMemcpyAsync(c.p, cig.data(), cig.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 	DBuf<PostFinRes> r; r.alloc(n);
 	const unsigned grid = (unsigned)std::min<size_t>(n, 256 * 32);
-	hipLaunchKernelGGL(k_cigar_finish, dim3(grid), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_nt4, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
+	hipLaunchKernelGGL(k_cigar_finish, dim3(grid), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostFinRes), hipMemcpyDeviceToHost, st));
 	if (cig.size()) PGA_HIP(hipMemcpyAsync(cig.data(), c.p, cig.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -331,12 +331,6 @@ void post_cigar_finish(const uint8_t *d_nt4, const std::vector<PostFin> &reqs, P
 }
 
 // bases of one window, back on the host (only the rare local-alignment windows the LL kernel does not take need them)
-void post_fetch(const uint8_t *d_nt4, uint64_t off, size_t n, std::vector<uint8_t> &out, hipStream_t st)
-{
-	out.resize(n);
-	if (!n) return;
-	PGA_HIP(hipMemcpyAsync(out.data(), d_nt4 + off, n, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
-}
+
 
 } // namespace pga

@@ -79,7 +79,7 @@ static inline uint8_t nt4_host(uint8_t r)
 	return code;
 }
 
-// ASCII -> nt4 (sketch.c:9-26 table: A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 4), sixteen bases per thread
+// ASCII -> bases (sketch.c:9-26 table: A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 4), sixteen bases per thread
 __device__ __forceinline__ uint32_t nt4_of(uint32_t r)
 {
 	const uint32_t c = r & 0xdf;
@@ -87,27 +87,24 @@ __device__ __forceinline__ uint32_t nt4_of(uint32_t r)
 	if (r < 0x40) code = 4u;
 	return code;
 }
-// Two stores come out of one pass: nt4 (1 B/base: the DP kernels index single bases of arbitrary windows and strands) and the PACKED
-// store the sketch kernel streams -- 2 bits per base, sixteen bases per 32-bit word, plus one "not ACGT" bit per base (the reference
-// packs its index sequences the same way at index time, index.c:438-446, mmpriv.h:30-31, four bits per base there).
+// The resident store: 2 bits per base, sixteen bases per 32-bit word, plus one "not ACGT" bit per base (the reference packs its index
+// sequences at index time too, four bits per base: index.c:438-446, mmpriv.h:30-31).  Every kernel of the path reads bases from it
+// (PkBases, pga_common.h): 0.375 bytes per base written here, no byte-per-base copy exists.
 __global__ __launch_bounds__(256)
-void k_encode_nt4(const uint4 *__restrict__ raw, uint4 *__restrict__ nt4, uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmask, uint64_t n16)
+void k_encode_pk(const uint4 *__restrict__ raw, uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmask, uint64_t n16)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n16) return;
 	const uint4 v = raw[i];
-	auto word = [](uint32_t w) { return nt4_of(w & 0xff) | nt4_of(w >> 8 & 0xff) << 8 | nt4_of(w >> 16 & 0xff) << 16 | nt4_of(w >> 24) << 24; };
-	uint4 o; o.x = word(v.x), o.y = word(v.y), o.z = word(v.z), o.w = word(v.w);
-	nt4[i] = o;
-	const uint32_t in[4] = {o.x, o.y, o.z, o.w};
+	const uint32_t in[4] = {v.x, v.y, v.z, v.w};
 	uint32_t bits = 0, nm = 0;
 #pragma unroll
-	for (int j = 0; j < 16; ++j) { const uint32_t c = (in[j >> 2] >> (8 * (j & 3))) & 0xff; bits |= (c & 3u) << (2 * j); nm |= (c > 3 ? 1u : 0u) << j; }
+	for (int j = 0; j < 16; ++j) { const uint32_t c = nt4_of((in[j >> 2] >> (8 * (j & 3))) & 0xff); bits |= (c & 3u) << (2 * j); nm |= (c > 3 ? 1u : 0u) << j; }
 	pk2[i] = bits; nmask[i] = (uint16_t)nm;
 }
 
 // The hand-over of a batch: the caller's ASCII sequences go to the device as they are -- host threads gather them into pinned
-// staging buffers, chunk by chunk, while the previous chunk is on its way over PCIe -- and are encoded THERE (k_encode_nt4).  The
+// staging buffers, chunk by chunk, while the previous chunk is on its way over PCIe -- and are encoded THERE (k_encode_pk).  The
 // host keeps no copy of the bases: nothing on the host reads them (pga_align.cpp), except 64 probe positions per sequence that let
 // mm_map() check that a query really is the indexed sequence of that name.
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st)
@@ -124,7 +121,6 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	}
 	// sequences are padded to a 16-byte multiple (and 64 more) so that wide loads never straddle the allocation
 	const uint64_t padded = (S.total + 15) / 16 * 16;
-	S.d_nt4.alloc(padded + 64);
 	S.d_pk2.alloc((size_t)(padded / 16) + 8); S.d_nmask.alloc((size_t)(padded / 16) + 8);
 	const uint64_t chunk = (uint64_t)64 << 20;
 	const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
@@ -159,13 +155,12 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			if (nb > e - b) memset(x.pin + (e - b), 'N', (size_t)(nb - (e - b)));
 			PGA_HIP(hipMemcpyAsync(x.dev, x.pin, (size_t)nb, hipMemcpyHostToDevice, st));
 			PGA_HIP(hipEventRecord(x.sent, st));
-			hipLaunchKernelGGL(k_encode_nt4, dim3((unsigned)((nb / 16 + 255) / 256)), dim3(256), 0, st, (const uint4*)x.dev, (uint4*)(S.d_nt4.p + b), S.d_pk2.p + b / 16, S.d_nmask.p + b / 16, nb / 16);
+			hipLaunchKernelGGL(k_encode_pk, dim3((unsigned)((nb / 16 + 255) / 256)), dim3(256), 0, st, (const uint4*)x.dev, S.d_pk2.p + b / 16, S.d_nmask.p + b / 16, nb / 16);
 		}
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipStreamSynchronize(st));
 		for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
 	}
-	PGA_HIP(hipMemsetAsync(S.d_nt4.p + padded, 4, 64, st));
 	PGA_HIP(hipMemsetAsync(S.d_pk2.p + padded / 16, 0, 8 * sizeof(uint32_t), st));
 	PGA_HIP(hipMemsetAsync(S.d_nmask.p + padded / 16, 0xff, 8 * sizeof(uint16_t), st));
 	S.d_off.upload(S.off, st);
@@ -345,13 +340,13 @@ void k_sketch_tiles(const uint32_t *__restrict__ pk2, const uint16_t *__restrict
 }
 
 // ---- generic serial kernel: one lane per sequence, the streaming formulation (slots, ring of w entries) ----
-__global__ void k_sketch_serial(const uint8_t *__restrict__ nt4, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
+__global__ void k_sketch_serial(PkBases bases, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
                                 int n_seq, int w, int k, u128 *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ cnt,
                                 u128 *__restrict__ ring_all)
 {
 	int rid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rid >= n_seq) return;
-	const uint8_t *s = nt4 + seq_off[rid];
+	const uint64_t s0 = seq_off[rid];                                  // the sequence's first base in the packed store
 	const int len = (int)seq_len[rid];
 	u128 *ring = ring_all + (size_t)rid * 256;
 	u128 *o = out ? out + out_off[rid] : nullptr;
@@ -363,7 +358,7 @@ __global__ void k_sketch_serial(const uint8_t *__restrict__ nt4, const uint64_t 
 	for (int j = 0; j < w; ++j) ring[j] = none;
 	auto push = [&](u128 v) { if (o) o[n] = v; ++n; };
 	for (int i = 0; i < len; ++i) {
-		int c = s[i];
+		int c = bases.at(s0 + (uint64_t)i);
 		u128 info = none;
 		if (c < 4) {
 			fw = (fw << 2 | (uint64_t)c) & mask;
@@ -476,7 +471,7 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 	} else {
 		DBuf<uint64_t> d_cnt((size_t)n + 1); d_cnt.zero(st);
 		DBuf<u128> ring((size_t)n * 256);
-		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.d_nt4.p, S.d_off.p, S.d_len.p, n, w, k,
+		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.bases(), S.d_off.p, S.d_len.p, n, w, k,
 		                   (u128*)nullptr, (const uint64_t*)nullptr, d_cnt.p, ring.p);
 		exclusive_scan_u64(d_cnt.p, M.seq_off.p, (size_t)n + 1, st);
 		uint64_t total = 0;
@@ -484,7 +479,7 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 		PGA_HIP(hipStreamSynchronize(st));
 		M.n = total;
 		M.mz.alloc(total ? total : 1);
-		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.d_nt4.p, S.d_off.p, S.d_len.p, n, w, k,
+		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.bases(), S.d_off.p, S.d_len.p, n, w, k,
 		                   M.mz.p, M.seq_off.p, (uint64_t*)nullptr, ring.p);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipStreamSynchronize(st));
