@@ -342,24 +342,41 @@ def main():
         if world == 1:
             sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, on_result=on_result)
             return agg
-        # phase 1: this rank's subtrees, no communication; one gather; phase 2: the merges above the cut on rank 0
+        # phase 1: this rank's subtrees, no communication; one gather.  Phase 2: the merges above the cut -- few, large, one after the other
+        # along the tree -- by ALL ranks together: every rank indexes the whole call and maps its share of the queries of every group
+        # (pga_batch_align_shard), level by level in an order every rank computes for itself; one more gather.
         mine_ids = {t.tid for t in tasks if owner[t.tid] == rank}
         if mine_ids:
             sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=mine_ids, on_result=on_result)
-        t0 = time.perf_counter()
-        m = np.concatenate(recs) if recs else np.zeros(0, MATCH_DTYPE)
-        cg = np.concatenate(pools) if pools else np.zeros(0, np.uint32)
-        pm = gather_blobs(m.view(np.uint8), cdev, dst=0, as_bytes=False)
-        pc = gather_blobs(cg.view(np.uint8), cdev, dst=0, as_bytes=False)
-        agg["gather_s"] += time.perf_counter() - t0
-        if rank == 0:
-            n_gathered = sum(t.numel() for t in pm) // MATCH_DTYPE.itemsize
-            top = {t.tid for t in tasks if owner[t.tid] == -1}
-            n_before = agg["n_matches"]
-            if top:
-                sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=top,
-                                    done={t.tid for t in tasks if owner[t.tid] != -1}, on_result=on_result)
-            agg["n_matches"] = n_gathered + (agg["n_matches"] - n_before)
+
+        def gather_all():
+            t0 = time.perf_counter()
+            m = np.concatenate(recs) if recs else np.zeros(0, MATCH_DTYPE)
+            cg = np.concatenate(pools) if pools else np.zeros(0, np.uint32)
+            pm = gather_blobs(m.view(np.uint8), cdev, dst=0, as_bytes=False)
+            gather_blobs(cg.view(np.uint8), cdev, dst=0, as_bytes=False)
+            recs.clear(); pools.clear(); pool_len[0] = 0
+            agg["gather_s"] += time.perf_counter() - t0
+            return sum(t.numel() for t in pm) // MATCH_DTYPE.itemsize if pm is not None else 0
+
+        n_gathered = gather_all()
+        top = [t.tid for t in tasks if owner[t.tid] == -1]
+        done = {t.tid for t in tasks if owner[t.tid] != -1}
+        while top:
+            level = [tid for tid in top if all(d in done for d in tasks[tid].deps)]
+            ts = [tasks[i] for i in sorted(level)]
+            tb = sched.TaskBatch(ts)
+            t0 = time.perf_counter()
+            rb = batch.ResidentBatch(tb)
+            t1 = time.perf_counter()
+            res = rb.align(sensitivity=10, want_raw=True, n_threads=n_threads, shard=(rank, world))
+            t2 = time.perf_counter()
+            rb.close()
+            on_result(ts, (res, t1 - t0, t2 - t1), t0, t2)
+            done.update(level)
+            top = [tid for tid in top if tid not in done]
+        n_gathered += gather_all()
+        agg["n_matches"] = n_gathered
         return agg
 
     def step_waves():
@@ -452,7 +469,7 @@ def main():
                    "schedule": (f"ready set: every find_matches call starts when the calls it depends on are done (children's last round, own previous round); "
                                 f"{args.slots} batches in flight, <= {args.cap_gbp} Gbp each" if args.schedule == "ready" else "level-synchronous waves, one batch per wave"),
                    "parallelism": (f"guide tree cut into subtrees dealt to {world} rank(s) by base count, no data-path collective, one match-list gather to rank 0, "
-                                   f"merges above the cut on rank 0" if args.schedule == "ready" else
+                                   f"merges above the cut by all ranks together (replicated index, queries of every group split over the ranks), one more gather" if args.schedule == "ready" else
                                    f"groups of every wave sharded over {world} rank(s) by base count, match-list gather to rank 0 per wave")},
         "resident_gbp_s": units / max(last["align_s"], 1e-9) / 1e9 if world == 1 and args.schedule == "waves" else None,
         "rank0_seconds_per_step": {"hand_over": last["create_s"], "align": last["align_s"], "gather": last["gather_s"],

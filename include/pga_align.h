@@ -68,6 +68,10 @@ int pga_align_groups(const pga_params_t *params, int32_t n_groups, const int64_t
 typedef struct pga_batch_s pga_batch_t;
 int pga_batch_create(int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out);
 int pga_batch_align(pga_batch_t *batch, const pga_params_t *params, pga_result_t **out);
+/* Multi-GPU hosts, waves with fewer groups than ranks (the reference parallelises over the queries of one index,
+ * align_with_minimap2_lib.rs:64-74): every shard indexes ALL sequences of the batch and maps, of every group, a contiguous range of the
+ * queries (balanced by length).  The shards' match lists are disjoint; their union ordered by (group, query) is pga_batch_align's list. */
+int pga_batch_align_shard(pga_batch_t *batch, const pga_params_t *params, int32_t shard, int32_t n_shards, pga_result_t **out);
 void pga_batch_free(pga_batch_t *batch);
 int64_t pga_result_n_matches(const pga_result_t *r);
 const pga_match_t *pga_result_matches(const pga_result_t *r);

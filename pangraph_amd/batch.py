@@ -60,6 +60,8 @@ def lib():
         d.pga_batch_create.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         d.pga_batch_align.restype = C.c_int
         d.pga_batch_align.argtypes = [C.c_void_p, C.POINTER(pga_params_t), C.POINTER(C.c_void_p)]
+        d.pga_batch_align_shard.restype = C.c_int
+        d.pga_batch_align_shard.argtypes = [C.c_void_p, C.POINTER(pga_params_t), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         d.pga_batch_free.argtypes = [C.c_void_p]
         d.pga_result_n_matches.restype = C.c_int64
         d.pga_result_n_matches.argtypes = [C.c_void_p]
@@ -179,11 +181,13 @@ class ResidentBatch:
             raise PgaError(lib().pga_last_error().decode())
 
     def align(self, sensitivity: int = 10, kmer_length: Optional[int] = None, indel_len_threshold: int = 100, n_threads: int = 0,
-              want_rows: bool = False, want_raw: bool = False) -> BatchResult:
+              want_rows: bool = False, want_raw: bool = False, shard: Optional[tuple] = None) -> BatchResult:
+        """shard = (i, n): map only the i-th of n contiguous query ranges of every group (all sequences are indexed): pga_batch_align_shard"""
         d = lib()
         p = pga_params_t(sensitivity, kmer_length or 0, indel_len_threshold, n_threads)
         out = C.c_void_p()
-        if d.pga_batch_align(self.h, C.byref(p), C.byref(out)) != 0:
+        rc = d.pga_batch_align(self.h, C.byref(p), C.byref(out)) if shard is None else d.pga_batch_align_shard(self.h, C.byref(p), int(shard[0]), int(shard[1]), C.byref(out))
+        if rc != 0:
             raise PgaError(d.pga_last_error().decode())
         return _unpack(self.pb, out, want_rows, want_raw)
 

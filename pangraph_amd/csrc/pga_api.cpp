@@ -84,6 +84,7 @@ extern "C" int mm_check_opt(const mm_idxopt_t *io, const mm_mapopt_t *mo) // opt
 struct PgaIdx {
 	mm_idx_t hdr;                    // must stay first: the Rust side reads n_seq, seq[i].name, seq[i].len
 	SeqSet S; Minimizers M; Index I; DBuf<uint32_t> grp; DBuf<int32_t> d_name_rank, d_mid_occ;
+	DBuf<uint8_t> d_own; bool sharded = false;    // pga_batch_align_shard: the queries this call maps (all sequences are indexed)
 	std::vector<int32_t> mid_occ_raw;   // mm_idx_cal_max_occ per group (cached per fraction)
 	float mid_occ_frac = -1.0f;
 	std::vector<mm_idx_seq_t> seq_hdr; std::vector<std::string> names;
@@ -204,7 +205,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	SeedResult SR;
 	{
 		EventTimer et(ix.st);
-		seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm);
+		seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm, ix.sharded ? ix.d_own.p : nullptr);
 		KernelStat &ks = ix.tm.kern[K_SEED];         // query minimizers probe the table, anchors written, read and written by the sort
 		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
 	}
@@ -481,7 +482,17 @@ extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, cons
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 
-extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_result_t **out)
+static int batch_align_impl(pga_batch_t *B, const pga_params_t *params, int shard, int n_shards, pga_result_t **out);
+extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_result_t **out) { return batch_align_impl(B, params, 0, 1, out); }
+// "replicate the index on each GPU and split the queries into contiguous ranges balanced by their lengths" -- for waves with
+// fewer groups than ranks.  Every shard indexes ALL sequences of the batch and maps the queries of its range of every group; the match
+// lists of the shards are disjoint and their union, ordered by (group, query), is the list of the unsharded call.
+extern "C" int pga_batch_align_shard(pga_batch_t *B, const pga_params_t *params, int32_t shard, int32_t n_shards, pga_result_t **out)
+{
+	if (n_shards < 1 || shard < 0 || shard >= n_shards) { *out = nullptr; set_err("pga_batch_align_shard: shard index outside [0, n_shards)"); return -1; }
+	return batch_align_impl(B, params, shard, n_shards, out);
+}
+static int batch_align_impl(pga_batch_t *B, const pga_params_t *params, int shard, int n_shards, pga_result_t **out)
 {
 	*out = nullptr;
 	try {
@@ -507,6 +518,23 @@ extern "C" int pga_batch_align(pga_batch_t *B, const pga_params_t *params, pga_r
 					ix.mid_occ_frac = -1.0f; ix.have_results = false;
 				}
 				const double up = ix.tm.upload; ix.tm = Timers(); ix.tm.upload = up;
+				ix.sharded = n_shards > 1;
+				if (ix.sharded) {
+					// contiguous query ranges per group, balanced by length: query i of a group goes to the shard its midpoint falls into
+					std::vector<uint8_t> own((size_t)ix.S.n_seq, 0);
+					for (int g = 0; g < ix.S.n_grp; ++g) {
+						const int64_t b = ix.S.grp_off[(size_t)g], e = ix.S.grp_off[(size_t)g + 1];
+						uint64_t total = 0; for (int64_t i = b; i < e; ++i) total += ix.S.len[(size_t)i];
+						uint64_t cum = 0;
+						for (int64_t i = b; i < e; ++i) {
+							const uint64_t mid = cum + ix.S.len[(size_t)i] / 2;
+							const int sh = total ? (int)std::min<uint64_t>((uint64_t)n_shards - 1, (unsigned __int128)mid * (uint64_t)n_shards / total) : 0;
+							own[(size_t)i] = sh == shard ? 1 : 0;
+							cum += ix.S.len[(size_t)i];
+						}
+					}
+					ix.d_own.upload(own, ix.st);
+				}
 				idx_sketch_index(ix);          // the index is part of the hot path: rebuilt on every call, like every find_matches does
 				mm_mapopt_t mo = mo0;
 				if (mo.bw_long < mo.bw) mo.bw_long = mo.bw;

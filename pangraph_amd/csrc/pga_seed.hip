@@ -40,12 +40,13 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
 
 // seed.c:5-28 -- keep[i]=0 for query minimizers whose hash is over-represented inside the query
 __global__ void k_mz_keep(const u128 *__restrict__ mz, uint64_t n, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ grp,
-                          const uint32_t *__restrict__ occ_off, const uint64_t *__restrict__ occ, SeedParams P, uint32_t *__restrict__ keep)
+                          const uint32_t *__restrict__ occ_off, const uint64_t *__restrict__ occ, SeedParams P, const uint8_t *__restrict__ own, uint32_t *__restrict__ keep)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t kp = 1;
 	const uint32_t qid = (uint32_t)(mz[i].y >> 32);
+	if (own && !own[qid]) { keep[i] = 0; return; }                     // a query of another shard (pga_batch_align_shard): indexed here, mapped there
 	const uint64_t n_mv = seq_off[qid + 1] - seq_off[qid];
 	const int32_t mid_occ = P.mid_occ(qid);
 	if (n_mv > (uint64_t)mid_occ && P.q_occ_frac > 0.0f && mid_occ > 0) {
@@ -294,7 +295,7 @@ template <class T> static void excl_scan(const T *in, uint64_t *out, size_t n, h
 }
 
 void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<uint32_t> &grp_of_mz, const mm_mapopt_t &opt,
-              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st, Timers *tm)
+              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st, Timers *tm, const uint8_t *d_own)
 {
 	const int n_seq = S.n_seq;
 	const uint64_t n = M.n;
@@ -306,7 +307,7 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 
 	// 1. query-side filter + order-preserving compaction
 	DBuf<uint32_t> keep(n), pos(n + 1);
-	hipLaunchKernelGGL(k_mz_keep, dim3(nb), dim3(256), 0, st, M.mz.p, n, M.seq_off.p, grp_of_mz.p, I.occ_off.p, I.occ.p, P, keep.p);
+	hipLaunchKernelGGL(k_mz_keep, dim3(nb), dim3(256), 0, st, M.mz.p, n, M.seq_off.p, grp_of_mz.p, I.occ_off.p, I.occ.p, P, d_own, keep.p);
 	DBuf<uint64_t> pos64(n + 1);
 	{
 		// exclusive scan over n+1 items (the extra item yields the total)

@@ -100,8 +100,10 @@ def merge_match_lists(parts_m: Sequence[np.ndarray], parts_c: Sequence[np.ndarra
         base += len(c)
     rec = np.concatenate(recs) if recs else np.zeros(0, MATCH_DTYPE)
     pool = np.concatenate(pools) if pools else np.zeros(0, np.uint32)
-    # a rank's records are already in (group, query, own order) order: a stable sort by group restores the global order
-    rec = rec[np.argsort(rec["group"], kind="stable")]
+    # a rank's records are already in (group, query, own order) order: a stable sort by (group, query) restores the single-rank order,
+    # also when the queries of ONE group were split over the ranks (pga_batch_align_shard)
+    key = rec["group"].astype(np.int64) << 32 | rec["qry"].astype(np.int64)
+    rec = rec[np.argsort(key, kind="stable")]
     return rec, pool
 
 

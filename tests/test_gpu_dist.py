@@ -127,3 +127,113 @@ def test_c4_every_wave_two_ranks_gather_vs_reference_digests():
         assert p.exitcode == 0
     assert ok is True, info
     assert info[1] == 30 and info[2] > 1000, info
+
+
+def _worker_split(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from pangraph_amd import batch
+        from pangraph_amd.dist import gather_matches
+        from pangraph_amd.levels import Population, Rates
+        batch.set_device(0)
+        waves = Population(9, 6, 200_000, Rates(ev_min=300, ev_max=6000)).build_waves()
+        ok, n_rec, n_mine = True, 0, 0
+        for label, groups, names in (waves[0], waves[-2], waves[-1]):          # leaf pairs, and the root merge: ONE group, both self-merge rounds
+            ids = list(range(len(groups)))
+            rb = batch.ResidentBatch(batch.PreparedBatch(groups, names))
+            res = rb.align(sensitivity=10, want_raw=True, shard=(rank, world))  # every rank: all groups, its share of the queries of each
+            mine = _records(res)[0]
+            n_mine += len(mine)
+            got = gather_matches(res.raw_matches, res.raw_cigars, ids, [ids] * world, torch.device("cpu"), dst=0)
+            if rank == 0:
+                full = batch.ResidentBatch(batch.PreparedBatch(groups, names)).align(sensitivity=10, want_raw=True)
+                wm, wc = _records(full)
+                gm, gc = got
+                ok &= len(gm) == len(wm)
+                for a, b in zip(gm, wm):
+                    same = all(a[f] == b[f] for f in a.dtype.names if f not in ("cigar_off", "pad"))
+                    same &= bool((gc[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] == wc[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["n_cigar"])]).all())
+                    ok &= bool(same)
+                n_rec += len(wm)
+        if rank == 0:
+            ok &= 0 < n_mine < n_rec                                               # the work really was split
+            q.put((bool(ok), (n_rec, n_mine)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        if rank == 0:
+            q.put((False, repr(e)))
+        raise
+
+
+def test_one_group_split_over_two_ranks_equals_single_rank():
+    """SURVEY 8e / align_with_minimap2_lib.rs:64-74: waves with fewer groups than ranks -- every rank indexes the whole group and maps a
+    contiguous range of its queries (pga_batch_align_shard); the gathered list is the single-rank list, record for record."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker_split, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok, n = q.get(timeout=600)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok is True, n
+    assert n[0] > 20
+
+
+def _worker_nccl(q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(39500 + os.getpid() % 2000)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from pangraph_amd.dist import gather_blobs, gather_matches, max_over_ranks, sum_over_ranks, MATCH_DTYPE
+        blob = np.arange(1000, dtype=np.uint8)
+        got = gather_blobs(blob, dev, dst=0)
+        ok = got == [blob.tobytes()]
+        ok &= max_over_ranks(2.5, dev) == 2.5 and sum_over_ranks(4.0, dev) == 4.0
+        m = np.zeros(3, MATCH_DTYPE); m["group"] = [0, 1, 1]; m["qry"] = [2, 1, 0]; m["n_cigar"] = 1; m["cigar_off"] = [0, 1, 2]
+        rec, pool = gather_matches(m.view(np.uint8), np.arange(3, dtype=np.uint32).view(np.uint8), [0, 1], [[0, 1]], dev, dst=0)
+        ok &= list(rec["qry"]) == [2, 0, 1] and len(pool) == 3
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((bool(ok), ""))
+    except Exception as e:  # noqa: BLE001
+        q.put((False, repr(e)))
+        raise
+
+
+def test_nccl_backend_runs_the_gather_on_one_gpu():
+    """bench.py --gpus N uses the `nccl` backend (RCCL): at least once, on the one GPU of the test box, the process group comes up and the
+    collectives of pangraph_amd.dist (all_gather of sizes, all_reduce) run through it"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(q,))
+    p.start()
+    ok, msg = q.get(timeout=300)
+    p.join(timeout=120)
+    assert ok is True, msg
+
+
+def test_bench_two_ranks_on_one_device_gathers_every_match():
+    """bench.py --gpus 2 (ranks over gloo, both on GPU 0): subtrees on their ranks, the merges above the cut by both ranks together with the
+    queries of every group split -- the gathered match count equals the single-rank build's"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGA_BENCH_SINGLE_DEVICE="1")
+    common = ["--genomes", "12", "--length", "150000", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--no-next-rows"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1]); b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert a["n_matches_gathered"] == b["n_matches_gathered"] > 50
+    assert b["n_gpus"] == 2 and abs(a["config"]["genomes"] - b["config"]["genomes"]) == 0
