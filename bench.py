@@ -48,27 +48,26 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/r*_pmc_hbm_traffic_c5.json: FETCH_SIZE and WRITE_SIZE in separate passes, in KB; FETCH_SIZE is doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  NOT measured in this run; None if there is no PMC summary."""
+def pmc_traffic(kernel: str, launches_per_step: float):
+    """HBM bytes of `kernel` per LAUNCH AS THE ROOFLINE COUNTS LAUNCHES (launches_per_step: e.g. one sort replay = many dispatches), from
+    the committed rocprofv3 --pmc passes of this same workload (profiles/r*_pmc_hbm_traffic_c5.json: one step per pass, FETCH_SIZE and
+    WRITE_SIZE in separate passes, in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950).  The same unit as
+    roofline.alg_bytes_per_launch.  NOT measured in this run; None if there is no PMC summary."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_c5.json")))
-    if not files:
+    if not files or not launches_per_step:
         return None
     d = json.load(open(files[-1]))
+    steps = float(d.get("_meta", {}).get("steps", 1))
     names = [x for x in kernel.replace(" ", "").split("+") if x.startswith("k_")]
     if not names:
         return None
-    tot, n = 0.0, 0
+    tot = 0.0
     for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        disp = 0
         for k, v in d.get(c, {}).items():
             if any(nm in k for nm in names):
                 tot += mul * v["sum"] * 1024.0
-                disp += v["dispatches"]
-        n = max(n, disp)
-    return tot / n if n else None
+    return tot / steps / launches_per_step if tot else None
 
 
 def pmc_issue():
@@ -94,30 +93,32 @@ def _cpu_worker(args):
 
 
 def cpu_baseline(waves, budget_s: float):
-    """The reference C on the host cores: one group per process, one group from every wave until the budget is used."""
+    """The reference C on the host cores, on WHOLE waves of the same build: the leaf wave (height 1, round 0), a wave from the middle of
+    the tree and the root's round 0 -- every group of each, one group per process, all usable cores busy (largest group first); then the
+    same code on ONE core for a leaf pair and a mid-tree group.  A wave whose estimated cost exceeds the budget is sampled (every k-th
+    group) and the sample says so."""
     import multiprocessing as mp
     so = os.path.join(ROOT, "oracle", "_ref", "libmm2ref.so")
     kind = "reference"
     if not os.path.exists(so):
         so, kind = os.path.join(ROOT, "oracle", "libpgoracle.so"), "port"
     cores = usable_cpus()
-    # calibrate on the smallest group of the first wave, then take one group per wave (the largest that fits what is left)
-    _, g0, n0 = waves[0]
+    r0 = [i for i, (label, _, _) in enumerate(waves) if "round 0" in label] or [0]
+    picks = sorted({r0[0], r0[len(r0) // 2], r0[-1]})
+    # calibrate on the smallest group of the first wave
+    _, g0, n0 = waves[picks[0]]
     i0 = min(range(len(g0)), key=lambda i: sum(len(s) for s in g0[i]))
     t1, b1, _ = _cpu_worker((so, g0[i0], n0[i0]))
     rate1 = b1 / max(t1, 1e-3)
-    budget_bases = rate1 * budget_s * cores
-    per_job_cap = rate1 * budget_s * 1.2          # no single job longer than ~the budget
-    jobs, used = [], 0.0
-    for _, groups, names in waves:
+    jobs, notes = [], []
+    for w in picks:
+        label, groups, names = waves[w]
         sizes = [sum(len(s) for s in g) for g in groups]
-        cand = [i for i in range(len(groups)) if sizes[i] <= per_job_cap and used + sizes[i] <= budget_bases]
-        if cand:
-            i = max(cand, key=lambda j: sizes[j])
-            jobs.append((so, groups[i], names[i]))
-            used += sizes[i]
-    if not jobs:
-        jobs = [(so, g0[i0], n0[i0])]
+        est = sum(sizes) / rate1 / cores
+        step = max(1, int(-(-est // max(budget_s, 1e-3))))                 # every step-th group keeps the wave inside the budget
+        ids = list(range(0, len(groups), step))
+        jobs += [(so, groups[i], names[i]) for i in ids]
+        notes.append(f"{label.split(' (')[0]}: {len(ids)} of {len(groups)} groups" + ("" if step == 1 else f" (every {step}th)"))
     n = min(cores, len(jobs))
     jobs.sort(key=lambda j: -sum(len(s) for s in j[1]))
     t0 = time.time()
@@ -125,9 +126,14 @@ def cpu_baseline(waves, budget_s: float):
         res = pool.map(_cpu_worker, jobs, chunksize=1)
     wall = time.time() - t0
     bases = sum(r[1] for r in res)
+    # one core: a leaf pair (above) and the median group of the middle wave
+    _, gm, nm = waves[picks[len(picks) // 2]]
+    im = sorted(range(len(gm)), key=lambda i: sum(len(s) for s in gm[i]))[len(gm) // 2]
+    tm, bm, _ = _cpu_worker((so, gm[im], nm[im]))
     return {"value": bases / wall / 1e9, "unit": "Gbp/s", "cores": n, "kind": kind,
-            "sample": f"{len(jobs)} groups, one from every wave that fits ({bases / 1e6:.1f} Mbp), {n} processes x 1 thread, {wall:.1f} s wall, "
-                      f"{sum(r[0] for r in res):.1f} core-s; 1 core on a leaf pair: {rate1 / 1e9:.5f} Gbp/s"}
+            "sample": f"whole waves, every group: {'; '.join(notes)} ({bases / 1e6:.1f} Mbp), {n} processes x 1 thread, {wall:.1f} s wall, "
+                      f"{sum(r[0] for r in res):.1f} core-s",
+            "one_core_gbp_s": {"leaf_pair": rate1 / 1e9, "mid_tree_group": bm / max(tm, 1e-3) / 1e9}}
 
 
 def respawn_under_torchrun(n: int):
@@ -304,7 +310,7 @@ def main():
     for t in tasks:
         if owner[t.tid] in (rank, -1) or world == 1:
             t.prepare()
-    slot_threads = max(2, n_threads // max(1, min(args.slots, 2)))
+    slot_threads = int(os.environ.get("PGA_BENCH_SLOT_THREADS", max(2, n_threads // max(1, min(args.slots, 2)))))
 
     def step_ready():
         from pangraph_amd.dist import MATCH_DTYPE, gather_blobs
@@ -475,7 +481,7 @@ def main():
         "rank0_seconds_per_step": {"hand_over": last["create_s"], "align": last["align_s"], "gather": last["gather_s"],
                                    "note": "summed over the batches in flight at the same time (ready-set schedule): not a decomposition of ms_per_step"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(kname), "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run)",
+                     "traffic": pmc_traffic(kname, klaunch), "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run); bytes per launch in the unit of alg_bytes_per_launch",
                      "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
                      "alg_bytes_per_launch": kbytes / klaunch if klaunch else None,
                      "note": "device_ms_per_step are HIP-event times on each kernel's own stream; streams overlap, so they do not add up to ms_per_step",

@@ -68,6 +68,12 @@ int pga_align_groups(const pga_params_t *params, int32_t n_groups, const int64_t
 typedef struct pga_batch_s pga_batch_t;
 int pga_batch_create(int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out);
 int pga_batch_align(pga_batch_t *batch, const pga_params_t *params, pga_result_t **out);
+/* The batch of the next self-merge round: a sequence with seqs[i] == NULL is the src_index[i]-th sequence of `old` (numbered in hand-over
+ * order) and is copied device to device from its packed store; the others are handed over as in pga_batch_create (block
+ * sequences stay resident across rounds; the reference re-copies every block as ASCII per call, minimap2/src/index.rs:31-37).  seq_lens[i]
+ * of a derived sequence must equal its source's.  `old` is not modified and may be freed afterwards. */
+int pga_batch_derive(const pga_batch_t *old, int32_t n_groups, const int64_t *group_off, const char *const *seqs, const int64_t *src_index,
+                     const uint32_t *seq_lens, const char *const *names, pga_batch_t **out);
 /* Multi-GPU hosts, waves with fewer groups than ranks (the reference parallelises over the queries of one index,
  * align_with_minimap2_lib.rs:64-74): every shard indexes ALL sequences of the batch and maps, of every group, a contiguous range of the
  * queries (balanced by length).  The shards' match lists are disjoint; their union ordered by (group, query) is pga_batch_align's list. */

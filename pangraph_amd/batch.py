@@ -63,6 +63,8 @@ def lib():
         d.pga_batch_align_shard.restype = C.c_int
         d.pga_batch_align_shard.argtypes = [C.c_void_p, C.POINTER(pga_params_t), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         d.pga_batch_free.argtypes = [C.c_void_p]
+        d.pga_batch_derive.restype = C.c_int
+        d.pga_batch_derive.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         d.pga_result_n_matches.restype = C.c_int64
         d.pga_result_n_matches.argtypes = [C.c_void_p]
         d.pga_result_matches.restype = C.POINTER(pga_match_t)
@@ -201,6 +203,37 @@ class ResidentBatch:
             self.close()
         except Exception:
             pass
+
+
+class DerivedBatch(ResidentBatch):
+    """The batch of the next self-merge round (pga_batch_derive): `groups` holds sequences (str / bytes) or ints -- an int i means "the i-th
+    sequence of `old`, as it lies on the device" (numbered in the order `old` was handed over); only the others are uploaded."""
+
+    def __init__(self, old: ResidentBatch, groups, names):
+        flat, src, lens, flat_names, off = [], [], [], [], [0]
+        old_lens = [old.pb.lens[i] for i in range(sum(1 for _ in old.pb.names))]
+        for g, nm in zip(groups, names):
+            for s, n in zip(g, nm):
+                if isinstance(s, int):
+                    flat.append(None); src.append(s); lens.append(old_lens[s])
+                else:
+                    b = s if isinstance(s, bytes) else s.encode()
+                    flat.append(b); src.append(-1); lens.append(len(b))
+                flat_names.append(n.encode())
+            off.append(len(flat))
+        n = len(flat)
+
+        class _PB:
+            pass
+        pb = _PB()
+        pb.n_groups = len(groups); pb.names = [x.decode() for x in flat_names]; pb._keep = (flat, flat_names)
+        pb.seqs = (C.c_char_p * n)(*flat); pb.cnames = (C.c_char_p * n)(*flat_names)
+        pb.lens = (C.c_uint32 * n)(*lens); pb.off = (C.c_int64 * (len(groups) + 1))(*off); pb.total_bases = sum(lens)
+        self.pb = pb
+        self.h = C.c_void_p()
+        srcs = (C.c_int64 * n)(*src)
+        if lib().pga_batch_derive(old.h, pb.n_groups, pb.off, pb.seqs, srcs, pb.lens, pb.cnames, C.byref(self.h)) != 0:
+            raise PgaError(lib().pga_last_error().decode())
 
 
 def align_prepared(pb: PreparedBatch, sensitivity: int = 10, kmer_length: Optional[int] = None, indel_len_threshold: int = 100,

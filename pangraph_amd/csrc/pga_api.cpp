@@ -141,7 +141,8 @@ static void idx_sketch_index(PgaIdx &ix)
 	ix.indexed = true;
 }
 
-static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp = 1, const int64_t *grp_off = nullptr, bool do_index = true)
+static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp = 1, const int64_t *grp_off = nullptr, bool do_index = true,
+                         const SeqFrom *from = nullptr, const uint8_t *const *from_probe = nullptr)
 {
 	require_device();
 	std::unique_ptr<PgaIdx> ix(new PgaIdx());
@@ -152,7 +153,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	double t0 = now_s();
 	const int64_t one_grp[2] = {0, n};
 	if (!grp_off) grp_off = one_grp, n_grp = 1;
-	upload_seqs(ix->S, n, seq, len, name, n_grp, grp_off, ix->st);
+	upload_seqs(ix->S, n, seq, len, name, n_grp, grp_off, ix->st, from, from_probe);
 	ix->names = ix->S.name;
 	ix->seq_hdr.resize((size_t)n);
 	for (int i = 0; i < n; ++i) {
@@ -441,10 +442,41 @@ extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, co
 struct BatchesInFlight { BatchesInFlight() { batch_call_enter(); } ~BatchesInFlight() { batch_call_leave(); } };
 struct pga_batch_s { std::vector<std::unique_ptr<PgaIdx>> parts; std::vector<int> g0; std::vector<std::vector<int64_t>> goff; int w = 0, k = 0; uint64_t bases = 0; };
 
+static int batch_create_impl(const pga_batch_s *old, const int64_t *src_index, int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out);
 extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out)
+{
+	return batch_create_impl(nullptr, nullptr, n_groups, group_off, seqs, seq_lens, names, out);
+}
+// The next self-merge round of a merge (graph_merging.rs:26-69) maps the merged graph: most blocks are the blocks of the round before.
+// A sequence with seqs[i] == NULL is taken from `old` (its src_index[i]-th sequence, in the order they were handed over) by a device-to-
+// device copy of its packed bases; only the others cross PCIe.  The reference re-copies every sequence as an ASCII C string on every
+// find_matches call (packages/minimap2/src/index.rs:31-37, map.rs:377-381).  `old` stays valid and may be freed afterwards.
+extern "C" int pga_batch_derive(const pga_batch_t *old, int32_t n_groups, const int64_t *group_off, const char *const *seqs, const int64_t *src_index, const uint32_t *seq_lens,
+                                const char *const *names, pga_batch_t **out)
+{
+	if (!old || !src_index) { *out = nullptr; set_err("pga_batch_derive: null batch or index array"); return -1; }
+	return batch_create_impl(old, src_index, n_groups, group_off, seqs, seq_lens, names, out);
+}
+static int batch_create_impl(const pga_batch_s *old, const int64_t *src_index, int32_t n_groups, const int64_t *group_off, const char *const *seqs, const uint32_t *seq_lens, const char *const *names, pga_batch_t **out)
 {
 	*out = nullptr;
 	try {
+		// where the sequences of the old batch lie: (part, index in the part) by their global index
+		std::vector<int64_t> old_first;
+		if (old) { old_first.push_back(0); for (auto &p : old->parts) old_first.push_back(old_first.back() + p->S.n_seq); }
+		std::vector<SeqFrom> from; std::vector<const uint8_t*> from_probe;
+		if (old) {
+			const int64_t n_all = group_off[n_groups];
+			from.assign((size_t)n_all, SeqFrom{PkBases{nullptr, nullptr}, 0}); from_probe.assign((size_t)n_all, nullptr);
+			for (int64_t i = 0; i < n_all; ++i) if (!seqs[i]) {
+				const int64_t g = src_index[i];
+				if (g < 0 || g >= old_first.back()) throw std::runtime_error("pga_batch_derive: source index outside the old batch");
+				const size_t p = (size_t)(std::upper_bound(old_first.begin(), old_first.end(), g) - old_first.begin()) - 1;
+				const SeqSet &S = old->parts[p]->S; const size_t li = (size_t)(g - old_first[p]);
+				if (S.len[li] != seq_lens[i]) throw std::runtime_error("pga_batch_derive: length of a derived sequence differs from its source");
+				from[(size_t)i] = SeqFrom{S.bases(), S.off[li]}; from_probe[(size_t)i] = S.probe.data() + li * 64;
+			}
+		}
 		std::unique_ptr<pga_batch_s> B(new pga_batch_s());
 		// Sub-batches: at most PGA_MAX_BATCH_BASES each (32-bit anchor indices), and -- when the batch is large enough -- at
 		// least PGA_PARTS of them (default 1; 2 pays on very large batches): the parts are aligned CONCURRENTLY, each on its own stream, so the
@@ -472,7 +504,7 @@ extern "C" int pga_batch_create(int32_t n_groups, const int64_t *group_off, cons
 			for (int g = g0; g <= g1; ++g) goff[g - g0] = group_off[g] - b;
 			if (n > 0) {
 				// w,k are not known yet: upload only (w=k=1 placeholders are overwritten by pga_batch_align)
-				B->parts.emplace_back(idx_build(1, 1, (int)n, seqs + b, seq_lens + b, names + b, g1 - g0, goff.data(), false));
+				B->parts.emplace_back(idx_build(1, 1, (int)n, seqs + b, seq_lens + b, names + b, g1 - g0, goff.data(), false, old ? from.data() + b : nullptr, old ? from_probe.data() + b : nullptr));
 				B->g0.push_back(g0); B->goff.push_back(goff); B->bases += bases;
 			}
 			g0 = g1;

@@ -163,7 +163,9 @@ int thread_budget();
 void set_part_concurrency(int n);
 int part_concurrency();             // concurrent parts of this call, or batch calls in flight in the process, whichever is larger
 void batch_call_enter(); void batch_call_leave();
-void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st);
+struct SeqFrom { PkBases store; uint64_t pos; };       // where a sequence that is already resident lies (pga_batch_derive)
+void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st,
+                 const SeqFrom *from = nullptr, const uint8_t *const *from_probe = nullptr);
 void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm = nullptr);
 std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f, hipStream_t st);
 

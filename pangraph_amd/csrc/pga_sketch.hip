@@ -107,7 +107,33 @@ void k_encode_pk(const uint4 *__restrict__ raw, uint32_t *__restrict__ pk2, uint
 // staging buffers, chunk by chunk, while the previous chunk is on its way over PCIe -- and are encoded THERE (k_encode_pk).  The
 // host keeps no copy of the bases: nothing on the host reads them (pga_align.cpp), except 64 probe positions per sequence that let
 // mm_map() check that a query really is the indexed sequence of that name.
-void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st)
+// sequences that are already resident (pga_batch_derive): seq[i] == nullptr, their bases are old store `from[i].store` at base position
+// `from[i].pos`; they are copied device to device into their place of the new store after the host's sequences are encoded
+__global__ void k_repack(uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmask, uint64_t n_words, const uint64_t *__restrict__ off, int n_seq, const SeqFrom *__restrict__ from)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words) return;
+	const uint64_t p0 = w << 4;
+	if (p0 >= off[n_seq]) return;
+	int lo = 0, hi = n_seq - 1;                                        // the sequence that holds base p0
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= p0) lo = mid; else hi = mid - 1; }
+	uint32_t bits = pk2[w], nm = nmask[w];
+	bool touched = false;
+	for (uint32_t j = 0; j < 16; ++j) {
+		const uint64_t p = p0 + j;
+		while (lo < n_seq && off[lo + 1] <= p) ++lo;
+		if (lo >= n_seq) break;
+		const SeqFrom F = from[lo];
+		if (!F.store.pk2) continue;
+		const int c = F.store.at(F.pos + (p - off[lo]));
+		bits = (bits & ~(3u << (2 * j))) | ((uint32_t)(c & 3) << (2 * j));
+		nm = (nm & ~(1u << j)) | ((c > 3 ? 1u : 0u) << j);
+		touched = true;
+	}
+	if (touched) { pk2[w] = bits; nmask[w] = (uint16_t)nm; }
+}
+
+void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st, const SeqFrom *from, const uint8_t *const *from_probe)
 {
 	S.n_seq = n;
 	S.off.assign((size_t)n + 1, 0); S.len.assign(len, len + n); S.name.resize(n);
@@ -117,6 +143,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	for (int i = 0; i < n; ++i) {
 		const uint32_t L = len[i]; const uint32_t step = L > 64 ? L / 64 : 1;
 		int k = 0;
+		if (!seq[i]) { if (!from || !from[i].store.pk2) throw std::runtime_error("pga: sequence without bases"); if (from_probe && from_probe[i]) memcpy(&S.probe[(size_t)i * 64], from_probe[i], 64); continue; }
 		for (uint32_t p = 0; p < L && k < 64; p += step, ++k) S.probe[(size_t)i * 64 + k] = nt4_host((uint8_t)seq[i][p]);
 	}
 	// sequences are padded to a 16-byte multiple (and 64 more) so that wide loads never straddle the allocation
@@ -139,7 +166,8 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 				for (uint64_t p = lo; p < hi;) {
 					while (S.off[(size_t)i + 1] <= p) ++i;
 					const uint64_t stop = std::min<uint64_t>(hi, S.off[(size_t)i + 1]);
-					memcpy(x.pin + (p - b), seq[i] + (p - S.off[(size_t)i]), (size_t)(stop - p));
+					if (seq[i]) memcpy(x.pin + (p - b), seq[i] + (p - S.off[(size_t)i]), (size_t)(stop - p));
+					else memset(x.pin + (p - b), 'N', (size_t)(stop - p));       // resident elsewhere: filled in by k_repack
 					p = stop;
 				}
 			};
@@ -165,6 +193,18 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	PGA_HIP(hipMemsetAsync(S.d_nmask.p + padded / 16, 0xff, 8 * sizeof(uint16_t), st));
 	S.d_off.upload(S.off, st);
 	S.d_len.upload(S.len, st);
+	if (from) {
+		bool any = false; for (int i = 0; i < n; ++i) any |= !seq[i];
+		if (any && S.total) {
+			std::vector<SeqFrom> f(from, from + n);
+			for (int i = 0; i < n; ++i) if (seq[i]) f[(size_t)i].store = PkBases{nullptr, nullptr};
+			DBuf<SeqFrom> d_from; d_from.upload(f, st);
+			const uint64_t n_words = padded / 16;
+			hipLaunchKernelGGL(k_repack, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, S.d_pk2.p, S.d_nmask.p, n_words, S.d_off.p, n, d_from.p);
+			PGA_HIP(hipGetLastError());
+			PGA_HIP(hipStreamSynchronize(st));
+		}
+	}
 	S.n_grp = n_grp;
 	S.grp_off.assign(grp_off, grp_off + n_grp + 1);
 	S.grp_of_seq.assign((size_t)n, 0);

@@ -35,7 +35,7 @@ __device__ __forceinline__ void rs_push2(RsRun *out, uint32_t *n_out, RsRun *out
 // one wave per array: small arrays are finished here, the others enter the run queue at their first non-trivial level
 __global__ __launch_bounds__(64)
 void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int64_t *__restrict__ len, int n_seg, const uint32_t *__restrict__ flag, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
-               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, RsRun *__restrict__ out_b, uint32_t *__restrict__ n_out_b, uint32_t cap_b)
+               RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, RsRun *__restrict__ out_b, uint32_t *__restrict__ n_out_b, uint32_t cap_b, uint32_t big_min)
 {
 	__shared__ RsLds L;
 	const int s = blockIdx.x, lane = threadIdx.x;
@@ -47,7 +47,7 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 	const uint64_t vary = rs_varying_bits(a + b, n, lane);
 	if (vary == 0) return;
 	const int shift = (63 - __clzll((long long)vary)) & ~7;
-	if (out_b && n >= RSB_MIN) rs_push(out_b, n_out_b, cap_b, b, (uint32_t)n, shift, vary, lane);
+	if (out_b && n >= (int64_t)big_min) rs_push(out_b, n_out_b, cap_b, b, (uint32_t)n, shift, vary, lane);
 	else rs_push2(out, n_out, out_s, n_out_s, cap, b, (uint32_t)n, shift, vary, lane);
 }
 
@@ -55,7 +55,7 @@ void k_rs_init(u128 *__restrict__ a, const uint64_t *__restrict__ off, const int
 __global__ __launch_bounds__(RSB_NT)
 void k_rs_pass_big(u128 *__restrict__ a, const RsRun *__restrict__ in, const uint32_t *__restrict__ n_in, RsRun *__restrict__ out_b, uint32_t *__restrict__ n_out_b, RsRun *__restrict__ out, uint32_t *__restrict__ n_out,
                    RsRun *__restrict__ out_s, uint32_t *__restrict__ n_out_s, uint32_t cap, uint32_t cap_b, uint32_t *__restrict__ work, unsigned long long *__restrict__ prof, uint32_t *__restrict__ rend_all, uint8_t *__restrict__ dig_all,
-                   RsHint hint, u128 *__restrict__ tmp_all, uint2 *__restrict__ lg_all, uint4 *__restrict__ blg_all, int run_min, int pass_no)
+                   RsHint hint, u128 *__restrict__ tmp_all, uint2 *__restrict__ lg_all, uint4 *__restrict__ blg_all, int run_min, int pass_no, uint32_t big_min)
 {
 	__shared__ RsBigLds S;
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -162,7 +162,7 @@ void k_rs_pass_big(u128 *__restrict__ a, const RsRun *__restrict__ in, const uin
 					continue;
 				}
 				if (follow && o == big_off && c == big_len) { if (lane == 0) S.ctl[10] = 1u; continue; }
-				if (c >= RSB_MIN) rs_push(out_b, n_out_b, cap_b, g0, c, next, R.vary, lane);
+				if (c >= big_min) rs_push(out_b, n_out_b, cap_b, g0, c, next, R.vary, lane);
 				else rs_push2(out, n_out, out_s, n_out_s, cap, g0, c, next, R.vary, lane);
 			}
 			rs_fence_wg();
@@ -449,9 +449,11 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	ctr.zero(st);
 	// runs of RSB_MIN records or more go to the workgroup kernel (pga_sort_big.h); PGA_RS_NO_BIG=1 keeps everything on single waves
 	static const bool use_big = getenv("PGA_RS_NO_BIG") == nullptr && getenv("PGA_NO_RUNWALK") == nullptr && getenv("PGA_NO_TWOBUCKET") == nullptr && getenv("PGA_NO_DIGITWALK") == nullptr && getenv("PGA_RS_ASYNC") == nullptr;
-	const uint32_t cap_b = use_big ? (uint32_t)std::min<uint64_t>(n_total / RSB_MIN + 2, cap) : 1u;
+	static const unsigned big_grid = getenv("PGA_RS_BIG_GRID") ? (unsigned)std::max(1, atoi(getenv("PGA_RS_BIG_GRID"))) : 512u;
+	static const uint32_t big_min = getenv("PGA_RS_BIG_MIN") ? (uint32_t)std::max(1025, atoi(getenv("PGA_RS_BIG_MIN"))) : (uint32_t)RSB_MIN;
+	const uint32_t cap_b = use_big ? (uint32_t)std::min<uint64_t>(n_total / big_min + 2, cap) : 1u;
 	DBuf<RsRun> qb0(cap_b), qb1(cap_b);
-	hipLaunchKernelGGL(k_rs_init, dim3((unsigned)n_seg), dim3(64), 0, st, a, d_off, d_len, n_seg, d_flag, q0.p, ctr.p + 0, qs.p, ctr.p + 18, cap, use_big ? qb0.p : (RsRun*)nullptr, ctr.p + 20, cap_b);
+	hipLaunchKernelGGL(k_rs_init, dim3((unsigned)n_seg), dim3(64), 0, st, a, d_off, d_len, n_seg, d_flag, q0.p, ctr.p + 0, qs.p, ctr.p + 18, cap, use_big ? qb0.p : (RsRun*)nullptr, ctr.p + 20, cap_b, big_min);
 	const unsigned grid = 2048;
 	RsRun *qin = q0.p, *qout = q1.p;
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
@@ -483,8 +485,8 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	for (int pass = 0; pass < 8; ++pass) {      // at most one pass per key byte
 		EventTimer ep(st);
 		// (a queue that overflowed cap_b is caught below: big runs are at most n_total / RSB_MIN)
-		if (use_big) hipLaunchKernelGGL(k_rs_pass_big, dim3(std::min<unsigned>(512u, cap_b)), dim3(RSB_NT), 0, st, a, qbin, ctr.p + 20 + 2 * pass, qbout, ctr.p + 20 + 2 * (pass + 1), qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, cap_b, ctr.p + 20 + 2 * pass + 1,
-		                                verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, digb.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p, blg.p, run_min, pass);
+		if (use_big) hipLaunchKernelGGL(k_rs_pass_big, dim3(std::min<unsigned>(big_grid, cap_b)), dim3(RSB_NT), 0, st, a, qbin, ctr.p + 20 + 2 * pass, qbout, ctr.p + 20 + 2 * (pass + 1), qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, cap_b, ctr.p + 20 + 2 * pass + 1,
+		                                verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, digb.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p, blg.p, run_min, pass, big_min);
 		hipLaunchKernelGGL(k_rs_pass, dim3(grid), dim3(64), 0, st, a, qin, ctr.p + 2 * pass, qout, ctr.p + 2 * (pass + 1), qs.p, ctr.p + 18, cap, ctr.p + 2 * pass + 1, verbose ? dprof.p + 4 * pass : (unsigned long long*)nullptr, rend.p, hint ? *hint : RsHint{nullptr, nullptr, nullptr}, tmp2.p, lg.p, run_min);
 		if (verbose) {
 			pass_ms[pass] = ep.stop();

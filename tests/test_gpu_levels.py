@@ -170,3 +170,35 @@ def test_concurrent_mm_map_16_threads(gpu_lib, ref_lib):
     assert len(out) == len(seqs)
     for nm in names:
         assert out[nm] == by_q.get(nm, []), nm
+
+
+def test_block_sequences_stay_resident_across_rounds(gpu_lib):
+    """SURVEY 8(f)-4 / graph_merging.rs:26-69: the self-merge loop maps the merged graph again and again; most blocks of a round are the
+    blocks of the round before.  One handle aligned twice gives the same list twice (nothing is re-uploaded), and the batch of the next round
+    DERIVED from it -- kept blocks copied device to device out of the packed store, at new offsets, next to newly uploaded ones -- aligns
+    exactly like a batch built from scratch from the same sequences."""
+    from pangraph_amd import batch
+    from pangraph_amd.synth import evolve_population, random_seq, mutate
+    rng = np.random.default_rng(12)
+    pop = evolve_population(31, 14, 30011, snp=0.01, indel=0.001, n_inv=1, n_ins=1, n_del=1, max_event=3000)       # odd lengths: nothing is word-aligned
+    pop = [s if isinstance(s, str) else s.tobytes().decode() for s in pop]
+    names = [str(70001 + 7919 * i) for i in range(len(pop))]
+    g_old = [pop[0:5], pop[5:9], pop[9:14]]
+    n_old = [names[0:5], names[5:9], names[9:14]]
+    rb = batch.ResidentBatch(batch.PreparedBatch(g_old, n_old))
+    first = [rows_to_lists(r) for r in rb.align(sensitivity=10, want_rows=True).groups]
+    again = [rows_to_lists(r) for r in rb.align(sensitivity=10, want_rows=True).groups]
+    assert first == again and sum(len(r) for r in first) > 10
+    # the next round: blocks 1, 3, 4 of group 0 merged away into a new consensus, group 1 untouched, group 2 reordered with one new block
+    new_a = mutate(rng, np.frombuffer(pop[1].encode(), dtype=np.uint8), snp=0.004, indel=0.0).tobytes().decode()
+    new_b = random_seq(rng, 7777).tobytes().decode()
+    g_new = [[0, new_a, 2], [5, 6, 7, 8], [13, 9, new_b, 11]]
+    n_new = [[names[0], "424242", names[2]], names[5:9], [names[13], names[9], "99", names[11]]]
+    derived = batch.DerivedBatch(rb, g_new, n_new)
+    got = [rows_to_lists(r) for r in derived.align(sensitivity=10, want_rows=True).groups]
+    flat_old = [s for g in g_old for s in g]
+    g_ref = [[flat_old[s] if isinstance(s, int) else s for s in g] for g in g_new]
+    want = product_align_groups(g_ref, n_new, sensitivity=10)
+    assert got == want and sum(len(r) for r in got) > 5
+    rb.close()                                                           # the old batch may go: the derived one owns its copy
+    assert [rows_to_lists(r) for r in derived.align(sensitivity=10, want_rows=True).groups] == want
