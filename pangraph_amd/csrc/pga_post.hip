@@ -29,6 +29,17 @@ __device__ __forceinline__ int post_qbase(PkBases bases, uint64_t q_off, int qle
 	return c < 4 ? 3 - c : 4;
 }
 
+// sixteen bases from base position pos on (any alignment): w = their 2-bit codes (base i at bits 2i), m = their "not ACGT" bits
+__device__ __forceinline__ void pk_window16(const PkBases &B, uint64_t pos, uint32_t &w, uint32_t &m)
+{
+	const uint64_t i = pos >> 4; const uint32_t sft = (uint32_t)pos & 15u;
+	const uint64_t ww = (uint64_t)B.pk2[i] | (uint64_t)B.pk2[i + 1] << 32;
+	w = (uint32_t)(ww >> (2u * sft));
+	const uint32_t mm = (uint32_t)B.nmask[i] | (uint32_t)B.nmask[i + 1] << 16;
+	m = (mm >> sft) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_sum_incl(v), 63); }
+
 // ------------------------------------------------------------------------------------------------ identity probes
 // One WAVE per probe at a time (grid-stride): the lanes read 64 consecutive bases of both windows per step (coalesced; a lane per
 // probe would pull a whole cache line for every byte), the mismatch count is a ballot + popcount, the early exit is uniform.
@@ -244,42 +255,62 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 			const uint32_t c = cg[k], op = c & 0xf; const int len = (int)(c >> 4);
 			if (op == 0) {
 				int ambi = 0, diff = 0;
-				// one 64-base block: counts, and the clamped running score in its block form (see the header)
-				auto block = [&](int tb, int qb, bool on, int cnt) {
-					const bool is_ambi = on && (tb > 3 || qb > 3), is_diff = on && !is_ambi && tb != qb;
-					const int x = !on ? 0 : is_ambi ? sc_ambi : is_diff ? sc_mis : sc_mch;
-					const unsigned long long m_ambi = __ballot(is_ambi), m_diff = __ballot(is_diff);
-					ambi += __popcll(m_ambi), diff += __popcll(m_diff);
-					if ((m_ambi | m_diff) == 0 && sc_mch > 0) { s += (double)sc_mch * (double)cnt; smax = smax > s ? smax : s; return; }   // all matches: s only grows
-					const int P = (int)wave_prefix_sum_incl((uint32_t)x);           // lanes beyond the run add 0: their P repeats the last value
-					const int Pm = wave_prefix_min_incl(P);
-					const double neg_in = -s, pm = (double)Pm;
-					const double floor_ = neg_in < pm ? neg_in : pm;
-					const double si = (double)P - floor_;
-					const double mx = -wave_min_f64_key(-(on ? si : 0.0));          // maximum of s over the block's valid positions
+				// 1024 bases per trip, sixteen CONSECUTIVE bases per lane, straight from the packed store: two 32-bit windows (target, query --
+				// the reverse strand is the window read backwards and complemented) XORed give the sixteen comparisons of a lane at once; four
+				// word loads per lane and side cover what sixty-four byte loads did.  The clamped running score in its block form (see the
+				// header): a lane sums its sixteen scores and takes their prefix minimum, one prefix sum and one prefix minimum across the lanes
+				// place them, a second pass over the sixteen positions evaluates s at every position (int32 sums, the reference's doubles).
+				for (int b = 0; b < len; b += 1024) {
+					const int j0 = b + 16 * lane;
+					const int v = len - j0 <= 0 ? 0 : len - j0 >= 16 ? 16 : len - j0;
+					const int n_tot = len - b < 1024 ? len - b : 1024;
+					uint32_t tw = 0, tm = 0, qw = 0, qm = 0;
+					if (v > 0) {
+						pk_window16(bases, t0 + (uint64_t)(toff + j0), tw, tm);
+						const int pj = q0 + qoff + j0;
+						if (!F.q_rev) pk_window16(bases, F.q_off + (uint64_t)pj, qw, qm);
+						else {
+							const int64_t hi = (int64_t)F.qlen_full - 1 - pj;           // the base of j0; the next fifteen lie below it
+							if (hi >= 15 || F.q_off >= 16) {
+								uint32_t w, m;
+								pk_window16(bases, F.q_off + (uint64_t)(hi - 15), w, m);
+								w = __brev(w); w = ((w >> 1) & 0x55555555u) | ((w & 0x55555555u) << 1);     // sixteen 2-bit groups in reverse order
+								qw = ~w; qm = __brev(m) >> 16;
+							} else {
+								for (int i = 0; i < v; ++i) { const int c = post_qbase(bases, F.q_off, F.qlen_full, q0, F.q_rev, qoff + j0 + i); if (c > 3) qm |= 1u << i; else qw |= (uint32_t)c << (2 * i); }
+							}
+						}
+					}
+					const uint32_t vm16 = v >= 16 ? 0xffffu : (1u << v) - 1u, vm32 = v >= 16 ? ~0u : (1u << (2 * v)) - 1u;
+					uint32_t amb = (tm | qm) & vm16;
+					uint32_t sp = amb; sp = (sp | sp << 8) & 0x00ff00ffu; sp = (sp | sp << 4) & 0x0f0f0f0fu; sp = (sp | sp << 2) & 0x33333333u; sp = (sp | sp << 1) & 0x55555555u;
+					uint32_t d2 = tw ^ qw; d2 = (d2 | d2 >> 1) & 0x55555555u & vm32 & ~sp;        // bit 2i: base i differs (and neither side is ambiguous)
+					const int n_a = (int)wave_sum_u32((uint32_t)__popc(amb)), n_d = (int)wave_sum_u32((uint32_t)__popc(d2));
+					ambi += n_a, diff += n_d;
+					if (n_a == 0 && n_d == 0 && sc_mch > 0) { s += (double)sc_mch * (double)n_tot; smax = smax > s ? smax : s; continue; }   // all matches: s only grows
+					int T = 0, Lm = 0x3fffffff;
+					for (int i = 0; i < v; ++i) { const int x = (amb >> i & 1u) ? sc_ambi : (d2 >> (2 * i) & 1u) ? sc_mis : sc_mch; T += x; Lm = Lm < T ? Lm : T; }
+					const int Bx = (int)wave_prefix_sum_incl((uint32_t)T) - T;          // sum of the scores in front of this lane
+					const int Gi = wave_prefix_min_incl(v > 0 ? Bx + Lm : 0x3fffffff);    // prefix minimum up to and including this lane
+					const int Ge = wave_shr1(Gi, 0x3fffffff);                            // ... of the lanes in front
+					const double neg_in = -s;
+					double lmax = 0.0, slast = 0.0;
+					{
+						int run = Bx, pmin = Ge;
+						for (int i = 0; i < v; ++i) {
+							const int x = (amb >> i & 1u) ? sc_ambi : (d2 >> (2 * i) & 1u) ? sc_mis : sc_mch;
+							run += x; pmin = pmin < run ? pmin : run;
+							const double pm = (double)pmin, floor_ = neg_in < pm ? neg_in : pm;
+							const double si = (double)run - floor_;
+							lmax = lmax > si ? lmax : si; slast = si;
+						}
+					}
+					const double mx = -wave_min_f64_key(-(v > 0 ? lmax : 0.0));
 					smax = smax > mx ? smax : mx;
-					const long long bits = __double_as_longlong(si);
-					const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
-					s = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);   // lane 63 carries P of the last valid base, and its prefix minimum
-				};
-				int b = 0;
-				// eight blocks per trip: sixteen loads in flight per lane (a single block per trip would pay the full memory latency every 64 bases)
-				for (; b + 512 <= len; b += 512) {
-					int tb[8], qb[8];
-#pragma unroll
-					for (int u = 0; u < 8; ++u) { tb[u] = post_tbase(bases, t0, toff + b + 64 * u + lane); qb[u] = post_qbase(bases, F.q_off, F.qlen_full, q0, F.q_rev, qoff + b + 64 * u + lane); }
-					bool clean = true;
-#pragma unroll
-					for (int u = 0; u < 8; ++u) clean &= tb[u] == qb[u] && tb[u] <= 3;
-					if (__ballot(!clean) == 0 && sc_mch > 0) { s += (double)sc_mch * 512.0; smax = smax > s ? smax : s; continue; }
-#pragma unroll
-					for (int u = 0; u < 8; ++u) block(tb[u], qb[u], true, 64);
-				}
-				for (; b < len; b += 64) {
-					const int l = b + lane; const bool on = l < len;
-					int tb = 0, qb = 0;
-					if (on) { tb = post_tbase(bases, t0, toff + l); qb = post_qbase(bases, F.q_off, F.qlen_full, q0, F.q_rev, qoff + l); }
-					block(tb, qb, on, len - b < 64 ? len - b : 64);
+					const int ll = (n_tot - 1) >> 4;                                     // the lane of the trip's last base
+					const long long bits = __double_as_longlong(slast);
+					const int lo = rl((int)(bits & 0xffffffffLL), ll), hi2 = rl((int)(bits >> 32), ll);
+					s = __longlong_as_double(((long long)hi2 << 32) | (unsigned)lo);
 				}
 				blen += len - ambi, mlen += len - (ambi + diff), n_ambi += ambi;
 				toff += len, qoff += len;
