@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work per core (0 disables)")
     ap.add_argument("--schedule", choices=("ready", "waves"), default=os.environ.get("PGA_BENCH_SCHEDULE", "ready"),
                     help="ready: a find_matches call starts when the calls it depends on are done (pangraph_amd/schedule.py); waves: level-synchronous, one batch per wave")
+    ap.add_argument("--inputs", choices=("resident", "host"), default=os.environ.get("PGA_BENCH_INPUTS", "resident"),
+                    help="resident: the block sequences of every call are in HBM (packed store) before the timed region, a call takes its inputs by a "
+                         "device-to-device copy (pga_batch_derive); host: every call hands over host strings inside the timed region (PCIe-inclusive rate)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("PGA_BENCH_SLOTS", 3)), help="batches in flight (ready-set schedule)")
     ap.add_argument("--cap-gbp", type=float, default=float(os.environ.get("PGA_BENCH_CAP_GBP", 1.2)), help="largest batch of the ready-set schedule")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the one-off timings of the SURVEY 8(f) rows (guide tree, map_variations) reported next to the headline")
@@ -311,6 +314,19 @@ def main():
         if owner[t.tid] in (rank, -1) or world == 1:
             t.prepare()
     slot_threads = int(os.environ.get("PGA_BENCH_SLOT_THREADS", max(2, n_threads // max(1, min(args.slots, 2)))))
+    # inputs resident before the timed region: one batch handle holds the sequences of every call this rank can meet (0.375 B per base in
+    # HBM); lib_first[tid] = index of the call's first sequence in it.  Only the ready-set schedule takes its inputs from there.
+    lib, lib_first = None, None
+    if args.inputs == "resident" and args.schedule == "ready":
+        t_lib = time.time()
+        own = [t for t in tasks if owner[t.tid] in (rank, -1) or world == 1]
+        lib_first = {}
+        n_lib = 0
+        for t in own:
+            lib_first[t.tid] = n_lib
+            n_lib += len(t.seqs)
+        lib = batch.ResidentBatch(sched.TaskBatch(own))
+        t_lib = time.time() - t_lib
 
     def step_ready():
         from pangraph_amd.dist import MATCH_DTYPE, gather_blobs
@@ -319,9 +335,9 @@ def main():
         recs, pools, pool_len = [], [], [0]
 
         def run_batch(ts):
-            tb = sched.TaskBatch(ts)
+            tb = sched.TaskBatch(ts, lib_first)
             t0 = time.perf_counter()
-            rb = batch.ResidentBatch(tb)                          # hand-over: inside the timed region
+            rb = batch.ResidentBatch(tb, derive_from=lib)         # inputs resident: device-to-device; --inputs host: hand-over inside the timed region
             t1 = time.perf_counter()
             res = rb.align(sensitivity=10, want_raw=world > 1, n_threads=slot_threads)
             t2 = time.perf_counter()
@@ -371,9 +387,9 @@ def main():
         while top:
             level = [tid for tid in top if all(d in done for d in tasks[tid].deps)]
             ts = [tasks[i] for i in sorted(level)]
-            tb = sched.TaskBatch(ts)
+            tb = sched.TaskBatch(ts, lib_first)
             t0 = time.perf_counter()
-            rb = batch.ResidentBatch(tb)
+            rb = batch.ResidentBatch(tb, derive_from=lib)
             t1 = time.perf_counter()
             res = rb.align(sensitivity=10, want_raw=True, n_threads=n_threads, shard=(rank, world))
             t2 = time.perf_counter()
@@ -471,7 +487,10 @@ def main():
                                f"(tree heights 1..{len(waves) // 2} x self-merge rounds 0,1), {sum(len(g) for _, g, _ in waves)} find_matches calls, "
                                f"U = {units / 1e9:.2f} Gbp per step (asm10, -c -X -s 90)" + (" [LEAF LEVEL ONLY]" if args.leaf_only else ""),
                    "genomes": args.genomes, "genome_length": args.length, "seed": args.seed, "waves": len(waves),
-                   "timed_region": "per batch: pga_batch_create (H2D + encoding) + pga_batch_align; + match-list gather",
+                   "inputs": ("resident: the block sequences of every find_matches call lie in HBM (packed store, 0.375 B per base) before the timed region; a call takes "
+                              "them by a device-to-device copy (pga_batch_derive)" if lib is not None else "host: every call hands over host strings (PCIe-inclusive rate)"),
+                   "timed_region": ("per batch: pga_batch_derive (device-to-device copy of the call's sequences) + pga_batch_align; + match-list gather" if lib is not None else
+                                    "per batch: pga_batch_create (H2D + encoding) + pga_batch_align; + match-list gather"),
                    "schedule": (f"ready set: every find_matches call starts when the calls it depends on are done (children's last round, own previous round); "
                                 f"{args.slots} batches in flight, <= {args.cap_gbp} Gbp each" if args.schedule == "ready" else "level-synchronous waves, one batch per wave"),
                    "parallelism": (f"guide tree cut into subtrees dealt to {world} rank(s) by base count, no data-path collective, one match-list gather to rank 0, "
@@ -496,6 +515,7 @@ def main():
         "waves_rank0": [{"wave": w, "Mbp": b / 1e6, "hand_over_s": round(c, 4), "align_s": round(a, 4), "matches": int(m)} for w, b, c, a, m in last["per_wave"]],
         "batches_rank0": [{"t0": round(a, 4), "t1": round(b, 4), "calls": n, "Mbp": round(bs / 1e6, 1), "matches": m} for a, b, n, bs, m in sorted(last.get("batches", []))],
         "workload_generation_s": t_gen,
+        "inputs_made_resident_s": t_lib if lib is not None else None,
     }
     if rank == 0:
         if args.cpu_budget > 0 and world == 1:

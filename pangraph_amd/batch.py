@@ -176,10 +176,16 @@ def _stats_dict(st) -> dict:
 class ResidentBatch:
     """Sequences of a PreparedBatch copied to HBM once (pga_batch_create); align() runs the whole hot path on them."""
 
-    def __init__(self, pb: PreparedBatch):
+    def __init__(self, pb: PreparedBatch, derive_from: Optional["ResidentBatch"] = None):
+        """derive_from: `pb.src[i]` is the index (in hand-over order) of sequence i in that resident batch and `pb.seqs[i]` is NULL: the bases
+        are copied device to device (pga_batch_derive), nothing crosses PCIe."""
         self.pb = pb
         self.h = C.c_void_p()
-        if lib().pga_batch_create(pb.n_groups, pb.off, pb.seqs, pb.lens, pb.cnames, C.byref(self.h)) != 0:
+        if derive_from is not None:
+            rc = lib().pga_batch_derive(derive_from.h, pb.n_groups, pb.off, pb.seqs, pb.src, pb.lens, pb.cnames, C.byref(self.h))
+        else:
+            rc = lib().pga_batch_create(pb.n_groups, pb.off, pb.seqs, pb.lens, pb.cnames, C.byref(self.h))
+        if rc != 0:
             raise PgaError(lib().pga_last_error().decode())
 
     def align(self, sensitivity: int = 10, kmer_length: Optional[int] = None, indel_len_threshold: int = 100, n_threads: int = 0,

@@ -98,6 +98,16 @@ struct PkBases {
 		const uint32_t b = pk2[w], n = nmask[w];
 		return ((n >> sft) & 1u) ? 4 : (int)((b >> (2u * sft)) & 3u);
 	}
+	// sixteen bases from base position pos on (any alignment): w = their 2-bit codes (base i at bits 2i; 00 where the base is not ACGT),
+	// m = their "not ACGT" bits.  (The stores are padded: the word behind the last one exists.)
+	__device__ __forceinline__ void window16(uint64_t pos, uint32_t &w, uint32_t &m) const
+	{
+		const uint64_t i = pos >> 4; const uint32_t sft = (uint32_t)pos & 15u;
+		const uint64_t ww = (uint64_t)pk2[i] | (uint64_t)pk2[i + 1] << 32;
+		w = (uint32_t)(ww >> (2u * sft));
+		const uint32_t mm = (uint32_t)nmask[i] | (uint32_t)nmask[i + 1] << 16;
+		m = (mm >> sft) & 0xffffu;
+	}
 };
 
 struct SeqSet {

@@ -29,15 +29,6 @@ __device__ __forceinline__ int post_qbase(PkBases bases, uint64_t q_off, int qle
 	return c < 4 ? 3 - c : 4;
 }
 
-// sixteen bases from base position pos on (any alignment): w = their 2-bit codes (base i at bits 2i), m = their "not ACGT" bits
-__device__ __forceinline__ void pk_window16(const PkBases &B, uint64_t pos, uint32_t &w, uint32_t &m)
-{
-	const uint64_t i = pos >> 4; const uint32_t sft = (uint32_t)pos & 15u;
-	const uint64_t ww = (uint64_t)B.pk2[i] | (uint64_t)B.pk2[i + 1] << 32;
-	w = (uint32_t)(ww >> (2u * sft));
-	const uint32_t mm = (uint32_t)B.nmask[i] | (uint32_t)B.nmask[i + 1] << 16;
-	m = (mm >> sft) & 0xffffu;
-}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_sum_incl(v), 63); }
 
 // ------------------------------------------------------------------------------------------------ identity probes
@@ -266,14 +257,14 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 					const int n_tot = len - b < 1024 ? len - b : 1024;
 					uint32_t tw = 0, tm = 0, qw = 0, qm = 0;
 					if (v > 0) {
-						pk_window16(bases, t0 + (uint64_t)(toff + j0), tw, tm);
+						bases.window16(t0 + (uint64_t)(toff + j0), tw, tm);
 						const int pj = q0 + qoff + j0;
-						if (!F.q_rev) pk_window16(bases, F.q_off + (uint64_t)pj, qw, qm);
+						if (!F.q_rev) bases.window16(F.q_off + (uint64_t)pj, qw, qm);
 						else {
 							const int64_t hi = (int64_t)F.qlen_full - 1 - pj;           // the base of j0; the next fifteen lie below it
 							if (hi >= 15 || F.q_off >= 16) {
 								uint32_t w, m;
-								pk_window16(bases, F.q_off + (uint64_t)(hi - 15), w, m);
+								bases.window16(F.q_off + (uint64_t)(hi - 15), w, m);
 								w = __brev(w); w = ((w >> 1) & 0x55555555u) | ((w & 0x55555555u) << 1);     // sixteen 2-bit groups in reverse order
 								qw = ~w; qm = __brev(m) >> 16;
 							} else {

@@ -117,6 +117,14 @@ __global__ void k_repack(uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmas
 	if (p0 >= off[n_seq]) return;
 	int lo = 0, hi = n_seq - 1;                                        // the sequence that holds base p0
 	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= p0) lo = mid; else hi = mid - 1; }
+	if (p0 + 16 <= off[lo + 1]) {                                      // the whole word lies in one sequence: a shifted copy of two source words
+		const SeqFrom F = from[lo];
+		if (!F.store.pk2) return;
+		uint32_t ww, mm;
+		F.store.window16(F.pos + (p0 - off[lo]), ww, mm);
+		pk2[w] = ww; nmask[w] = (uint16_t)mm;
+		return;
+	}
 	uint32_t bits = pk2[w], nm = nmask[w];
 	bool touched = false;
 	for (uint32_t j = 0; j < 16; ++j) {
@@ -152,14 +160,27 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	const uint64_t chunk = (uint64_t)64 << 20;
 	const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
 	if (n_chunks) {
-		struct Stage { uint8_t *pin = nullptr; uint8_t *dev = nullptr; hipEvent_t sent; };
+		struct Stage { uint8_t *pin = nullptr; uint8_t *dev = nullptr; hipEvent_t sent; bool used = false; };
 		Stage sg[2];
-		for (Stage &x : sg) { x.pin = (uint8_t*)pin_alloc(chunk); x.dev = (uint8_t*)dev_alloc(chunk); PGA_HIP(hipEventCreateWithFlags(&x.sent, hipEventDisableTiming)); }
+		bool staged = false; uint64_t n_staged = 0;
 		const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)thread_budget(), 16));
 		for (uint64_t c = 0; c < n_chunks; ++c) {
-			Stage &x = sg[c & 1];
 			const uint64_t b = c * chunk, e = std::min<uint64_t>(S.total, b + chunk);
-			if (c >= 2) PGA_HIP(hipEventSynchronize(x.sent));          // the staging buffer's previous chunk has left the host
+			if (from) {
+				// a chunk that holds only sequences resident elsewhere does not cross PCIe: its words start as "not ACGT" and k_repack fills them
+				bool host = false;
+				for (int i = (int)(std::upper_bound(S.off.begin(), S.off.end(), b) - S.off.begin()) - 1; i < n && S.off[(size_t)i] < e; ++i) if (seq[i] && S.off[(size_t)i + 1] > b && len[i]) { host = true; break; }
+				if (!host) {
+					const uint64_t nbw = (e - b + 15) / 16;
+					PGA_HIP(hipMemsetAsync(S.d_pk2.p + b / 16, 0, nbw * sizeof(uint32_t), st));
+					PGA_HIP(hipMemsetAsync(S.d_nmask.p + b / 16, 0xff, nbw * sizeof(uint16_t), st));
+					continue;
+				}
+			}
+			if (!staged) { for (Stage &x : sg) { x.pin = (uint8_t*)pin_alloc(chunk); x.dev = (uint8_t*)dev_alloc(chunk); PGA_HIP(hipEventCreateWithFlags(&x.sent, hipEventDisableTiming)); } staged = true; }
+			Stage &x = sg[n_staged++ & 1];
+			if (x.used) PGA_HIP(hipEventSynchronize(x.sent));          // the staging buffer's previous chunk has left the host
+			x.used = true;
 			// gather [b, e) of the concatenation: every thread copies a contiguous slice
 			auto gather = [&](uint64_t lo, uint64_t hi) {
 				int i = (int)(std::upper_bound(S.off.begin(), S.off.end(), lo) - S.off.begin()) - 1;
@@ -187,7 +208,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 		}
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipStreamSynchronize(st));
-		for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
+		if (staged) for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
 	}
 	PGA_HIP(hipMemsetAsync(S.d_pk2.p + padded / 16, 0, 8 * sizeof(uint32_t), st));
 	PGA_HIP(hipMemsetAsync(S.d_nmask.p + padded / 16, 0xff, 8 * sizeof(uint16_t), st));

@@ -120,12 +120,20 @@ def topo_order(tasks: List[Task]) -> List[int]:
 class TaskBatch:
     """The flat C arrays pga_batch_create wants, for a list of tasks (one group per task); no copy of the bases."""
 
-    def __init__(self, tasks: Sequence[Task]):
+    def __init__(self, tasks: Sequence[Task], lib_first: Optional[Sequence[int]] = None):
+        """lib_first: the sequences of task t are sequences lib_first[t.tid], lib_first[t.tid] + 1, ... of a batch that is already resident
+        (batch.ResidentBatch(tb, derive_from=that batch)): no base pointer is handed over, `src` holds the indices (pga_batch_derive)."""
         for t in tasks:
             t.prepare()
         self.tasks = list(tasks)
         self.n_groups = len(tasks)
+        self.src = None
+        if lib_first is not None:
+            self._src = np.concatenate([np.arange(lib_first[t.tid], lib_first[t.tid] + len(t.seqs), dtype=np.int64) for t in tasks]) if tasks else np.zeros(0, np.int64)
+            self.src = self._src.ctypes.data_as(C.POINTER(C.c_int64))
         self._ptr = np.concatenate([t.ptr for t in tasks]) if tasks else np.zeros(0, np.uint64)
+        if lib_first is not None:
+            self._ptr = np.zeros_like(self._ptr)
         self._lens = np.concatenate([t.lens for t in tasks]) if tasks else np.zeros(0, np.uint32)
         self._nptr = np.concatenate([t.nptr for t in tasks]) if tasks else np.zeros(0, np.uint64)
         self._off = np.zeros(self.n_groups + 1, dtype=np.int64)

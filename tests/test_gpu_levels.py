@@ -202,3 +202,34 @@ def test_block_sequences_stay_resident_across_rounds(gpu_lib):
     assert got == want and sum(len(r) for r in got) > 5
     rb.close()                                                           # the old batch may go: the derived one owns its copy
     assert [rows_to_lists(r) for r in derived.align(sensitivity=10, want_rows=True).groups] == want
+
+
+@pytest.mark.gpu
+def test_calls_take_their_inputs_from_a_resident_library(gpu_lib):
+    """bench.py --inputs resident: the block sequences of EVERY find_matches call of a build are handed over once (one batch handle, never
+    aligned); a batch of calls is then derived from it -- every sequence by a device-to-device copy of its packed words, nothing crosses PCIe
+    -- and must align exactly like the same calls handed over as host strings."""
+    from pangraph_amd import batch
+    from pangraph_amd import schedule as sched
+    pop = Population(5, 6, 60_013)                                       # odd length: the calls' sequences start at every word phase
+    tasks = sched.build_tasks(pop)
+    first, n = {}, 0
+    for t in tasks:
+        first[t.tid] = n
+        n += len(t.seqs)
+    lib = batch.ResidentBatch(sched.TaskBatch(tasks))
+    picks = [tasks[::2], tasks[1::2], tasks[-3:]]                        # batches that take their calls from all over the library
+    total = 0
+    for ts in picks:
+        host = batch.ResidentBatch(sched.TaskBatch(ts))
+        want = host.align(sensitivity=10, want_raw=True)
+        dev = batch.ResidentBatch(sched.TaskBatch(ts, first), derive_from=lib)
+        got = dev.align(sensitivity=10, want_raw=True)
+        assert np.array_equal(np.asarray(got.raw_matches), np.asarray(want.raw_matches))
+        assert np.array_equal(np.asarray(got.raw_cigars), np.asarray(want.raw_cigars))
+        total += int(want.stats["n_matches"])
+        for r in (want, got):
+            r.close()
+        host.close(); dev.close()
+    assert total > 20
+    lib.close()
