@@ -349,7 +349,7 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //   9      large unbanded first-pass gap fills, one problem spread over several workgroups in column strips (pga_ksw_strips.hip)
 //   10     banded problems whose band ring fits 2048 columns (end extensions, banded fills): rows in registers, one barrier per
 //          diagonal (pga_ksw_lanes.hip); what classes 2 and 3 held before
-//   11     like 10 with 1024-thread workgroups: rings of up to 8192 columns (exact second passes of 2-8 kb, wide bands)
+//   11     like 10 with ONE wave per problem: rings of up to 512 columns (end extensions next to a block end, narrow banded fills)
 //   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
 //          first passes of class 4 keep room for their sequences in LDS)
 #define DP_NCLASS 12
@@ -380,7 +380,7 @@ void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *
 
 bool lanes_eligible(const DpJob &j, int nt);
 size_t lanes_cig_bytes(int q_cap, int t_cap);
-size_t lanes_chunk_bytes();
+size_t lanes_chunk_bytes(int nt);
 void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
@@ -394,11 +394,11 @@ static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
 	if (unbanded && j.tlen <= 256) return 0;
 	if (unbanded && j.tlen <= 512) return 1;
+	static const bool no_narrow = getenv("PGA_NO_LANES_NARROW") != nullptr;   // A/B: narrow rings go to the four-wave workgroups again
+	if (!no_lanes && !no_narrow && allow_band && lanes_eligible(j, 64)) return 11;
 	if (!no_lanes && allow_band && lanes_eligible(j, 256)) return 10;      // (allow_band is off in the second pass over problems a kernel handed back)
-	// (measured slower than the workgroup kernel: sixteen waves each pay the per-diagonal skeleton, four to a SIMD -- 2 x 4 kb second passes
-	// 56 ms against 11-20 ms; kept behind PGA_LANES_BIG=1)
-	static const bool lanes_big = getenv("PGA_LANES_BIG") != nullptr;
-	if (!no_lanes && lanes_big && allow_band && lanes_eligible(j, 1024)) return 11;
+	// (1024-thread workgroups were measured slower than the workgroup kernel: sixteen waves each pay the per-diagonal skeleton, four to a SIMD
+	// -- 2 x 4 kb second passes 56 ms against 11-20 ms)
 	const size_t rows = (size_t)14 * wide_ring(j), l = rows + 2 * (size_t)wide_seqcap(j);
 	if (l <= 48 * 1024) return 2;
 	if (l <= 76 * 1024) return 3;
@@ -560,7 +560,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
 		static const int c8w = getenv("PGA_C8_WAVES") ? atoi(getenv("PGA_C8_WAVES")) : 16;
-		size_t n_waves = c == 11 ? 256 : c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
+		size_t n_waves = c == 11 ? 256 * (size_t)(getenv("PGA_C11_WAVES") ? atoi(getenv("PGA_C11_WAVES")) : 8) : c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
 		if (c == 9) {                                                                   // every problem of the class is in flight at once, each with its whole matrix
@@ -573,11 +573,12 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			// one CIGAR buffer per workgroup + a pool of direction-matrix chunks: what the class would need if every problem ran to its
 			// last diagonal, but not more than half of the budget (most extensions z-drop early; a dry pool hands problems back)
 			int q_cap = 16, t_cap = 16; size_t tot = 0;
-			for (uint32_t id : cls[c]) { q_cap = std::max(q_cap, jobs[id].qlen); t_cap = std::max(t_cap, jobs[id].tlen); tot += need[id] + lanes_chunk_bytes(); }
+			const size_t chunk = lanes_chunk_bytes(c == 11 ? 64 : 256);
+			for (uint32_t id : cls[c]) { q_cap = std::max(q_cap, jobs[id].qlen); t_cap = std::max(t_cap, jobs[id].tlen); tot += need[id] + chunk; }
 			const size_t cigb = n_waves * lanes_cig_bytes(q_cap, t_cap);
-			size_t pool = std::min(tot, std::max(budget / 2, 4 * n_waves * lanes_chunk_bytes()));
-			pool = std::max(pool, 2 * n_waves * lanes_chunk_bytes()) / lanes_chunk_bytes() * lanes_chunk_bytes();
-			lanes_pool_chunks[c - 10] = (uint32_t)(pool / lanes_chunk_bytes()) | (pool >= tot ? 0x80000000u : 0u);   // (top bit: the pool covers every problem in full: no reservation tiers)
+			size_t pool = std::min(tot, std::max(budget / 2, 4 * n_waves * chunk));
+			pool = std::max(pool, 2 * n_waves * chunk) / chunk * chunk;
+			lanes_pool_chunks[c - 10] = (uint32_t)(pool / chunk) | (pool >= tot ? 0x80000000u : 0u);   // (top bit: the pool covers every problem in full: no reservation tiers)
 			waves_of[c] = n_waves;
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], cigb + pool + 256);
 			continue;
@@ -648,7 +649,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		else if (c == 10 || c == 11) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_extd2_lanes(c == 11 ? 1024 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_extd2_lanes(c == 11 ? 64 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }

@@ -38,7 +38,9 @@ namespace pga {
 #define LBT 64
 #define LANES_C 8
 #define LANES_CHUNK (2u << 20)     // bytes of a direction-matrix chunk
+#define LANES_CHUNK_NARROW (512u << 10)   // ... of the one-wave instantiation (rings of at most 512 columns)
 #define LANES_MAXCHUNK 192
+__host__ __device__ constexpr uint32_t lanes_chunk_of(int nt) { return nt <= 64 ? LANES_CHUNK_NARROW : LANES_CHUNK; }
 
 __device__ __forceinline__ void diag_range_l(int r, int qlen, int tlen, int w, int &st0, int &en0)
 {
@@ -73,6 +75,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
                    DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
 	constexpr int NW = NT / 64, C = LANES_C, RC = NT * C;
+	constexpr uint32_t CHUNK = lanes_chunk_of(NT);
 	extern __shared__ __align__(16) uint8_t qq[];       // the query window, orientation and complement resolved
 	__shared__ uint32_t s_job;
 	__shared__ LaneRec s_rec[2][NT / 64];
@@ -126,9 +129,51 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 			int c = bases.at(q_base + (uint64_t)(J.qlen_full - 1 - pj));
 			return c < 4 ? 3 - c : 4;
 		};
-		for (int j = tid; j < qlen; j += NT) qq[j] = (uint8_t)query_at(j);
-		for (int i = tid; i < T + 8; i += NT) tq[i] = (uint8_t)target_at(i);
-		const int rpc = LANES_CHUNK / n_col;                   // diagonals per chunk
+		// the windows, sixteen bases per thread and trip: consecutive j are consecutive store positions, ascending or descending (two word
+		// loads + two mask loads per sixteen bases instead of thirty-two loads); bytes 0..3 = ACGT, 4 = anything else
+		{
+			const bool q_desc = (J.seq_rev != 0) != (J.q_rev != 0);
+			const int64_t q_p0 = (int64_t)q_base + (J.q_rev ? (int64_t)J.qlen_full - 1 - J.qs - (J.seq_rev ? qlen - 1 : 0) : (int64_t)J.qs + (J.seq_rev ? qlen - 1 : 0));   // store position of j = 0
+			const uint32_t cm = J.q_rev ? 0x03030303u : 0u;
+			for (int j0 = 16 * tid; j0 < qlen; j0 += 16 * NT) {
+				const int64_t lo = q_desc ? q_p0 - j0 - 15 : q_p0 + j0;
+				if (lo < 0) { for (int j = j0; j < j0 + 16 && j < qlen; ++j) qq[j] = (uint8_t)query_at(j); continue; }
+				uint32_t w, m; bases.window16((uint64_t)lo, w, m);
+				if (q_desc) { w = __brev(w); w = ((w >> 1) & 0x55555555u) | ((w & 0x55555555u) << 1); m = __brev(m) >> 16; }
+				uint4 o; uint32_t *op = &o.x;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					uint32_t x = (w >> (8 * g)) & 0xffu; x = (x | x << 12) & 0x000f000fu; x = (x | x << 6) & 0x03030303u;
+					const uint32_t y = (((m >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u;
+					op[g] = ((x ^ cm) & ~(y * 3u)) | (y << 2);
+				}
+				*reinterpret_cast<uint4*>(qq + j0) = o;               // (the window is padded to sixteen: bytes behind qlen are never read as bases)
+			}
+			const int64_t t_p0 = (int64_t)t_base + (J.seq_rev ? tlen - 1 : 0);
+			for (int i0 = 16 * tid; i0 < T + 16; i0 += 16 * NT) {
+				uint4 o = make_uint4(0u, 0u, 0u, 0u);
+				if (i0 < tlen) {
+					const int64_t lo = J.seq_rev ? t_p0 - i0 - 15 : t_p0 + i0;
+					if (lo < 0) { uint32_t *op = &o.x; for (int i = i0; i < i0 + 16; ++i) op[(i - i0) >> 2] |= target_at(i) << (8 * ((i - i0) & 3)); }
+					else {
+						uint32_t w, m; bases.window16((uint64_t)lo, w, m);
+						if (J.seq_rev) { w = __brev(w); w = ((w >> 1) & 0x55555555u) | ((w & 0x55555555u) << 1); m = __brev(m) >> 16; }
+						const int v = tlen - i0;                          // bases of this word inside the target: behind them the window holds zeros
+						if (v < 16) { w &= (1u << (2 * v)) - 1u; m &= (1u << v) - 1u; }
+						uint32_t *op = &o.x;
+#pragma unroll
+						for (int g = 0; g < 4; ++g) {
+							uint32_t x = (w >> (8 * g)) & 0xffu; x = (x | x << 12) & 0x000f000fu; x = (x | x << 6) & 0x03030303u;
+							const uint32_t y = (((m >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u;
+							op[g] = (x & ~(y * 3u)) | (y << 2);
+						}
+					}
+				}
+				if (i0 + 16 <= T + 8) *reinterpret_cast<uint4*>(tq + i0) = o;
+				else *reinterpret_cast<uint2*>(tq + i0) = make_uint2(o.x, o.y);     // T + 8 is the window's last byte
+			}
+		}
+		const int rpc = CHUNK / n_col;                   // diagonals per chunk
 		auto want_chunk = [&](int c) {                        // (thread 0) make sure chunk c of this problem exists
 			if (c < LANES_MAXCHUNK && c >= s_have) {
 				// the second half of the pool is reserved progressively for the workgroups with the lower indices (they hold the largest
@@ -209,7 +254,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				if (tid == 0) want_chunk(row_c + 1);                 // one chunk ahead: visible behind this diagonal's barrier
 				const uint32_t chunk_id = s_chunk[row_c];
 				if (chunk_id == 0xffffffffu) { sat = 1; break; }
-				prow = pool_base + (size_t)chunk_id * LANES_CHUNK;
+				prow = pool_base + (size_t)chunk_id * CHUNK;
 			}
 			if (++row_o == rpc) row_o = 0, ++row_c;
 			int need_hi = en > st0 + span - 1 ? en : st0 + span - 1;
@@ -481,7 +526,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 						if (r >= 0 && col >= 0) {
 							int st0, en0; diag_range_l(r, qlen, tlen, w, st0, en0);
 							const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
-							if (st0 <= en0 && col >= off && col <= off_end) val = pool_base[(size_t)s_chunk[r / rpc] * LANES_CHUNK + (size_t)(r % rpc) * n_col + (col - off)];
+							if (st0 <= en0 && col >= off && col <= off_end) val = pool_base[(size_t)s_chunk[r / rpc] * CHUNK + (size_t)(r % rpc) * n_col + (col - off)];
 						}
 						wv[row] = val;
 					}
@@ -533,9 +578,11 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 }
 
 // a problem the lane kernel takes: its band ring fits the NT*8 columns of an NT-thread workgroup (256: end extensions and banded fills, many per
-// CU; 1024: the few exact second passes and wide bands of up to 8 k columns, four waves per SIMD) and its windows fit LDS
+// CU; 64: the same for rings of at most 512 columns -- extensions towards a block end a few hundred bases away, thousands per round in the
+// upper levels of a build: one wave, no workgroup barrier, four times as many in flight) and its windows fit LDS
 bool lanes_eligible(const DpJob &j, int nt)
 {
+	const size_t chunk = lanes_chunk_of(nt);
 	if (j.flag & PGA_JOB_LL) return false;
 	if (j.qlen < 1 || j.tlen < 1 || j.qlen > 28 * 1024 || j.tlen > 28 * 1024) return false;
 	const int T = (j.tlen + 15) / 16 * 16;
@@ -545,11 +592,11 @@ bool lanes_eligible(const DpJob &j, int nt)
 	if (R > nt * LANES_C) return false;
 	int n_col = j.qlen < j.tlen ? j.qlen : j.tlen;
 	n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
-	return ((size_t)j.qlen + j.tlen) / (LANES_CHUNK / (size_t)n_col) + 2 <= LANES_MAXCHUNK;
+	return ((size_t)j.qlen + j.tlen) / (chunk / (size_t)n_col) + 2 <= LANES_MAXCHUNK;
 }
 
 size_t lanes_cig_bytes(int q_cap, int t_cap) { return (4 * ((size_t)q_cap + t_cap + 8) + 255) & ~(size_t)255; }
-size_t lanes_chunk_bytes() { return LANES_CHUNK; }
+size_t lanes_chunk_bytes(int nt) { return lanes_chunk_of(nt); }
 
 template <int NT> static void launch_lanes_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab,
                                               size_t cig_bytes, uint32_t n_chunks, int q_cap, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
@@ -563,7 +610,7 @@ void launch_extd2_lanes(int nt, unsigned n_blocks, int q_cap, int t_cap, const D
                         DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st)
 {
 	const size_t lds = (((size_t)q_cap + 15) & ~(size_t)15) + (((size_t)t_cap + 15) & ~(size_t)15) + 16;
-	if (nt >= 1024) launch_lanes_nt<1024>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
+	if (nt <= 64) launch_lanes_nt<64>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
 	else launch_lanes_nt<256>(n_blocks, lds, st, jobs, n_jobs, bases, P, counter, slab, lanes_cig_bytes(q_cap, t_cap), n_chunks, q_cap, res, pool, cursor, pool_cap);
 }
 
