@@ -967,6 +967,42 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	}
 }
 
+// ---- a hint for the replay of the candidate sort (lchain.c:52: radix_sort_128x(z, z + n_z)) ------------------------------------------------
+// A stable device sort of the candidates by (query, score) tells which buckets of the reference's unstable sort hold no two equal scores:
+// their final order is the sorted order, whatever the sort did on the way (pga_sort_big.h).  Scores rise along a chain, so almost every bucket
+// below the top level is one.  Slots behind a query's n_z candidates sort to the end of its segment (score field all ones).
+__global__ void k_z_keys(const u128 *__restrict__ z, const uint64_t *__restrict__ q_aoff, const int64_t *__restrict__ n_z, int n_seq, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int lo = 0, hi = n_seq;
+	while (lo < hi) { int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= i) lo = m + 1; else hi = m; }
+	const bool valid = (int64_t)(i - q_aoff[lo]) < n_z[lo];
+	key[i] = (uint64_t)lo << 32 | (valid ? (uint64_t)(uint32_t)z[i].x : 0xffffffffULL);
+	idx[i] = (uint32_t)i;
+}
+__global__ void k_z_sorted(const u128 *__restrict__ z, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx, uint64_t n, const uint64_t *__restrict__ q_aoff, const int64_t *__restrict__ n_z,
+                           uint64_t *__restrict__ sx, uint64_t *__restrict__ sy, uint32_t *__restrict__ q_tie)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t k = key[i];
+	if ((uint32_t)k == 0xffffffffu) { sx[i] = sy[i] = 0; return; }
+	sx[i] = (uint64_t)(uint32_t)k; sy[i] = z[idx[i]].y;
+	if (i > 0 && key[i - 1] == k) q_tie[k >> 32] = 1;                    // same query, same score
+}
+// queries without equal scores: the sorted order is the answer
+__global__ void k_z_take_sorted(u128 *__restrict__ z, const uint64_t *__restrict__ sx, const uint64_t *__restrict__ sy, const uint64_t *__restrict__ q_aoff, const int64_t *__restrict__ n_z, int n_seq,
+                                const uint32_t *__restrict__ q_tie, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int lo = 0, hi = n_seq;
+	while (lo < hi) { int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= i) lo = m + 1; else hi = m; }
+	if (q_tie[lo] || (int64_t)(i - q_aoff[lo]) >= n_z[lo]) return;
+	u128 v; v.x = sx[i]; v.y = sy[i]; z[i] = v;
+}
+
 __global__ void k_gather_chains(const uint64_t *__restrict__ u, const uint64_t *__restrict__ q_aoff, const uint64_t *__restrict__ coff, int n_seq, uint64_t *__restrict__ out)
 {
 	const int q = blockIdx.x;
@@ -1065,7 +1101,33 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		double ms_list = 0, ms_sort = 0;
 		ms_list = et.stop();
 		EventTimer et2(st);
-		replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st, tm);
+		static const bool z_hint = getenv("PGA_NO_Z_HINT") == nullptr;
+		if (!z_hint) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st, tm);
+		else {
+			DBuf<uint64_t> key0(n_a), key1(n_a), sx(n_a), sy(n_a);
+			DBuf<uint32_t> idx0(n_a), idx1(n_a), dupc(n_a), q_tie((size_t)n_seq);
+			q_tie.zero(st);
+			hipLaunchKernelGGL(k_z_keys, dim3(nba), dim3(256), 0, st, z.p, q_aoff.p, n_z.p, n_seq, n_a, key0.p, idx0.p);
+			int bits = 1; while ((1LL << bits) < n_seq) ++bits;
+			size_t tb = 0;
+			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, key0.p, key1.p, idx0.p, idx1.p, n_a, 0, 32 + bits, st));
+			DBuf<uint8_t> tmp(tb ? tb : 1);
+			PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, key0.p, key1.p, idx0.p, idx1.p, n_a, 0, 32 + bits, st));
+			hipLaunchKernelGGL(k_z_sorted, dim3(nba), dim3(256), 0, st, z.p, key1.p, idx1.p, n_a, q_aoff.p, n_z.p, sx.p, sy.p, q_tie.p);
+			{
+				struct Dp { const uint64_t *k; };
+				Dp dp{key1.p};
+				auto flag_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), [dp] __device__ (uint64_t i) { return (uint32_t)(i > 0 && dp.k[i] == dp.k[i - 1]); });
+				size_t tb2 = 0;
+				PGA_HIP(rocprim::inclusive_scan(nullptr, tb2, flag_it, dupc.p, n_a, rocprim::plus<uint32_t>(), st));
+				DBuf<uint8_t> tmp2(tb2 ? tb2 : 1);
+				PGA_HIP(rocprim::inclusive_scan(tmp2.p, tb2, flag_it, dupc.p, n_a, rocprim::plus<uint32_t>(), st));
+			}
+			hipLaunchKernelGGL(k_z_take_sorted, dim3(nba), dim3(256), 0, st, z.p, sx.p, sy.p, q_aoff.p, n_z.p, n_seq, q_tie.p, n_a);
+			const RsHint hint{sx.p, sy.p, dupc.p};
+			replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint);
+			PGA_HIP(hipStreamSynchronize(st));                               // (the hint's buffers go out of scope)
+		}
 		ms_sort = et2.stop();
 		EventTimer et3(st);
 		hipLaunchKernelGGL(k_bt_walk, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, n_z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
