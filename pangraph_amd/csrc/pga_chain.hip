@@ -1024,6 +1024,11 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	P.pen_skip = (float)(opt.chain_skip_scale * 0.01 * k);
 	int32_t seg_dist = P.max_dist < P.bw ? P.bw : P.max_dist;
 	const unsigned nba = (unsigned)((n_a + 255) / 256);
+	// PGA_VERBOSE: host wall clock of the stage's steps (each mark drains the stream)
+	const bool vmarks = getenv("PGA_VERBOSE") != nullptr;
+	auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_mark = vmarks ? wall() : 0.0; std::string marks;
+	auto mark = [&](const char *what) { if (!vmarks) return; (void)hipStreamSynchronize(st); const double t = wall(); char b[96]; snprintf(b, sizeof b, " %s %.1f", what, (t - t_mark) * 1e3); marks += b; t_mark = t; };
 	// segments
 	DBuf<uint32_t> flag(n_a + 1); flag.zero(st);
 	hipLaunchKernelGGL(k_mark_query_starts, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, st, q_aoff.p, n_seq, n_a, flag.p);
@@ -1059,9 +1064,11 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		DBuf<uint8_t> tmp(tb ? tb : 1);
 		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 0, 32, st));
 	}
+	mark("segments");
 	DBuf<CNode> nd_main(n_a), nd_inner(n_a);
 	DBuf<int32_t> f(n_a), pp(n_a), t(n_a), v(n_a);
 	t.zero(st);
+	mark("buffers");
 	{
 		DBuf<uint32_t> seg_flag(n_seg);
 		EventTimer et(st);
@@ -1088,6 +1095,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		if (tm) { tm->kern[K_CHAIN].ms += ms; tm->kern[K_CHAIN].launches += 1; tm->kern[K_CHAIN].alg_bytes += 36.0 * (double)n_a; } // 16 B anchor read + f,p,v,t
 	}
 	hipLaunchKernelGGL(k_fix_pred, dim3(nba), dim3(256), 0, st, seg_start.p, n_seg, n_a, q_aoff.p, n_seq, seg_incl.p, pp.p);
+	mark("chain kernels");
 	// backtrack + compact, one lane per query
 	DBuf<u128> z(n_a), w(n_a), out(n_a);
 	DBuf<uint64_t> u(n_a), u2(n_a);
@@ -1142,6 +1150,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
 	}
 	PGA_HIP(hipGetLastError());
+	mark("backtrack");
 	O.n_u = n_u.download(st); O.n_v = n_v.download(st);
 	// the chains of a query are the first n_u entries of its slice of u: only those travel (a leaf part holds ~5 k chains in an array of
 	// 57 M slots), and land at the same positions of the host array
@@ -1159,7 +1168,10 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 			for (int q = 0; q < n_seq; ++q) if (O.n_u[(size_t)q] > 0) memcpy(O.u.data() + h_off[(size_t)q], hc.data() + coff[(size_t)q], (size_t)O.n_u[(size_t)q] * sizeof(uint64_t));
 		}
 	}
+	mark("chains to host");
 	download_to(O.a, out.p, out.n, st);
+	mark("anchors to host");
+	if (vmarks) fprintf(stderr, "[pga]   chain stage, host ms:%s\n", marks.c_str());
 }
 
 } // namespace pga

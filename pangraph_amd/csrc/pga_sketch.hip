@@ -400,6 +400,177 @@ void k_sketch_tiles(const uint32_t *__restrict__ pk2, const uint16_t *__restrict
 	}
 }
 
+// ---- the same tiles, eight CONSECUTIVE positions per thread (w known at compile time, k odd, 2k + 13 <= 64) ----
+// What the kernel above pays per position -- two k-mer extractions from the LDS image, a scan of the w hashes of its window, w-element
+// loops whenever one lane of the wave meets rule C2 -- is paid here per EIGHT positions or not at all:
+//   * the two k-mer words roll from base to base (sketch.c:104-110), as does the run of ACGT bases;
+//   * a minimizer candidate is ONE 64-bit key, hash << 13 | (4095 - local index) << 1 | strand (all ones: no k-mer): the unsigned minimum of
+//     a window is its smallest hash at its rightmost position (the `<=` of sketch.c:127,135), and the key holds all an emission needs;
+//   * keys go through LDS once (column-major over the eight positions of a thread: conflict-free both ways); a thread fetches the w keys in
+//     front of its own eight and gets its nine window minima from one suffix-minimum and one prefix-minimum chain (w + 16 comparisons);
+//   * the same two chains over the keys with the index field flipped give the LEFTMOST minimum: the two differ exactly when the window
+//     holds its smallest hash twice -- only then are the "identical k-mers in the window" loops of rules A and C2 (sketch.c:121-125,
+//     138-142) run at all;
+//   * positions of a thread are consecutive, so one wave scan + one barrier order the emissions of the tile.
+#define SK8_HALO 96
+template <int W>
+__global__ __launch_bounds__(SK_THREADS)
+void k_sketch_tiles8(const uint32_t *__restrict__ pk2, const uint16_t *__restrict__ nmask, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
+                     const SkTile *__restrict__ tiles, int k, u128 *__restrict__ stage, uint32_t stage_cap, uint32_t *__restrict__ tile_cnt, int *__restrict__ overflow)
+{
+	static_assert(W >= 9 && W <= 32, "the two minimum chains meet at element 8");
+	constexpr int HB = (W + 7) / 8;                          // chunks of eight positions in front of the tile whose keys the first windows need
+	constexpr int NCH = SK_THREADS + HB, KS = NCH + 1;
+	constexpr int NPOS = SK_TILE + SK8_HALO;
+	constexpr uint64_t NONE = ~0ULL, FLIP = 0x1ffeULL;
+	__shared__ uint32_t s_bits[NPOS / 16 + 4];
+	__shared__ uint32_t s_nmask[NPOS / 32 + 4];
+	__shared__ uint64_t s_key[8 * KS];                       // key of local index L at [(L & 7) * KS + (L >> 3)]; L = 0 <-> position t0 - 8 * HB
+	__shared__ uint32_t s_wsum[SK_THREADS / 64];
+
+	const SkTile tl = tiles[blockIdx.x];
+	const uint32_t rid = tl.rid, len = seq_len[rid];
+	const int64_t t0 = tl.start;
+	const uint64_t goff = seq_off[rid];
+	const int tid = threadIdx.x;
+	const uint64_t mask = (1ULL << 2 * k) - 1;
+	const int sh1 = 2 * (k - 1);
+
+	// ---- 1. the 2-bit + N-bit image of [t0 - HALO, t0 + TILE), as in k_sketch_tiles ----
+	const int64_t g_lo = (int64_t)goff + t0 - SK8_HALO;
+	const int64_t ga = g_lo >= 0 ? (g_lo & ~15LL) : -(((-g_lo) + 15) & ~15LL);
+	const int pad = (int)(g_lo - ga);
+	for (int c = tid; c < NPOS / 16 + 4; c += SK_THREADS) {
+		const int64_t g = ga + (int64_t)c * 16;
+		uint32_t bits = 0, nm = 0xffffu;
+		if (g >= 0 && (uint64_t)g < goff + len + 16) { bits = pk2[g >> 4]; nm = nmask[g >> 4]; }
+		const int64_t lo64 = (int64_t)goff - g, hi64 = (int64_t)goff + (int64_t)len - g;
+		const int lo = lo64 < 0 ? 0 : lo64 > 16 ? 16 : (int)lo64, hi = hi64 < 0 ? 0 : hi64 > 16 ? 16 : (int)hi64;
+		const uint32_t inside = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+		nm |= ~inside & 0xffffu;
+		{
+			uint32_t m = ~nm & 0xffffu;
+			m = (m | m << 8) & 0x00ff00ffu; m = (m | m << 4) & 0x0f0f0f0fu; m = (m | m << 2) & 0x33333333u; m = (m | m << 1) & 0x55555555u;
+			bits &= m | m << 1;
+		}
+		s_bits[c] = bits;
+		reinterpret_cast<uint16_t*>(s_nmask)[c] = (uint16_t)nm;
+	}
+	__syncthreads();
+
+	// ---- 2. keys of a chunk of eight positions: rolling k-mer words, rolling run ----
+	uint64_t own[8]; int run_at[8];
+	auto chunk = [&](int c, bool keep) {
+		const int L0 = 8 * c;
+		const int lq0 = pad + SK8_HALO - 8 * HB + L0;          // image position of the chunk's first base
+		const uint64_t win = lds_bits(s_bits, 2u * (uint32_t)(lq0 - k), 2u * (uint32_t)k);     // the k-mer ending just before the chunk, base j at bits 2j
+		uint64_t rv = (~win) & mask, fw = rev2(win) >> (64 - 2 * k);
+		const int nb = W + k;
+		int run;
+		{
+			const uint64_t nwin = lds_bits(s_nmask, (uint32_t)(lq0 - nb), (uint32_t)nb);
+			const uint64_t top = nwin << (64 - nb);
+			run = top == 0 ? nb : __clzll((long long)top);
+		}
+		const uint32_t b16 = (uint32_t)lds_bits(s_bits, 2u * (uint32_t)lq0, 16u), n8 = (uint32_t)lds_bits(s_nmask, (uint32_t)lq0, 8u);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint64_t cb = (b16 >> (2 * j)) & 3u;
+			fw = (fw << 2 | cb) & mask;
+			rv = rv >> 2 | (3ULL ^ cb) << sh1;
+			run = ((n8 >> j) & 1u) ? 0 : run + 1;
+			const uint32_t z = fw < rv ? 0u : 1u;
+			const uint64_t h = hash64(z ? rv : fw, mask);
+			const uint64_t key = run >= k ? (h << 13 | (uint64_t)(4095 - (L0 + j)) << 1 | z) : NONE;
+			s_key[j * KS + c] = key;
+			if (keep) { own[j] = key; run_at[j] = run; }
+		}
+	};
+	if (tid < HB) chunk(tid, false);
+	chunk(tid + HB, true);
+	__syncthreads();
+
+	// ---- 3. the nine windows of the thread: window j ends at local index L0 - 1 + j ----
+	const int L0 = 8 * (tid + HB);
+	uint64_t e[W + 8];
+#pragma unroll
+	for (int d = 1; d <= W; ++d) e[W - d] = s_key[((8 - (d & 7)) & 7) * KS + (tid + HB - ((d + 7) >> 3))];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) e[W + j] = own[j];
+	uint64_t R[9]; uint32_t dup = 0;                          // rightmost minimum of window j; bit j: the window holds its smallest hash more than once
+	{
+		uint64_t sx[9]; sx[8] = NONE;
+#pragma unroll
+		for (int j = 7; j >= 0; --j) sx[j] = e[j] < sx[j + 1] ? e[j] : sx[j + 1];
+		uint64_t px = NONE;
+#pragma unroll
+		for (int t = 8; t < W + 8; ++t) { px = e[t] < px ? e[t] : px; if (t >= W - 1) { const uint64_t a = sx[t - W + 1]; R[t - W + 1] = a < px ? a : px; } }
+	}
+	{
+		uint64_t sx[9]; sx[8] = NONE;
+#pragma unroll
+		for (int j = 7; j >= 0; --j) { const uint64_t v = e[j] ^ FLIP; sx[j] = v < sx[j + 1] ? v : sx[j + 1]; }
+		uint64_t px = NONE;
+#pragma unroll
+		for (int t = 8; t < W + 8; ++t) {
+			const uint64_t v = e[t] ^ FLIP; px = v < px ? v : px;
+			if (t >= W - 1) { const uint64_t a = sx[t - W + 1]; const uint64_t l = a < px ? a : px; dup |= ((l ^ FLIP) != R[t - W + 1] ? 1u : 0u) << (t - W + 1); }
+		}
+	}
+
+	// ---- 4. emission rules (oracle/pgo_sketch.c: rules A-D) for the thread's eight positions, in position order ----
+	auto key_at = [&](int L) -> uint64_t { return s_key[(L & 7) * KS + (L >> 3)]; };
+	auto idx_of = [](uint64_t key) -> int { return 4095 - (int)((key >> 1) & 4095u); };
+	const int tile_n = (int)min((int64_t)SK_TILE, (int64_t)len - t0);
+	uint32_t flags = 0, n_mine = 0;                            // four rule bits per position
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int c = 8 * tid + j;
+		if (c >= tile_n) continue;
+		const int L = L0 + j, run = run_at[j];
+		const uint64_t kp = R[j], kc = R[j + 1], xp = own[j];
+		const bool prev_real = kp != NONE, cur_real = kc != NONE;
+		const uint64_t hp = kp >> 13, hx = xp >> 13;            // (NONE >> 13 is above every hash: the comparisons below order like the reference's)
+		const bool ruleA = run == W + k - 1 && prev_real;
+		bool ruleB = false, ruleC1 = false, ruleC2 = false;
+		if (hx <= hp) ruleB = run >= W + k && prev_real;
+		else if (idx_of(kp) == L - W) { ruleC1 = run >= W + k - 1 && prev_real; ruleC2 = run >= W + k - 1 && cur_real; }
+		const bool ruleD = (t0 + c == (int64_t)len - 1) && cur_real;
+		uint32_t n = (ruleB || ruleC1 ? 1u : 0u) + (ruleD ? 1u : 0u);
+		if (ruleA && ((dup >> j) & 1u)) { const int pi = idx_of(kp); for (int t = L - W + 1; t < L; ++t) { const uint64_t kt = key_at(t); n += (kt != NONE && (kt >> 13) == hp && t != pi) ? 1u : 0u; } }
+		if (ruleC2 && ((dup >> (j + 1)) & 1u)) { const int ci = idx_of(kc); const uint64_t hc = kc >> 13; for (int t = L - W + 1; t <= L; ++t) { const uint64_t kt = key_at(t); n += (kt != NONE && (kt >> 13) == hc && t != ci) ? 1u : 0u; } }
+		flags |= ((ruleA ? 1u : 0u) | (ruleB || ruleC1 ? 2u : 0u) | (ruleC2 ? 4u : 0u) | (ruleD ? 8u : 0u)) << (4 * j);
+		n_mine += n;
+	}
+	const uint32_t incl = wave_prefix_sum_incl(n_mine);
+	if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+	__syncthreads();
+	uint32_t wbase = 0, total = 0;
+#pragma unroll
+	for (int wv = 0; wv < SK_THREADS / 64; ++wv) { const uint32_t sv = s_wsum[wv]; if (wv < (tid >> 6)) wbase += sv; total += sv; }
+	if (tid == 0) { tile_cnt[blockIdx.x] = total; if (total > stage_cap) atomicExch(overflow, 1); }
+	if (total == 0 || n_mine == 0) return;
+	u128 *out = stage + (size_t)blockIdx.x * stage_cap;
+	uint32_t oo = wbase + incl - n_mine;
+	const uint64_t ybase = (uint64_t)rid << 32;
+	const int64_t pos0 = t0 - 8 * HB;                          // sequence position of local index 0
+	auto emit = [&](uint64_t key) {
+		if (oo < stage_cap) { u128 r; r.x = (key >> 13) << 8 | (uint64_t)k; r.y = ybase | (uint64_t)(uint32_t)(pos0 + idx_of(key)) << 1 | (key & 1u); out[oo] = r; }
+		++oo;
+	};
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t f = (flags >> (4 * j)) & 15u;
+		if (!f) continue;
+		const int L = L0 + j;
+		const uint64_t kp = R[j], kc = R[j + 1];
+		if ((f & 1u) && ((dup >> j) & 1u)) { const int pi = idx_of(kp); const uint64_t hp = kp >> 13; for (int t = L - W + 1; t < L; ++t) { const uint64_t kt = key_at(t); if (kt != NONE && (kt >> 13) == hp && t != pi) emit(kt); } }
+		if (f & 2u) emit(kp);
+		if ((f & 4u) && ((dup >> (j + 1)) & 1u)) { const int ci = idx_of(kc); const uint64_t hc = kc >> 13; for (int t = L - W + 1; t <= L; ++t) { const uint64_t kt = key_at(t); if (kt != NONE && (kt >> 13) == hc && t != ci) emit(kt); } }
+		if (f & 8u) emit(kc);
+	}
+}
+
 // ---- generic serial kernel: one lane per sequence, the streaming formulation (slots, ring of w entries) ----
 __global__ void k_sketch_serial(PkBases bases, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
                                 int n_seq, int w, int k, u128 *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ cnt,
@@ -505,7 +676,12 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 		for (;;) {
 			DBuf<u128> stage(nt * (size_t)cap);
 			EventTimer et(st);
-			hipLaunchKernelGGL((k_sketch_tiles<63>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st,
+			// eight consecutive positions per thread where w is one of the presets' (asm5/asm10: 19, asm20: 10) and a key fits 64 bits
+			static const bool no8 = getenv("PGA_SKETCH_STRIDED") != nullptr;
+			const bool fit8 = !no8 && 2 * k + 13 <= 64 && 8 * ((w + 7) / 8) + w + k <= SK8_HALO;
+			if (fit8 && w == 19) hipLaunchKernelGGL((k_sketch_tiles8<19>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st, S.d_pk2.p, S.d_nmask.p, S.d_off.p, S.d_len.p, d_tiles.p, k, stage.p, cap, d_cnt.p, d_ovf.p);
+			else if (fit8 && w == 10) hipLaunchKernelGGL((k_sketch_tiles8<10>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st, S.d_pk2.p, S.d_nmask.p, S.d_off.p, S.d_len.p, d_tiles.p, k, stage.p, cap, d_cnt.p, d_ovf.p);
+			else hipLaunchKernelGGL((k_sketch_tiles<63>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st,
 			                   S.d_pk2.p, S.d_nmask.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
 			PGA_HIP(hipGetLastError());
 			const double k_ms = et.stop();
