@@ -232,7 +232,7 @@ def main():
     ap.add_argument("--inputs", choices=("resident", "host"), default=os.environ.get("PGA_BENCH_INPUTS", "resident"),
                     help="resident: the block sequences of every call are in HBM (packed store) before the timed region, a call takes its inputs by a "
                          "device-to-device copy (pga_batch_derive); host: every call hands over host strings inside the timed region (PCIe-inclusive rate)")
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("PGA_BENCH_SLOTS", 3)), help="batches in flight (ready-set schedule)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("PGA_BENCH_SLOTS", 6)), help="batches in flight (ready-set schedule)")
     ap.add_argument("--cap-gbp", type=float, default=float(os.environ.get("PGA_BENCH_CAP_GBP", 1.2)), help="largest batch of the ready-set schedule")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the one-off timings of the SURVEY 8(f) rows (guide tree, map_variations) reported next to the headline")
     args = ap.parse_args()

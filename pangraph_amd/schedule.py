@@ -149,7 +149,7 @@ class TaskBatch:
         return [n for t in self.tasks for n in t.names]
 
 
-def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], slots: int = 3, cap_bases: float = 1.2e9,
+def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], slots: int = 6, cap_bases: float = 1.2e9,
                   min_batch_bases: float = 0.0, done: Optional[set] = None, only: Optional[set] = None,
                   on_result: Optional[Callable[[List[Task], object, float, float], None]] = None):
     """Runs `tasks` (all of them, or the subset `only`) in dependency order; `run_batch(list of tasks)` is called from up to `slots` host
