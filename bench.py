@@ -437,11 +437,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    batch.busy_begin()                                         # union of the launch intervals per kernel family over the timed steps
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
+    busy = batch.busy_end()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -455,7 +457,8 @@ def main():
         if name == "-" or st["kern_launches"][i] <= 0:
             continue
         ms, n, by, cells = st["kern_ms"][i], st["kern_launches"][i], st["kern_alg_bytes"][i], st["kern_cells"][i]
-        e = {"device_ms_per_step": ms, "launches_per_step": n, "avg_launch_ms": ms / n}
+        e = {"device_ms_per_step": ms, "launches_per_step": n, "avg_launch_ms": ms / n,
+             "busy_ms_per_step": busy.get(name, 0.0) / args.steps}      # union of its launch intervals over all streams and batches (rank 0)
         if batch.KERNEL_BOUND[i] == "hbm":
             gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             e.update({"bound": "hbm", "alg_bytes_per_launch": by / n, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
@@ -503,7 +506,10 @@ def main():
                      "traffic": pmc_traffic(kname, klaunch), "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run); bytes per launch in the unit of alg_bytes_per_launch",
                      "launches_per_step": klaunch, "avg_launch_ms": kms / klaunch if klaunch else None,
                      "alg_bytes_per_launch": kbytes / klaunch if klaunch else None,
-                     "note": "device_ms_per_step are HIP-event times on each kernel's own stream; streams overlap, so they do not add up to ms_per_step",
+                     "note": "device_ms_per_step are HIP-event times on each kernel's own stream, summed over all launches; streams and batches overlap, so they do "
+                             "not add up to ms_per_step -- busy_ms_per_step is the UNION of a family's launch intervals on the device clock (what the step spent with "
+                             "that family queued or running), any_kernel_busy_ms_per_step the union over all families",
+                     "any_kernel_busy_ms_per_step": busy.get("any", 0.0) / args.steps, "timed_intervals_per_step": busy.get("intervals", 0) / args.steps,
                      "kernels": table},
         "dp": {"cells_evaluated": dp_cells, "gcups_over_dp_kernel_time": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
                "gcups_over_step": dp_cells / (ms_step * 1e-3) / 1e9, "nominal_cells_qlen_x_tlen": st["n_dp_cells"], "jobs": st["n_dp_jobs"],

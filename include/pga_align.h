@@ -130,6 +130,15 @@ int pga_result_filter(const pga_result_t *res, const pga_filter_params_t *fp, pg
 int pga_mash_distance(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist);
 int pga_guide_tree_nj(int32_t n, const double *dist, int32_t *merges);
 int pga_guide_tree(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist, int32_t *merges);
+/* The joining step picks the smallest Q (neighbor_joining.rs:77-96); its row and column sums are f64 sums taken in ndarray's order as
+ * restated here (not pinned against ndarray itself).  pga_nj_near_ties() = the number of joins of the calling thread's
+ * last pga_guide_tree_nj / pga_guide_tree call in which the Q of ANOTHER pair came within the error a different summation order can make
+ * (8 m^2 2^-53 max|d| at m live nodes) of the chosen one; *first_join (may be NULL) = the first such join, -1 if none.  The joins at
+ * m = 4 and m = 3 are left out of the count: there the Q of complementary pairs (at m = 3: of all pairs) are equal in exact arithmetic, so
+ * the last two joins of EVERY tree -- the root and its children -- are decided by the rounding of these sums, in the reference as here.
+ * 0 means no other join depends on the order the sums are taken in; otherwise a caller that needs the reference's tree bit for bit can
+ * run its own joining on the distance matrix. */
+int32_t pga_nj_near_ties(int32_t *first_join);
 /* stage tap: the minimizers of every sequence in the reference's order (value = Minimizer.value, position = Minimizer.position with
  * the sequence's index as id); seq_off has n + 1 entries */
 int pga_stage_mash_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, uint64_t **value, uint64_t **position, uint64_t *seq_off);
@@ -196,6 +205,14 @@ int pga_reconsensus(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_rc
                     const pga_ins_t *inss, const char *ins_seq, const pga_mapvar_params_t *params, pga_rc_out_t *out);
 void pga_rc_free(pga_rc_out_t *out);
 int pga_stats_version(void);     /* == PGA_STATS_VERSION of the header the library was built with */
+/* Measurement only (no reference interface behind it): the kern_ms sums of pga_stats_t count overlapping launches on different streams
+ * and batches several times.  Between pga_busy_begin() and pga_busy_end() every event-bracketed launch of the process leaves its interval
+ * on the device clock; pga_busy_end writes, for each of the PGA_N_KERNELS kernel families of pga_stats_t (same order), the length in ms of
+ * the UNION of its intervals, and in busy_ms[PGA_N_KERNELS] the union over all families (n >= PGA_N_KERNELS + 1).  Returns the number of
+ * intervals seen, -1 on error. */
+#define PGA_N_KERNELS 16
+int pga_busy_begin(void);
+int pga_busy_end(double *busy_ms, int32_t n);
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,10 @@ def lib():
         d.pga_batch_align_shard.restype = C.c_int
         d.pga_batch_align_shard.argtypes = [C.c_void_p, C.POINTER(pga_params_t), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         d.pga_batch_free.argtypes = [C.c_void_p]
+        d.pga_busy_begin.restype = C.c_int
+        d.pga_busy_begin.argtypes = []
+        d.pga_busy_end.restype = C.c_int
+        d.pga_busy_end.argtypes = [C.POINTER(C.c_double), C.c_int32]
         d.pga_batch_derive.restype = C.c_int
         d.pga_batch_derive.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         d.pga_result_n_matches.restype = C.c_int64
@@ -309,3 +313,22 @@ def filter_result(res: BatchResult, pb: PreparedBatch, indel_len_threshold: int 
 
 def align_groups(groups, names=None, **kw) -> BatchResult:
     return align_prepared(PreparedBatch(groups, names), **kw)
+
+
+def busy_begin() -> None:
+    """Opens the busy-interval log of the library (pga_busy_begin): see busy_end."""
+    if lib().pga_busy_begin() != 0:
+        raise PgaError(lib().pga_last_error().decode())
+
+
+def busy_end() -> dict:
+    """Closes the log: {kernel family: ms of the union of its launch intervals} + "any": the union over all families + "intervals"."""
+    n = len(KERNELS)
+    out = (C.c_double * (n + 1))()
+    rc = lib().pga_busy_end(out, n + 1)
+    if rc < 0:
+        raise PgaError(lib().pga_last_error().decode())
+    d = {KERNELS[i]: out[i] for i in range(n) if KERNELS[i] != "-" and out[i] > 0}
+    d["any"] = out[n]
+    d["intervals"] = rc
+    return d

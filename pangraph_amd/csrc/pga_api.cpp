@@ -7,6 +7,8 @@
 // records as malloc()ed mm_reg1_t[] exactly as minimap2 would (caller frees, packages/minimap2/src/map.rs:407-420).
 // Part 2 (include/pga_align.h): the native batch entry for a level-synchronous host.
 #include "pga_common.h"
+#include <mutex>
+#include <array>
 #include "pga_pipeline.h"
 #include "pga_dp.h"
 #include "../../include/pga_align.h"
@@ -133,7 +135,7 @@ static void idx_sketch_index(PgaIdx &ix)
 		EventTimer et(ix.st);
 		build_index_ex(ix.S, ix.M, w, k, ix.I, ix.grp, ix.st);
 		KernelStat &ks = ix.tm.kern[K_INDEX];        // 16 B minimizer read for the sort + sorted write + table write
-		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 48.0 * (double)ix.M.n;
+		ks.ms += et.stop(K_INDEX); ks.launches += 1; ks.alg_bytes += 48.0 * (double)ix.M.n;
 	}
 	double t3 = now_s();
 	mem_log("after sketch+index");
@@ -208,7 +210,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 		EventTimer et(ix.st);
 		seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm, ix.sharded ? ix.d_own.p : nullptr);
 		KernelStat &ks = ix.tm.kern[K_SEED];         // query minimizers probe the table, anchors written, read and written by the sort
-		ks.ms += et.stop(); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
+		ks.ms += et.stop(K_SEED); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
 	}
 	double t1 = now_s();
 	mem_log("after seed");
@@ -610,6 +612,48 @@ extern "C" int pga_set_device(int dev) { if (hipSetDevice(dev) != hipSuccess) { 
 extern "C" void pga_free(void *p) { free(p); }
 extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
 
+// ---- busy intervals (pga_common.h: busy_note) ----
+static_assert(pga::K_COUNT == PGA_N_KERNELS, "pga_stats_t and the busy log number the kernel families alike");
+namespace pga {
+struct BusyLog { std::mutex mu; bool open = false; hipEvent_t ref = nullptr; int dev = -1; std::vector<std::array<float, 3>> iv; };   // (kernel, start ms, end ms) since `ref`
+static BusyLog g_busy;
+void busy_note(int kern, hipEvent_t a, hipEvent_t b)
+{
+	if (!g_busy.open) return;                                       // (racy read: an interval next to begin / end may be missed, none is corrupted)
+	float t0 = 0, t1 = 0;
+	std::lock_guard<std::mutex> lk(g_busy.mu);
+	if (!g_busy.open || !g_busy.ref) return;
+	if (hipEventElapsedTime(&t0, g_busy.ref, a) != hipSuccess || hipEventElapsedTime(&t1, g_busy.ref, b) != hipSuccess) { (void)hipGetLastError(); return; }
+	g_busy.iv.push_back({(float)kern, t0, t1});
+}
+}
+extern "C" int pga_busy_begin(void)
+{
+	std::lock_guard<std::mutex> lk(pga::g_busy.mu);
+	if (pga::g_busy.ref) { (void)hipEventDestroy(pga::g_busy.ref); pga::g_busy.ref = nullptr; }
+	if (hipEventCreate(&pga::g_busy.ref) != hipSuccess || hipEventRecord(pga::g_busy.ref, nullptr) != hipSuccess || hipEventSynchronize(pga::g_busy.ref) != hipSuccess) { set_err("pga_busy_begin: no reference event"); return -1; }
+	pga::g_busy.iv.clear(); pga::g_busy.open = true;
+	return 0;
+}
+extern "C" int pga_busy_end(double *busy_ms, int32_t n)
+{
+	std::vector<std::array<float, 3>> iv;
+	{ std::lock_guard<std::mutex> lk(pga::g_busy.mu); pga::g_busy.open = false; iv.swap(pga::g_busy.iv); }
+	if (!busy_ms || n < PGA_N_KERNELS + 1) { set_err("pga_busy_end: room for PGA_N_KERNELS + 1 values needed"); return -1; }
+	auto union_ms = [&](int kern) {
+		std::vector<std::pair<float, float>> v;
+		for (auto &x : iv) if (kern < 0 || (int)x[0] == kern) v.emplace_back(x[1], x[2]);
+		std::sort(v.begin(), v.end());
+		double tot = 0; float lo = 0, hi = -1;
+		for (auto &p : v) { if (hi < lo || p.first > hi) { if (hi >= lo) tot += hi - lo; lo = p.first; hi = p.second; } else if (p.second > hi) hi = p.second; }
+		if (hi >= lo) tot += hi - lo;
+		return tot;
+	};
+	for (int k = 0; k < PGA_N_KERNELS; ++k) busy_ms[k] = union_ms(k);
+	busy_ms[PGA_N_KERNELS] = union_ms(-1);
+	return (int)iv.size();
+}
+
 // ---------------------------------------------------------------- stage taps (parity tests)
 template <class T> static T *dup_out(const std::vector<T> &v) { T *p = (T*)malloc((v.size() ? v.size() : 1) * sizeof(T)); if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T)); return p; }
 
@@ -727,6 +771,7 @@ namespace pga {
 void mash_stage_sketch(int n, const char *const *seqs, const uint32_t *lens, int k, int w, std::vector<uint64_t> &val, std::vector<uint64_t> &pos, std::vector<uint64_t> &off);
 void mash_distance_host(int n, const char *const *seqs, const uint32_t *lens, int k, int w, double *dist, int32_t *merges);
 void nj_host(int n, const double *dist, int32_t *merges);
+void nj_last_near(int32_t *count, int32_t *first);
 }
 
 extern "C" int pga_stage_mash_sketch(int32_t n, const char *const *seqs, const uint32_t *lens, int k, int w, uint64_t **value, uint64_t **position, uint64_t *seq_off)
@@ -758,6 +803,13 @@ extern "C" int pga_guide_tree(int32_t n, const char *const *seqs, const uint32_t
 	try { require_device(); mash_distance_host(n, seqs, lens, k, w, dist, merges); return 0; }
 	catch (std::exception &e) { set_err(e.what()); return -1; }
 }
+extern "C" int32_t pga_nj_near_ties(int32_t *first_join)
+{
+	int32_t c = 0, f = -1; pga::nj_last_near(&c, &f);
+	if (first_join) *first_join = f;
+	return c;
+}
+
 
 // ---------------------------------------------------------------- map_variations over all member sequences (pga_mapvar.hip)
 namespace pga {

@@ -1082,7 +1082,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
 		                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
 		PGA_HIP(hipGetLastError());
-		const double ms = et.stop();
+		const double ms = et.stop(K_CHAIN);
 		if (getenv("PGA_VERBOSE") && use_fast) {
 			std::vector<uint32_t> fl = seg_flag.download(st); size_t nf = 0, why[5] = {0, 0, 0, 0, 0}; for (uint32_t v : fl) { nf += v != 0; ++why[v < 5 ? v : 1]; }
 			fprintf(stderr, "[pga]   chain: %u segments, %zu re-run by the tree kernel (ring overflow %zu, size cap %zu, tied minimum %zu, inner candidates %zu), %.3f ms (fast kernel %.3f ms)\n", n_seg, nf, why[1], why[2], why[3], why[4], ms, ms_fast);
@@ -1107,7 +1107,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 		hipLaunchKernelGGL(k_bt_list, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, f.p, t.p, z.p, P, n_z.p, n_u.p, n_v.p);
 		double ms_list = 0, ms_sort = 0;
-		ms_list = et.stop();
+		ms_list = et.stop(K_BACKTRACK);
 		EventTimer et2(st);
 		static const bool z_hint = getenv("PGA_NO_Z_HINT") == nullptr;
 		if (!z_hint) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st, tm);
@@ -1140,7 +1140,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		EventTimer et3(st);
 		hipLaunchKernelGGL(k_bt_walk, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, n_z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
 		                   verbose ? prof.p : (unsigned long long*)nullptr);
-		const double ms_walk = et3.stop();
+		const double ms_walk = et3.stop(K_BACKTRACK);
 		const double ms = ms_list + ms_walk;                 // the sort replay is accounted under K_SORT
 		if (verbose) {
 			std::vector<unsigned long long> pr = prof.download(st);   // wall_clock64 ticks at 100 MHz

@@ -155,11 +155,15 @@ struct Timers {
 	double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0, dp_bases = 0, dp_cigar_ops = 0;
 	KernelStat kern[K_COUNT];   // device time of the path's own kernels, measured with HIP events on the launch stream
 };
+// Busy intervals (pga_busy_begin / pga_busy_end, pga_api.cpp): while a log is open, every event-bracketed launch of kernel family `kern`
+// leaves its interval [a, b] on the device's clock; the union per family and over all families is what a step really spent with that
+// kernel resident, however many streams and batches overlapped (the sums of kern[].ms do not add up to wall time).  Both events complete.
+void busy_note(int kern, hipEvent_t a, hipEvent_t b);
 // times everything enqueued on `st` between construction and stop()
 struct EventTimer {
 	hipEvent_t a, b; hipStream_t st;
 	explicit EventTimer(hipStream_t s) : st(s) { PGA_HIP(hipEventCreate(&a)); PGA_HIP(hipEventCreate(&b)); PGA_HIP(hipEventRecord(a, st)); }
-	double stop() { float ms = 0; PGA_HIP(hipEventRecord(b, st)); PGA_HIP(hipEventSynchronize(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); return ms; }
+	double stop(int kern = -1) { float ms = 0; PGA_HIP(hipEventRecord(b, st)); PGA_HIP(hipEventSynchronize(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); if (kern >= 0) busy_note(kern, a, b); return ms; }
 	~EventTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 };
 

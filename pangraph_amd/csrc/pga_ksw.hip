@@ -679,6 +679,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		PGA_HIP(hipEventSynchronize(X.e1));
 		float msf = 0, ms_off = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1)); (void)hipEventElapsedTime(&ms_off, ready, X.e0);
 		const double ms = msf;
+		busy_note(c == 6 ? K_LL : c == 8 ? K_BAND : c == 9 ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE, X.e0, X.e1);
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;

@@ -312,13 +312,18 @@ static void mash_distance_dev(const SeqSet &S, int k, int w, DBuf<double> &D, hi
 // enough work per step (n*n Q entries) for 1024 threads; the reference (tree/neighbor_joining.rs:16-103) has no limit, so neither has this.
 template <bool BIG>
 __global__ __launch_bounds__(NJ_NT)
-void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__restrict__ status, unsigned char *__restrict__ scratch)
+void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__restrict__ status, unsigned char *__restrict__ scratch, double d_max, int32_t *__restrict__ near)
 {
 	using alive_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
 	__shared__ uint16_t alive_s[BIG ? 1 : NJ_MAX];        // physical index of logical row/column
 	__shared__ int32_t node_s[BIG ? 1 : NJ_MAX];          // tree node of logical index
 	__shared__ double s0_s[BIG ? 1 : NJ_MAX], s1_s[BIG ? 1 : NJ_MAX]; // per logical index: left-to-right sum (= the column sum of the symmetric matrix) and unrolled sum of its row
 	__shared__ double rq[NJ_NT]; __shared__ unsigned long long ri[NJ_NT];
+	// The runner-up: the smallest Q of a DIFFERENT unordered pair (the transposed entry of the best is the same join).  When it lies within
+	// the error a different summation order could make -- the row and column sums of neighbor_joining.rs:60-75 are ndarray's, restated
+	// above, not pinned against ndarray itself -- the join is counted in near[0] (first such join in near[1]): the caller's flag.
+	__shared__ double rq2[NJ_NT]; __shared__ unsigned long long ri2[NJ_NT];
+	int32_t n_near = 0, first_near = -1;
 	double *s0 = BIG ? reinterpret_cast<double*>(scratch) : s0_s;
 	double *s1 = BIG ? reinterpret_cast<double*>(scratch) + n : s1_s;
 	int32_t *node = BIG ? reinterpret_cast<int32_t*>(scratch + (size_t)16 * n) : node_s;
@@ -348,7 +353,19 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 		__syncthreads();
 		// Q and its first minimum in row-major order
 		double bq = INFINITY; unsigned long long bidx = ~0ULL;
+		double q2nd = INFINITY; unsigned long long i2nd = ~0ULL;
 		const double mm2 = (double)m - 2.0;
+		auto same_pair = [&](unsigned long long a, unsigned long long b) {
+			if (a == ~0ULL || b == ~0ULL) return false;
+			const unsigned ar = (unsigned)(a / (unsigned)m), ac = (unsigned)(a % (unsigned)m), br = (unsigned)(b / (unsigned)m), bc = (unsigned)(b % (unsigned)m);
+			return (ar == br && ac == bc) || (ar == bc && ac == br);
+		};
+		// (best, runner-up of another pair) <- (best, runner-up) + candidate (q, idx)
+		auto take = [&](double &b, unsigned long long &bi_, double &s2, unsigned long long &si, double q, unsigned long long idx) {
+			if (idx == ~0ULL) return;
+			if (q < b || (q == b && idx < bi_)) { if (!same_pair(idx, bi_)) { s2 = b; si = bi_; } b = q; bi_ = idx; }
+			else if (q < s2 && !same_pair(idx, bi_)) { s2 = q; si = idx; }
+		};
 		for (int r = tid; r < m; r += NJ_NT) {
 			const double *row = D + (size_t)alive[r] * n;
 			const double sr = s1[r];
@@ -356,20 +373,29 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 				if (c == r) continue;
 				const double q = (mm2 * row[alive[c]] - s0[c]) - sr;
 				const unsigned long long idx = (unsigned long long)r * (unsigned)m + (unsigned)c;
-				if (q < bq || (q == bq && idx < bidx)) bq = q, bidx = idx;
+				if (q < q2nd || q < bq || (q == bq && idx < bidx)) take(bq, bidx, q2nd, i2nd, q, idx);
 			}
 		}
-		rq[tid] = bq; ri[tid] = bidx;
+		rq[tid] = bq; ri[tid] = bidx; rq2[tid] = q2nd; ri2[tid] = i2nd;
 		__syncthreads();
 		for (int sft = NJ_NT / 2; sft > 0; sft >>= 1) {
 			if (tid < sft) {
-				const double q2 = rq[tid + sft]; const unsigned long long i2 = ri[tid + sft];
-				if (q2 < rq[tid] || (q2 == rq[tid] && i2 < ri[tid])) rq[tid] = q2, ri[tid] = i2;
+				double b = rq[tid], s2 = rq2[tid]; unsigned long long bi_ = ri[tid], si = ri2[tid];
+				take(b, bi_, s2, si, rq[tid + sft], ri[tid + sft]);
+				take(b, bi_, s2, si, rq2[tid + sft], ri2[tid + sft]);
+				rq[tid] = b; ri[tid] = bi_; rq2[tid] = s2; ri2[tid] = si;
 			}
 			__syncthreads();
 		}
 		const unsigned long long best = ri[0];
 		if (best == ~0ULL) { if (tid == 0) *status = -1; return; }
+		{
+			// |error of a sum of m terms of size <= 1.5 d_max| <= m * 2^-53 * 1.5 m d_max; Q holds two of them and (m - 2) * d
+			const double tol = 8.0 * (double)m * (double)m * 1.1102230246251565e-16 * d_max;
+			// (m = 4 and m = 3 are not counted: there the Q of complementary pairs -- of all three pairs -- are EQUAL in exact arithmetic,
+			// so the last two joins of every tree rest on the rounding of the sums; see include/pga_align.h)
+			if (m > 4 && ri2[0] != ~0ULL && rq2[0] - rq[0] <= tol) { if (n_near == 0) first_near = t; ++n_near; }
+		}
 		int bi = (int)(best / (unsigned)m), bj = (int)(best % (unsigned)m);
 		const int i = bi < bj ? bi : bj, j = bi < bj ? bj : bi;
 		const int pi = alive[i], pj = alive[j];
@@ -400,23 +426,40 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 		else __threadfence_block();
 		__syncthreads();
 	}
-	if (tid == 0) { merges[2 * t] = node[0]; merges[2 * t + 1] = node[1]; *status = 0; }
+	if (tid == 0) { merges[2 * t] = node[0]; merges[2 * t + 1] = node[1]; *status = 0; if (near) { near[0] = n_near; near[1] = first_near; } }
 }
+
+static thread_local int32_t t_nj_near[2] = {0, -1};
+void nj_last_near(int32_t *count, int32_t *first) { *count = t_nj_near[0]; *first = t_nj_near[1]; }
 
 static void nj_dev(int n, double *d_D, std::vector<int32_t> &merges, hipStream_t st)
 {
 	merges.assign((size_t)std::max(0, n - 1) * 2, 0);
+	t_nj_near[0] = 0, t_nj_near[1] = -1;
 	if (n < 2) return;
+	// the scale of the matrix, for the near-tie bound
+	double d_max = 0.0;
+	{
+		DBuf<double> d_mx(1);
+		size_t tb = 0;
+		auto it = rocprim::make_transform_iterator(d_D, [] __device__ (double v) { return v < 0 ? -v : v; });
+		PGA_HIP(rocprim::reduce(nullptr, tb, it, d_mx.p, 0.0, (size_t)n * n, rocprim::maximum<double>(), st));
+		DBuf<uint8_t> tmp(tb ? tb : 1);
+		PGA_HIP(rocprim::reduce(tmp.p, tb, it, d_mx.p, 0.0, (size_t)n * n, rocprim::maximum<double>(), st));
+		d_max = d_mx.download(st)[0];
+	}
+	DBuf<int32_t> d_near(2); d_near.zero(st);
 	DBuf<int32_t> d_m((size_t)(n - 1) * 2); DBuf<int> d_s(1);
 	{ const int one = 1; PGA_HIP(hipMemcpyAsync(d_s.p, &one, sizeof(int), hipMemcpyHostToDevice, st)); }
 	DBuf<unsigned char> scratch;
 	if (n > NJ_MAX) {
 		scratch.alloc((size_t)24 * n + 64);
-		hipLaunchKernelGGL(k_nj<true>, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p, scratch.p);
-	} else hipLaunchKernelGGL(k_nj<false>, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p, (unsigned char*)nullptr);
+		hipLaunchKernelGGL(k_nj<true>, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p, scratch.p, d_max, d_near.p);
+	} else hipLaunchKernelGGL(k_nj<false>, dim3(1), dim3(NJ_NT), 0, st, n, d_D, d_m.p, d_s.p, (unsigned char*)nullptr, d_max, d_near.p);
 	PGA_HIP(hipGetLastError());
 	if (d_s.download(st)[0] != 0) throw std::runtime_error("pga: neighbor joining found no pair to join (the distance matrix holds NaN or infinity)");
 	merges = d_m.download(st);
+	{ std::vector<int32_t> nr = d_near.download(st); t_nj_near[0] = nr[0]; t_nj_near[1] = nr[1]; }
 }
 
 // ---------------------------------------------------------------- entry points used by pga_api.cpp

@@ -514,7 +514,7 @@ void replay_sort_segments(u128 *a, uint64_t n_total, const uint64_t *d_off, cons
 	hipLaunchKernelGGL(k_rs_small, dim3(8192), dim3(64), 0, st, a, qs.p, ctr.p + 18, cap, ctr.p + 19);
 	const double ms_small = verbose ? es.stop() : 0.0;
 	PGA_HIP(hipGetLastError());
-	const double ms = et.stop();
+	const double ms = et.stop(K_SORT);
 	if (tm) { tm->kern[K_SORT].ms += ms; tm->kern[K_SORT].launches += 1; tm->kern[K_SORT].alg_bytes += 32.0 * (double)n_total; }   // every record read and written once (per level, at least one)
 	std::vector<uint32_t> h = ctr.download(st);
 	if (!sync_passes) async_overflow = Qd.download(st)[0].overflow != 0;

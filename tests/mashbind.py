@@ -126,3 +126,11 @@ def product_nj(dll, d):
         dll.pga_last_error.restype = C.c_char_p
         raise RuntimeError(dll.pga_last_error().decode())
     return merges
+
+
+def product_nj_near_ties(dll):
+    """(count, first join) of the calling thread's last joining call: pga_nj_near_ties"""
+    dll.pga_nj_near_ties.restype = C.c_int32
+    dll.pga_nj_near_ties.argtypes = [C.POINTER(C.c_int32)]
+    first = C.c_int32(-2)
+    return int(dll.pga_nj_near_ties(C.byref(first))), int(first.value)

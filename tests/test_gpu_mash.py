@@ -75,6 +75,34 @@ def test_neighbor_joining_vs_oracle_random_matrices(gpu_lib, oracle_lib):
         assert (got == want).all(), n
 
 
+def test_near_tie_flag_of_the_joining_step(gpu_lib, oracle_lib):
+    """neighbor_joining.rs:77-96 takes the smallest Q; the sums behind Q are f64 sums in ndarray's order as restated (not pinned against ndarray).
+    pga_nj_near_ties counts the joins in which ANOTHER pair's Q lies within the reordering error of the chosen one: none for a matrix of
+    well separated distances, some as soon as distances repeat (quantised matrix: exact ties, the first minimum decides)."""
+    rng = np.random.default_rng(41)
+    n = 200
+    d = rng.random((n, n)); d = (d + d.T) / 2; np.fill_diagonal(d, 0.0)
+    got = mb.product_nj(gpu_lib.dll, d)
+    assert (got == mb.oracle_nj(oracle_lib.dll, d)).all()
+    assert mb.product_nj_near_ties(gpu_lib.dll) == (0, -1)
+    q = np.round(d * 4) / 4; q = (q + q.T) / 2; np.fill_diagonal(q, 0.0)
+    got = mb.product_nj(gpu_lib.dll, q)
+    assert (got == mb.oracle_nj(oracle_lib.dll, q)).all()
+    cnt, first = mb.product_nj_near_ties(gpu_lib.dll)
+    assert cnt > 0 and 0 <= first < n - 1
+    # two pairs whose Q differ by a few parts in 10^15: flagged although the values are not equal (six nodes: the joins at m = 4 and
+    # m = 3, tied in exact arithmetic in every tree, are not counted)
+    e = np.full((6, 6), 4.0); np.fill_diagonal(e, 0.0)
+    e[0, 1] = e[1, 0] = 1.0; e[2, 3] = e[3, 2] = 1.0 + 4e-15; e[4, 5] = e[5, 4] = 3.0
+    mb.product_nj(gpu_lib.dll, e)
+    assert mb.product_nj_near_ties(gpu_lib.dll) == (1, 0)
+    # the big-matrix variant of the kernel (state in device memory) carries the flag too
+    n = 2100
+    d = rng.random((n, n)); d = (d + d.T) / 2; np.fill_diagonal(d, 0.0)
+    mb.product_nj(gpu_lib.dll, d)
+    assert mb.product_nj_near_ties(gpu_lib.dll)[0] == 0
+
+
 def test_bit_matrix_slabs_do_not_change_the_counts(gpu_lib, oracle_lib, monkeypatch):
     rng = np.random.default_rng(23)
     seqs = [_rand(rng, 20000) for _ in range(5)]
