@@ -620,7 +620,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
-		hipStream_t cs = lane_stream[serial ? 0 : lane_of_class[c]];
+		static const bool on_main = getenv("PGA_DP_ON_MAIN") != nullptr;    // experiment: every class on the call's own stream (one hardware queue per batch)
+		hipStream_t cs = on_main ? st : lane_stream[serial ? 0 : lane_of_class[c]];
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
 		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
@@ -683,7 +684,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
-		download_to(r, X.d_r.p, ids.size(), lane_stream[getenv("PGA_DP_SERIAL") ? 0 : lane_of_class[c]]);
+		download_to(r, X.d_r.p, ids.size(), getenv("PGA_DP_ON_MAIN") ? st : lane_stream[getenv("PGA_DP_SERIAL") ? 0 : lane_of_class[c]]);
 		if (tm) {
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below.
 			// cells: what the kernel's loops evaluated -- the corridor kernel 32 columns on every diagonal, the register tiles the whole
