@@ -1065,7 +1065,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 0, 32, st));
 	}
 	mark("segments");
-	DBuf<CNode> nd_main(n_a), nd_inner(n_a);
+	DBuf<CNode> nd_main, nd_inner;                        // the tree re-enactment's nodes (64 B per anchor): only when a segment needs it
 	DBuf<int32_t> f(n_a), pp(n_a), t(n_a), v(n_a);
 	t.zero(st);
 	mark("buffers");
@@ -1079,8 +1079,24 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		if (use_fast && prof_on) hipLaunchKernelGGL((k_chain_fast<2048, true>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, cprof.p);
 		else if (use_fast) hipLaunchKernelGGL((k_chain_fast<2048, false>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
 		const double ms_fast = verbose ? et.stop() : 0.0;
-		hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
-		                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+		// segments the fast kernel gave up on (rare: ring overflow, a tied minimum, a crowded inner window) are re-run by the tree kernel
+		bool any_flagged = !use_fast;
+		if (use_fast) {
+			DBuf<uint32_t> n_fl(1);
+			struct Fl { const uint32_t *f; };
+			Fl fl{seg_flag.p};
+			auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0), [fl] __device__ (uint32_t i) { return (uint32_t)(fl.f[i] != 0); });
+			size_t tb = 0;
+			PGA_HIP(rocprim::reduce(nullptr, tb, it, n_fl.p, 0u, (size_t)n_seg, rocprim::plus<uint32_t>(), st));
+			DBuf<uint8_t> tmp(tb ? tb : 1);
+			PGA_HIP(rocprim::reduce(tmp.p, tb, it, n_fl.p, 0u, (size_t)n_seg, rocprim::plus<uint32_t>(), st));
+			any_flagged = n_fl.download(st)[0] != 0;
+		}
+		if (any_flagged) {
+			nd_main.alloc(n_a); nd_inner.alloc(n_a);
+			hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
+			                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
+		}
 		PGA_HIP(hipGetLastError());
 		const double ms = et.stop(K_CHAIN);
 		if (getenv("PGA_VERBOSE") && use_fast) {
