@@ -872,12 +872,21 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	// ---- walks (every lane executes the same control flow) ----
 	const int32_t max_drop = P.bw;
 	int64_t n_v = 0; int32_t n_u = 0;
+	// Almost every candidate is an inner anchor of a chain that a better candidate has already walked over: a batch whose 64 marks are all
+	// set needs nothing.  The candidates of the batch after next and the marks of the next batch are requested while this one is looked at
+	// (two dependent loads, ~2 us, per batch otherwise); marks are only ever set, so a mark read early can only err towards "look again".
+	auto load_z = [&](int64_t kb_, int32_t &f_, int32_t &i_) { const int64_t km = kb_ - 1 - lane; f_ = 0; i_ = -1; if (kb_ > 0 && km >= 0) { const u128 e = z[km]; f_ = (int32_t)e.x; i_ = (int32_t)e.y; } };
+	int32_t zf1, zi1, zf2, zi2, tm1 = 1;
+	load_z(n_z, zf1, zi1);
+	load_z(n_z - 64, zf2, zi2);
+	if (zi1 >= 0) tm1 = t[zi1];
 	for (int64_t kb = n_z; kb > 0; kb -= 64) {
 		// a batch of 64 candidates, highest rank in lane 0
-		const int64_t k_mine = kb - 1 - lane;
-		int32_t zf = 0, zi = -1;
-		if (k_mine >= 0) { zf = (int32_t)z[k_mine].x; zi = (int32_t)z[k_mine].y; }
-		unsigned long long todo = __ballot(zi >= 0);
+		const int32_t zf = zf1, zi = zi1, tm = tm1;
+		zf1 = zf2; zi1 = zi2; tm1 = 1;
+		if (zi1 >= 0) tm1 = t[zi1];                                  // (early: re-read below whenever it says "unmarked")
+		load_z(kb - 128, zf2, zi2);
+		unsigned long long todo = __ballot(zi >= 0 && tm == 0);
 		while (todo) {
 			// marks of the remaining candidates as of now (the previous chain may have covered some of them)
 			const bool open = zi >= 0 && ((todo >> lane) & 1) && t[zi] == 0;
