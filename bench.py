@@ -335,6 +335,7 @@ def main():
         recs, pools, pool_len = [], [], [0]
 
         def run_batch(ts):
+            batch.set_device(local)                               # HIP's current device belongs to the host thread: every worker says which one it means
             tb = sched.TaskBatch(ts, lib_first)
             t0 = time.perf_counter()
             rb = batch.ResidentBatch(tb, derive_from=lib)         # inputs resident: device-to-device; --inputs host: hand-over inside the timed region

@@ -1,0 +1,28 @@
+"""Where does a call near the root spend its time?  The last merges of the C5 build, each as its own batch, inputs resident."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pangraph_amd import batch, schedule as sched
+from pangraph_amd.levels import Population
+pop = Population(20260928, 1000, 5_000_000)
+tasks = sched.build_tasks(pop)
+top = sorted(tasks, key=lambda t: -pop.nodes[t.node].height)[:6]
+first, n = {}, 0
+for t in top:
+    t.prepare(); first[t.tid] = n; n += len(t.seqs)
+lib = batch.ResidentBatch(sched.TaskBatch(top))
+for rep in range(3):
+    for t in top:
+        t0 = time.perf_counter()
+        tb = sched.TaskBatch([t], first)
+        t1 = time.perf_counter()
+        rb = batch.ResidentBatch(tb, derive_from=lib)
+        t2 = time.perf_counter()
+        res = rb.align(sensitivity=10, want_raw=False, n_threads=8)
+        t3 = time.perf_counter()
+        st = res.stats
+        res.close(); rb.close()
+        t4 = time.perf_counter()
+        if rep == 2:
+            print(f"h{pop.nodes[t.node].height} r{t.round} n_seq={len(t.seqs)} Mbp={t.bases/1e6:.1f} matches={int(st['n_matches'])} | python batch {1e3*(t1-t0):.1f} derive {1e3*(t2-t1):.1f} align {1e3*(t3-t2):.1f} close {1e3*(t4-t3):.1f} ms | stages " +
+                  " ".join(f"{k} {1e3*st[k]:.1f}" for k in ("upload", "sketch", "index", "seed", "chain", "align", "total")))

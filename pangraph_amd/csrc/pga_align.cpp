@@ -942,14 +942,14 @@ struct RoundRunner {
 				try {
 					PGA_HIP(hipSetDevice(dev));
 					set_thread_budget(1);
-					PGA_HIP(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+					ss = stream_lease();
 					one[k].assign(1, open[k]);
 					Driver Dq(S, opt, D.k, ss);
 					RoundRunner R{S, opt, Dq, Q, out, one[k], set_id * 1000 + (int)k + 1, 1, ss, tm ? &tms[k] : nullptr, P, verbose, {}};
 					R.tail = true;
 					R.run();
 				} catch (std::exception &e) { errs[k] = e.what(); if (errs[k].empty()) errs[k] = "unknown error"; }
-				if (ss) { (void)hipStreamSynchronize(ss); (void)hipStreamDestroy(ss); }
+				if (ss) stream_release(ss);
 				dev_release_arena(arena);
 			}
 		};
@@ -970,8 +970,11 @@ struct RoundRunner {
 	{
 		static const int tail_max = getenv("PGA_TAIL_QUERIES") ? atoi(getenv("PGA_TAIL_QUERIES")) : 0;      // off by default: measured slower (the extra streams and lane sets get in the way of the other parts), see DESIGN.md
 		for (int round = 0; round < 100000; ++round) {
+			const double t_r0 = wall_s();
 			run_probes();
+			const double t_r1 = wall_s();
 			run_dp(round);
+			if (verbose) fprintf(stderr, "[pga]   set %d round %d: probes %.4f s, dp %.4f s\n", set_id, round, t_r1 - t_r0, wall_s() - t_r1);
 			const double t_adv0 = wall_s();
 			int unfinished;
 			for (;;) { unfinished = advance_pass(); if (!run_post()) break; }
@@ -1000,6 +1003,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	Driver D(S, opt, k, st);
 	std::vector<QueryCtx> Q((size_t)n_seq);
+	if (verbose) fprintf(stderr, "[pga]   align: contexts of %d queries %.4f s\n", n_seq, wall_s() - t_align0);
 	// ---- regions (mm_gen_regs) and plans ----
 	parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
 		QueryCtx &q = Q[qi];
@@ -1044,7 +1048,8 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	std::vector<std::vector<int>> sets((size_t)n_sets);
 	for (int i = 0; i < n_seq; ++i) sets[(size_t)(i % n_sets)].push_back(order[(size_t)i]);
 	for (auto &v : sets) std::sort(v.begin(), v.end());
-	if (n_sets == 1) { RoundRunner R{S, opt, D, Q, out, sets[0], 0, n_threads, st, tm, P, verbose, {}}; R.run(); return; }
+	if (verbose) fprintf(stderr, "[pga]   align: %d set(s) dealt at +%.4f s\n", n_sets, wall_s() - t_align0);
+	if (n_sets == 1) { RoundRunner R{S, opt, D, Q, out, sets[0], 0, n_threads, st, tm, P, verbose, {}}; R.run(); if (verbose) fprintf(stderr, "[pga]   align: rounds done at +%.4f s\n", wall_s() - t_align0); return; }
 	int dev = 0; PGA_HIP(hipGetDevice(&dev));
 	std::vector<Timers> tms((size_t)n_sets);
 	std::vector<std::string> errs((size_t)n_sets);
@@ -1056,15 +1061,16 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 		try {
 			PGA_HIP(hipSetDevice(dev));
 			set_thread_budget(std::max(1, n_threads / n_sets));
-			PGA_HIP(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+			ss = stream_lease();
 			Driver Ds(S, opt, k, ss);
 			RoundRunner R{S, opt, Ds, Q, out, sets[(size_t)s], s, std::max(1, n_threads / n_sets), ss, tm ? &tms[(size_t)s] : nullptr, P, verbose, {}};
 			R.run();
 		} catch (std::exception &e) { errs[(size_t)s] = e.what(); if (errs[(size_t)s].empty()) errs[(size_t)s] = "unknown error"; }
-		if (ss) { (void)hipStreamSynchronize(ss); (void)hipStreamDestroy(ss); }
+		if (ss) stream_release(ss);
 		dev_release_arena(arena);                 // (the DP lane streams drained inside dp_run; the set's stream just did)
 	});
 	for (auto &t : th) t.join();
+	if (verbose) fprintf(stderr, "[pga]   align: sets joined at +%.4f s\n", wall_s() - t_align0);
 	for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
 	if (tm) for (const Timers &t : tms) {
 		tm->dp_jobs += t.dp_jobs; tm->dp_cells += t.dp_cells; tm->dp_bases += t.dp_bases; tm->dp_cigar_ops += t.dp_cigar_ops;

@@ -100,16 +100,23 @@ struct PgaIdx {
 	hipStream_t st = 0;              // the part's own (non-blocking) stream
 	int arena = 0;                   // device-memory arena of the index, leased for its lifetime (pga_mem.cpp)
 	PgaIdx() : arena(dev_lease_arena()) {}
-	~PgaIdx() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } release_buffers(); dev_release_arena(arena); }
+	~PgaIdx() { if (st) { (void)hipStreamSynchronize(st); } release_buffers(); if (st) stream_release(st); dev_release_arena(arena); }
 	void release_buffers() { S.d_pk2.release(); S.d_nmask.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
 		I.key.release(); I.occ_off.release(); I.occ.release(); I.key_grp.release(); grp.release(); d_name_rank.release(); d_mid_occ.release(); }
 };
 
+// HIP's current device is a property of the HOST THREAD (device 0 until the thread says otherwise).  pga_set_device() therefore also records
+// the device as the process default, and every entry point applies it to the thread it is called on: a host that calls the library from
+// worker threads (the ready-set schedule of bench.py: one thread per batch in flight) works on the rank's device, not on device 0.
+static std::atomic<int> g_default_dev(-1);
+static void apply_default_device() noexcept { const int d = g_default_dev.load(); if (d >= 0) { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != d) (void)hipSetDevice(d); } }
 static void require_device()
 {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
 		throw std::runtime_error("pga: no HIP device visible -- libpgalign.so is a gfx950 backend and has no CPU fallback");
+	const int d = g_default_dev.load();
+	if (d >= 0) { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != d) PGA_HIP(hipSetDevice(d)); }
 }
 
 static void check_supported(const mm_mapopt_t &o, int k, int w)
@@ -150,7 +157,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	std::unique_ptr<PgaIdx> ix(new PgaIdx());
 	ArenaScope arena_scope(ix->arena);
 	memset(&ix->hdr, 0, sizeof(ix->hdr));
-	PGA_HIP(hipStreamCreateWithFlags(&ix->st, hipStreamNonBlocking));
+	ix->st = stream_lease();
 	if (w < 1) w = 1;
 	double t0 = now_s();
 	const int64_t one_grp[2] = {0, n};
@@ -243,7 +250,7 @@ extern "C" mm_idx_t *mm_idx_str(int w, int k, int is_hpc, int bucket_bits, int n
 		return reinterpret_cast<mm_idx_t*>(idx_build(w, k, n, seq, len.data(), name));
 	} catch (std::exception &e) { set_err(e.what()); fprintf(stderr, "[pga] mm_idx_str: %s\n", e.what()); return 0; }
 }
-extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete reinterpret_cast<PgaIdx*>(mi); }
+extern "C" void mm_idx_destroy(mm_idx_t *mi) { apply_default_device(); delete reinterpret_cast<PgaIdx*>(mi); }
 
 extern "C" void mm_mapopt_update(mm_mapopt_t *opt, const mm_idx_t *mi) // options.c:66-80
 {
@@ -320,6 +327,7 @@ extern "C" mm_reg1_t *mm_map(const mm_idx_t *mi, int l_seq, const char *seq, int
 	PgaIdx *ix = reinterpret_cast<PgaIdx*>(const_cast<mm_idx_t*>(mi));
 	if (l_seq == 0) return 0;
 	try {
+		require_device();                      // (the reference calls mm_map from its rayon workers: each thread gets the process's device)
 		auto it = name ? ix->by_name.find(name) : ix->by_name.end();
 		if (it == ix->by_name.end() || (int)ix->S.len[it->second] != l_seq)
 			throw std::runtime_error(std::string("pga: mm_map() query '") + (name ? name : "(null)") + "' is not one of the indexed sequences; this backend aligns a group all-vs-all "
@@ -407,6 +415,7 @@ extern "C" int pga_align_groups(const pga_params_t *params, int32_t n_groups, co
 {
 	*out = nullptr;
 	try {
+		require_device();
 		mm_idxopt_t io; mm_mapopt_t mo0;
 		params_to_opts(*params, io, mo0);
 		std::unique_ptr<pga_result_s> R(new pga_result_s());
@@ -599,7 +608,7 @@ static int batch_align_impl(pga_batch_t *B, const pga_params_t *params, int shar
 		return 0;
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
-extern "C" void pga_batch_free(pga_batch_t *B) { delete B; }
+extern "C" void pga_batch_free(pga_batch_t *B) { apply_default_device(); delete B; }
 
 extern "C" int64_t pga_result_n_matches(const pga_result_t *r) { return (int64_t)r->m.size(); }
 extern "C" const pga_match_t *pga_result_matches(const pga_result_t *r) { return r->m.data(); }
@@ -608,7 +617,7 @@ extern "C" const pga_stats_t *pga_result_stats(const pga_result_t *r) { return &
 extern "C" void pga_result_free(pga_result_t *r) { delete r; }
 extern "C" const char *pga_last_error(void) { return g_err.c_str(); }
 extern "C" int pga_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-extern "C" int pga_set_device(int dev) { if (hipSetDevice(dev) != hipSuccess) { set_err("hipSetDevice failed"); return -1; } return 0; }
+extern "C" int pga_set_device(int dev) { if (hipSetDevice(dev) != hipSuccess) { set_err("hipSetDevice failed"); return -1; } g_default_dev.store(dev); return 0; }
 extern "C" void pga_free(void *p) { free(p); }
 extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
 

@@ -159,6 +159,9 @@ struct Timers {
 // leaves its interval [a, b] on the device's clock; the union per family and over all families is what a step really spent with that
 // kernel resident, however many streams and batches overlapped (the sums of kern[].ms do not add up to wall time).  Both events complete.
 void busy_note(int kern, hipEvent_t a, hipEvent_t b);
+// leased non-blocking streams of the current device (pga_mem.cpp); release drains the stream
+hipStream_t stream_lease();
+void stream_release(hipStream_t s);
 // times everything enqueued on `st` between construction and stop()
 struct EventTimer {
 	hipEvent_t a, b; hipStream_t st;

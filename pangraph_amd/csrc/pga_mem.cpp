@@ -147,6 +147,31 @@ void dev_free(void *p)
 	for (void *q : drop) { NsScope sc(g_n_free, g_ns_free); (void)hipFree(q); }
 }
 
+// ---- pooled streams: a batch handle, a query set, a tail query each work on a stream of their own for a few milliseconds; creating and
+// destroying a stream costs about as much (hipStreamCreate ... hipStreamDestroy: ~1-3 ms with the synchronisation), so streams are leased.
+// A stream goes back drained (the caller synchronises it), so its next user starts on an empty stream.
+namespace { std::mutex g_st_mu; std::map<int, std::vector<hipStream_t>> g_st_idle; }
+hipStream_t stream_lease()
+{
+	int dev = 0; PGA_HIP(hipGetDevice(&dev));
+	{
+		std::lock_guard<std::mutex> lk(g_st_mu);
+		auto &v = g_st_idle[dev];
+		if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+	}
+	hipStream_t s = nullptr;
+	PGA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	return s;
+}
+void stream_release(hipStream_t s)
+{
+	if (!s) return;
+	(void)hipStreamSynchronize(s);
+	int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(s); return; }
+	std::lock_guard<std::mutex> lk(g_st_mu);
+	g_st_idle[dev].push_back(s);
+}
+
 void dev_mem_stats(long long out[4]) { out[0] = g_n_malloc; out[1] = g_ns_malloc; out[2] = g_n_free; out[3] = g_ns_free; }
 
 void dev_trim()
