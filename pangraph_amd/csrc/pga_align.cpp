@@ -24,6 +24,7 @@
 #include <thread>
 #include <atomic>
 #include <list>
+#include <condition_variable>
 #include <deque>
 #include <chrono>
 #include <cstdio>
@@ -418,7 +419,7 @@ struct QueryCtx {
 	bool finished = false;
 	// DP problems of this query (ids are per query; filled between the threaded phases)
 	std::vector<DpJob> jobs; std::vector<DpRes> res; std::vector<const uint32_t*> cig; std::vector<int> pending;   // cig[id] points into a per-round CIGAR pool
-	std::deque<uint32_t> own_cig;     // one-operation CIGARs of the gap fills answered by the identity probe (stable addresses)
+	std::unique_ptr<std::deque<uint32_t>> own_cig;   // one-operation CIGARs of the gap fills answered by the identity probe (stable addresses; made on first use: an empty deque already owns 0.5 KB)
 	std::vector<WalkAsk> walks;       // device requests raised by the last advance pass
 	std::vector<RegTask*> fins;
 };
@@ -466,8 +467,9 @@ struct Driver {
 		DpRes &r = Q.res[(size_t)id];
 		r.max = 0; r.max_q = r.max_t = r.mqe_t = r.mte_q = -1; r.mqe = r.mte = DP_NEG_INF;
 		r.score = mat[0] * (j.qlen - m) + mat[1] * m; r.n_cigar = 1; r.zdropped = 0; r.pad = 1;
-		Q.own_cig.push_back((uint32_t)j.qlen << 4);
-		Q.cig[(size_t)id] = &Q.own_cig.back();
+		if (!Q.own_cig) Q.own_cig.reset(new std::deque<uint32_t>());
+		Q.own_cig->push_back((uint32_t)j.qlen << 4);
+		Q.cig[(size_t)id] = &Q.own_cig->back();
 	}
 
 	// ---- plan (align.c:583-700): everything mm_align1 decides before its first DP call ----
@@ -729,18 +731,49 @@ struct Driver {
 	}
 };
 
+// parallel_for over a pool of persistent helper threads: a round of a small call runs a dozen of these loops, and starting eight
+// std::threads for each costs more than the loop (0.3 ms a time).  The caller always takes part, so a loop makes progress even when
+// every helper is busy with the loops of other batches; helpers join a loop through tickets and are counted, the caller leaves only when
+// the tickets nobody took are withdrawn and the helpers that joined are done.
+namespace {
+struct PfJob { std::atomic<size_t> next{0}; size_t n = 0; void (*run)(void*, size_t) = nullptr; void *ctx = nullptr; int active = 0; std::exception_ptr err; };
+struct PfPool {
+	std::mutex mu; std::condition_variable cv_work, cv_done; std::deque<PfJob*> tickets; std::vector<std::thread> th; bool stop = false;
+	void loop(PfJob *j) { try { for (;;) { const size_t i = j->next.fetch_add(1); if (i >= j->n) break; j->run(j->ctx, i); } } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!j->err) j->err = std::current_exception(); j->next.store(j->n); } }
+	void worker() {
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv_work.wait(lk, [&] { return stop || !tickets.empty(); });
+			if (stop) return;
+			PfJob *j = tickets.front(); tickets.pop_front(); ++j->active;
+			lk.unlock(); loop(j); lk.lock();
+			if (--j->active == 0) cv_done.notify_all();
+		}
+	}
+	void grow(size_t want) { while (th.size() < want) th.emplace_back([this] { worker(); }); }     // (mu held)
+	~PfPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_work.notify_all(); for (auto &t : th) t.join(); }
+};
+PfPool &pf_pool() { static PfPool *p = new PfPool(); return *p; }       // (leaked on purpose: no destructor order games at exit)
+}
 template <class F> static void parallel_for(size_t n, int n_threads, F f)
 {
 	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) f(i); return; }
-	std::atomic<size_t> next(0);
-	std::vector<std::thread> th;
-	std::exception_ptr err = nullptr; std::mutex em;
-	for (int t = 0; t < n_threads; ++t) th.emplace_back([&] {
-		try { for (;;) { size_t i = next.fetch_add(1); if (i >= n) break; f(i); } }
-		catch (...) { std::lock_guard<std::mutex> lk(em); if (!err) err = std::current_exception(); }
-	});
-	for (auto &t : th) t.join();
-	if (err) std::rethrow_exception(err);
+	PfJob job; job.n = n; job.ctx = &f; job.run = [](void *c, size_t i) { (*static_cast<F*>(c))(i); };
+	const size_t helpers = std::min<size_t>((size_t)n_threads - 1, n - 1);
+	PfPool &P = pf_pool();
+	{
+		std::lock_guard<std::mutex> lk(P.mu);
+		P.grow(std::min<size_t>(64, std::max<size_t>(P.th.size(), (size_t)std::max(usable_cpus(), n_threads))));
+		for (size_t h = 0; h < helpers; ++h) P.tickets.push_back(&job);
+	}
+	P.cv_work.notify_all();
+	P.loop(&job);
+	{
+		std::unique_lock<std::mutex> lk(P.mu);
+		for (auto it = P.tickets.begin(); it != P.tickets.end();) it = *it == &job ? P.tickets.erase(it) : it + 1;
+		P.cv_done.wait(lk, [&] { return job.active == 0; });
+	}
+	if (job.err) std::rethrow_exception(job.err);
 }
 
 // ---------------------------------------------------------------- one set of queries through its rounds
@@ -1049,7 +1082,10 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	for (int i = 0; i < n_seq; ++i) sets[(size_t)(i % n_sets)].push_back(order[(size_t)i]);
 	for (auto &v : sets) std::sort(v.begin(), v.end());
 	if (verbose) fprintf(stderr, "[pga]   align: %d set(s) dealt at +%.4f s\n", n_sets, wall_s() - t_align0);
-	if (n_sets == 1) { RoundRunner R{S, opt, D, Q, out, sets[0], 0, n_threads, st, tm, P, verbose, {}}; R.run(); if (verbose) fprintf(stderr, "[pga]   align: rounds done at +%.4f s\n", wall_s() - t_align0); return; }
+	// the contexts of a call hold a few small heap blocks per query and region (thousands of sequences per call near the root): they are
+	// taken apart by the worker threads, not one after the other at the closing brace
+	auto scrap = [&] { parallel_for(Q.size(), n_threads, [&](size_t i) { QueryCtx dead(std::move(Q[i])); }); };
+	if (n_sets == 1) { RoundRunner R{S, opt, D, Q, out, sets[0], 0, n_threads, st, tm, P, verbose, {}}; R.run(); scrap(); if (verbose) fprintf(stderr, "[pga]   align: rounds done at +%.4f s\n", wall_s() - t_align0); return; }
 	int dev = 0; PGA_HIP(hipGetDevice(&dev));
 	std::vector<Timers> tms((size_t)n_sets);
 	std::vector<std::string> errs((size_t)n_sets);
@@ -1071,6 +1107,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	});
 	for (auto &t : th) t.join();
 	if (verbose) fprintf(stderr, "[pga]   align: sets joined at +%.4f s\n", wall_s() - t_align0);
+	scrap();
 	for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
 	if (tm) for (const Timers &t : tms) {
 		tm->dp_jobs += t.dp_jobs; tm->dp_cells += t.dp_cells; tm->dp_bases += t.dp_bases; tm->dp_cigar_ops += t.dp_cigar_ops;

@@ -89,7 +89,7 @@ struct PgaIdx {
 	DBuf<uint8_t> d_own; bool sharded = false;    // pga_batch_align_shard: the queries this call maps (all sequences are indexed)
 	std::vector<int32_t> mid_occ_raw;   // mm_idx_cal_max_occ per group (cached per fraction)
 	float mid_occ_frac = -1.0f;
-	std::vector<mm_idx_seq_t> seq_hdr; std::vector<std::string> names;
+	std::vector<mm_idx_seq_t> seq_hdr;
 	std::map<std::string, int> by_name;
 	std::mutex mtx;
 	bool have_results = false, indexed = false; mm_mapopt_t res_opt;
@@ -163,22 +163,22 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	const int64_t one_grp[2] = {0, n};
 	if (!grp_off) grp_off = one_grp, n_grp = 1;
 	upload_seqs(ix->S, n, seq, len, name, n_grp, grp_off, ix->st, from, from_probe);
-	ix->names = ix->S.name;
+	const std::vector<std::string> &nm = ix->S.name;                  // (the names live in the sequence set: no second copy)
 	ix->seq_hdr.resize((size_t)n);
 	for (int i = 0; i < n; ++i) {
-		ix->seq_hdr[i].name = name && name[i] ? const_cast<char*>(ix->names[i].c_str()) : nullptr;
+		ix->seq_hdr[i].name = name && name[i] ? const_cast<char*>(nm[i].c_str()) : nullptr;
 		ix->seq_hdr[i].offset = ix->S.off[i]; ix->seq_hdr[i].len = len[i]; ix->seq_hdr[i].is_alt = 0;
-		if (name && name[i] && n_grp == 1) ix->by_name[ix->names[i]] = i;
+		if (name && name[i] && n_grp == 1) ix->by_name[nm[i]] = i;
 	}
 	// rank of every name under strcmp order inside its group (skip_seed compares names as C strings, map.c:84,89)
 	std::vector<int32_t> rank((size_t)n);
 	for (int g = 0; g < n_grp; ++g) {
 		const int b = (int)grp_off[g], m = (int)(grp_off[g + 1] - grp_off[g]);
 		std::vector<int> ord((size_t)m); for (int i = 0; i < m; ++i) ord[i] = b + i;
-		std::sort(ord.begin(), ord.end(), [&](int a, int c) { return strcmp(ix->names[a].c_str(), ix->names[c].c_str()) < 0; });
+		std::sort(ord.begin(), ord.end(), [&](int a, int c) { return strcmp(nm[a].c_str(), nm[c].c_str()) < 0; });
 		for (int i = 0; i < m; ++i) {
-			if (i > 0 && ix->names[ord[i]] == ix->names[ord[i - 1]] && name)
-				throw std::runtime_error("pga: duplicate sequence name '" + ix->names[ord[i]] + "' inside a group (index.c:436 asserts uniqueness)");
+			if (i > 0 && nm[ord[i]] == nm[ord[i - 1]] && name)
+				throw std::runtime_error("pga: duplicate sequence name '" + nm[ord[i]] + "' inside a group (index.c:436 asserts uniqueness)");
 			rank[ord[i]] = i;
 		}
 	}
