@@ -736,10 +736,10 @@ struct Driver {
 // every helper is busy with the loops of other batches; helpers join a loop through tickets and are counted, the caller leaves only when
 // the tickets nobody took are withdrawn and the helpers that joined are done.
 namespace {
-struct PfJob { std::atomic<size_t> next{0}; size_t n = 0; void (*run)(void*, size_t) = nullptr; void *ctx = nullptr; int active = 0; std::exception_ptr err; };
+struct PfJob { std::atomic<size_t> next{0}; size_t n = 0, chunk = 1; void (*run)(void*, size_t) = nullptr; void *ctx = nullptr; int active = 0; std::exception_ptr err; };
 struct PfPool {
 	std::mutex mu; std::condition_variable cv_work, cv_done; std::deque<PfJob*> tickets; std::vector<std::thread> th; bool stop = false;
-	void loop(PfJob *j) { try { for (;;) { const size_t i = j->next.fetch_add(1); if (i >= j->n) break; j->run(j->ctx, i); } } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!j->err) j->err = std::current_exception(); j->next.store(j->n); } }
+	void loop(PfJob *j) { try { for (;;) { const size_t i0 = j->next.fetch_add(j->chunk); if (i0 >= j->n) break; const size_t i1 = std::min(j->n, i0 + j->chunk); for (size_t i = i0; i < i1; ++i) j->run(j->ctx, i); } } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!j->err) j->err = std::current_exception(); j->next.store(j->n); } }
 	void worker() {
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;) {
@@ -755,10 +755,22 @@ struct PfPool {
 };
 PfPool &pf_pool() { static PfPool *p = new PfPool(); return *p; }       // (leaked on purpose: no destructor order games at exit)
 }
+// what a call leaves behind on the host (thousands of small heap blocks near the root of a build) is freed by a janitor thread, off the call's path
+template <class T> static void scrap_later(std::vector<T> &&v)
+{
+	struct Janitor {
+		std::mutex mu; std::condition_variable cv; std::deque<std::vector<T>> q; std::thread th;
+		Janitor() : th([this] { for (;;) { std::vector<T> v; { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty(); }); v = std::move(q.front()); q.pop_front(); } v.clear(); } }) { th.detach(); }
+	};
+	static Janitor *J = new Janitor();
+	{ std::lock_guard<std::mutex> lk(J->mu); J->q.push_back(std::move(v)); }
+	J->cv.notify_one();
+}
 template <class F> static void parallel_for(size_t n, int n_threads, F f)
 {
 	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) f(i); return; }
-	PfJob job; job.n = n; job.ctx = &f; job.run = [](void *c, size_t i) { (*static_cast<F*>(c))(i); };
+	// (items are taken a few at a time once there are thousands: one shared counter)
+	PfJob job; job.n = n; job.chunk = std::max<size_t>(1, n / 256); job.ctx = &f; job.run = [](void *c, size_t i) { (*static_cast<F*>(c))(i); };
 	const size_t helpers = std::min<size_t>((size_t)n_threads - 1, n - 1);
 	PfPool &P = pf_pool();
 	{
@@ -1082,9 +1094,9 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	for (int i = 0; i < n_seq; ++i) sets[(size_t)(i % n_sets)].push_back(order[(size_t)i]);
 	for (auto &v : sets) std::sort(v.begin(), v.end());
 	if (verbose) fprintf(stderr, "[pga]   align: %d set(s) dealt at +%.4f s\n", n_sets, wall_s() - t_align0);
-	// the contexts of a call hold a few small heap blocks per query and region (thousands of sequences per call near the root): they are
-	// taken apart by the worker threads, not one after the other at the closing brace
-	auto scrap = [&] { parallel_for(Q.size(), n_threads, [&](size_t i) { QueryCtx dead(std::move(Q[i])); }); };
+	// the contexts of a call hold a few small heap blocks per query and region (thousands of sequences per call near the root): a janitor
+	// thread takes them apart, not this call at its closing brace
+	auto scrap = [&] { scrap_later(std::move(Q)); };
 	if (n_sets == 1) { RoundRunner R{S, opt, D, Q, out, sets[0], 0, n_threads, st, tm, P, verbose, {}}; R.run(); scrap(); if (verbose) fprintf(stderr, "[pga]   align: rounds done at +%.4f s\n", wall_s() - t_align0); return; }
 	int dev = 0; PGA_HIP(hipGetDevice(&dev));
 	std::vector<Timers> tms((size_t)n_sets);
@@ -1108,6 +1120,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	for (auto &t : th) t.join();
 	if (verbose) fprintf(stderr, "[pga]   align: sets joined at +%.4f s\n", wall_s() - t_align0);
 	scrap();
+	if (verbose) fprintf(stderr, "[pga]   align: contexts taken apart at +%.4f s\n", wall_s() - t_align0);
 	for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
 	if (tm) for (const Timers &t : tms) {
 		tm->dp_jobs += t.dp_jobs; tm->dp_cells += t.dp_cells; tm->dp_bases += t.dp_bases; tm->dp_cigar_ops += t.dp_cigar_ops;

@@ -168,7 +168,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	for (int i = 0; i < n; ++i) {
 		ix->seq_hdr[i].name = name && name[i] ? const_cast<char*>(nm[i].c_str()) : nullptr;
 		ix->seq_hdr[i].offset = ix->S.off[i]; ix->seq_hdr[i].len = len[i]; ix->seq_hdr[i].is_alt = 0;
-		if (name && name[i] && n_grp == 1) ix->by_name[nm[i]] = i;
+		if (do_index && name && name[i] && n_grp == 1) ix->by_name[nm[i]] = i;     // (mm_map's lookup: a batch handle is never asked by name)
 	}
 	// rank of every name under strcmp order inside its group (skip_seed compares names as C strings, map.c:84,89)
 	std::vector<int32_t> rank((size_t)n);
@@ -229,6 +229,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	set_thread_budget(n_threads);
 	align_batch(ix.S, opt, ix.I.k, SR.h_q_aoff, CR, SR.h_rep_len, ix.results, n_threads, &ix.tm, ix.st);
 	double t3 = now_s();
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   align_batch returned after %.4f s\n", t3 - t2);
 	mem_log("after align");
 	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;
 	ix.have_results = true; ix.res_opt = opt;

@@ -546,7 +546,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// scratch budget per class: a slab is n_waves x the largest problem of the class, and n_waves is halved until it fits.  24 GB keeps
 	// ~100 concurrent 10 kb x 10 kb direction matrices; concurrent parts and query sets each hold a lane set, so four of them stay inside HBM
 	size_t budget = (size_t)(getenv("PGA_SLAB_GB") ? atof(getenv("PGA_SLAB_GB")) : 24.0) << 30;
-	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 8 < budget) budget = tot / 8; }
+	{ static const size_t dev_total = [] { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0; return tot; }();   // (once: the query is a driver call)
+	  if (dev_total && dev_total / 8 < budget) budget = dev_total / 8; }
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_begin = now();
