@@ -260,7 +260,12 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 			int need_hi = en > st0 + span - 1 ? en : st0 + span - 1;
 			if (need_hi > T - 1) need_hi = T - 1;
 			// a lane whose block fell out of the band on the left takes the block one ring further right (fresh rows)
-			if ((blk + NT) * C <= need_hi) { blk += NT; fresh(r - 1); const int j = r - blk * C; q_next = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u; }
+			// (a lane moves on once in NT * 8 diagonals: the whole block hides behind a scalar branch, so that the ~80 register moves of
+			// fresh() are not issued -- under an empty exec mask -- on every diagonal)
+			const bool moves_on = (blk + NT) * C <= need_hi;
+			if (__ballot(moves_on) != 0ULL) {
+				if (moves_on) { blk += NT; fresh(r - 1); const int j = r - blk * C; q_next = (j >= 0 && j < qlen) ? (uint32_t)qq[j] : 0u; }
+			}
 			const int t0 = blk * C;
 			LaneRec *recs = s_rec[r & 1];
 			// query byte of the block's first column (requested one diagonal ahead: its LDS latency hides behind the barrier)
