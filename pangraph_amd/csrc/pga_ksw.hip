@@ -561,7 +561,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
 		static const int c8w = getenv("PGA_C8_WAVES") ? atoi(getenv("PGA_C8_WAVES")) : 16;
-		size_t n_waves = c == 11 ? 256 * (size_t)(getenv("PGA_C11_WAVES") ? atoi(getenv("PGA_C11_WAVES")) : 8) : c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
+		size_t n_waves = c == 11 ? 256 * (size_t)(getenv("PGA_C11_WAVES") ? atoi(getenv("PGA_C11_WAVES")) : 10) : c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
 		if (c == 9) {                                                                   // every problem of the class is in flight at once, each with its whole matrix
