@@ -85,7 +85,9 @@ const uint32_t *pga_result_cigars(const pga_result_t *r, uint64_t *n_ops);
 const pga_stats_t *pga_result_stats(const pga_result_t *r);
 void pga_result_free(pga_result_t *r);
 const char *pga_last_error(void);
-/* number of visible HIP devices (<=0: none, the library cannot run) and selection of the one to use */
+/* number of visible HIP devices (<=0: none, the library cannot run) and selection of the one to use.  The selection holds for the PROCESS:
+ * HIP's current device belongs to the host thread, so every entry point of the library (mm_map included) applies the selected device to
+ * the thread it is called on -- worker threads of the host need not call pga_set_device themselves. */
 int pga_device_count(void);
 int pga_set_device(int dev);
 
