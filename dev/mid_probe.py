@@ -5,7 +5,7 @@ from pangraph_amd.levels import Population
 H = int(os.environ.get("H", "8"))
 pop = Population(20260928, 1000, 5_000_000)
 tasks = sched.build_tasks(pop)
-ts = [t for t in tasks if pop.nodes[t.node].height == H and t.round == 0]
+ts = [t for t in tasks if pop.nodes[t.node].height == H and t.round == 0][:int(os.environ.get("N", "100000"))]
 first, n = {}, 0
 for t in ts:
     t.prepare(); first[t.tid] = n; n += len(t.seqs)
