@@ -313,6 +313,8 @@ def main():
     for t in tasks:
         if owner[t.tid] in (rank, -1) or world == 1:
             t.prepare()
+    if os.environ.get("PGA_BENCH_WARM_STREAMS", "1") != "0":
+        batch.lib().pga_warm_streams(int(args.slots))
     slot_threads = int(os.environ.get("PGA_BENCH_SLOT_THREADS", max(2, n_threads // max(1, min(args.slots, 2)))))
     # inputs resident before the timed region: one batch handle holds the sequences of every call this rank can meet (0.375 B per base in
     # HBM); lib_first[tid] = index of the call's first sequence in it.  Only the ready-set schedule takes its inputs from there.

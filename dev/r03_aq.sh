@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+run() { name=$1; shift
+  env "$@" timeout 900 python bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-next-rows > gpurun_out/r03_aq_$name.json 2> gpurun_out/r03_aq_$name.err
+  python -c "import json; d=json.load(open('gpurun_out/r03_aq_$name.json')); print('$name', round(d['value'],3), round(d['ms_per_step']), {a: round(b,2) for a,b in d['stages_s'].items()})" || tail -5 gpurun_out/r03_aq_$name.err
+}
+run base1 X=1
+run flat1 PGA_LANE_FLAT_PRIO=1
+run hi1 PGA_LANE_FLAT_PRIO=2
+run base2 X=1
+run flat2 PGA_LANE_FLAT_PRIO=1
+run hi2 PGA_LANE_FLAT_PRIO=2

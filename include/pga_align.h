@@ -90,6 +90,8 @@ const char *pga_last_error(void);
  * the thread it is called on -- worker threads of the host need not call pga_set_device themselves. */
 int pga_device_count(void);
 int pga_set_device(int dev);
+/* optional: create n streams ahead of time for the batch handles a host keeps in flight at once (they land on different hardware queues) */
+int pga_warm_streams(int32_t n);
 
 /* Stage taps for parity tests (same semantics as the reference functions named in each comment). */
 /* mm_sketch (sketch.c:77): minimizers of n sequences; out arrays are malloc()ed, caller frees with pga_free */

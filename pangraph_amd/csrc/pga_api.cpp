@@ -620,6 +620,18 @@ extern "C" const char *pga_last_error(void) { return g_err.c_str(); }
 extern "C" int pga_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int pga_set_device(int dev) { if (hipSetDevice(dev) != hipSuccess) { set_err("hipSetDevice failed"); return -1; } g_default_dev.store(dev); return 0; }
 extern "C" void pga_free(void *p) { free(p); }
+// n streams are created now, one after the other, and left in the pool the batch handles take their streams from: the runtime spreads
+// streams over its hardware queues in creation order, so the n handles a host keeps in flight start on n different queues
+extern "C" int pga_warm_streams(int32_t n)
+{
+	try {
+		require_device();
+		std::vector<hipStream_t> v;
+		for (int i = 0; i < n; ++i) v.push_back(pga::stream_lease());
+		for (auto it = v.rbegin(); it != v.rend(); ++it) pga::stream_release(*it);
+		return 0;
+	} catch (std::exception &e) { set_err(e.what()); return -1; }
+}
 extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
 
 // ---- busy intervals (pga_common.h: busy_note) ----

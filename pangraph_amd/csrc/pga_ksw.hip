@@ -446,7 +446,16 @@ struct LaneLease {
 		set = new LaneSet(); set->dev = dev; set->arena = dev_lease_arena();
 		int prio_lo = 0, prio_hi = 0;
 		PGA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // numerically lower = higher priority
-		for (int l = 0; l < 4; ++l) PGA_HIP(hipStreamCreateWithPriority(&set->stream[l], hipStreamNonBlocking, l == 0 ? prio_lo : prio_hi));
+		// The runtime keeps one pool of hardware queues PER PRIORITY (GPU_MAX_HW_QUEUES each): lanes at the low and at the high priority do
+		// not share queues with one another nor with the batches' own (default-priority) streams.  Two lanes per pool, one of the two with the
+		// long kernels (lane 2: end extensions, inversion tests; lane 3: strips) in each: with six batches in flight 12 + 12 streams on 6 + 6
+		// queues (measured: lanes 1-3 all high 3.75-3.83 s per step, lanes {0,1} low / {2,3} high 3.60-3.64, {0,3} low / {1,2} high 3.49-3.61;
+		// every lane at the default priority 4.6 s).  PGA_LANE_PRIO=lhhh etc. for experiments (l low, h high, n default).
+		static const std::string pr = getenv("PGA_LANE_PRIO") && strlen(getenv("PGA_LANE_PRIO")) == 4 ? getenv("PGA_LANE_PRIO") : "lhhl";
+		for (int l = 0; l < 4; ++l) {
+			if (pr[(size_t)l] == 'n') PGA_HIP(hipStreamCreateWithFlags(&set->stream[l], hipStreamNonBlocking));
+			else PGA_HIP(hipStreamCreateWithPriority(&set->stream[l], hipStreamNonBlocking, pr[(size_t)l] == 'l' ? prio_lo : prio_hi));
+		}
 	}
 	~LaneLease()
 	{
@@ -622,7 +631,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
 		static const bool on_main = getenv("PGA_DP_ON_MAIN") != nullptr;    // experiment: every class on the call's own stream (one hardware queue per batch)
-		hipStream_t cs = on_main ? st : lane_stream[serial ? 0 : lane_of_class[c]];
+		static const bool three = getenv("PGA_DP_THREE_LANES") != nullptr;   // experiment: lane 3's classes (strips, class 3) share lane 1's stream
+		hipStream_t cs = on_main ? st : lane_stream[serial ? 0 : (three && lane_of_class[c] == 3) ? 1 : lane_of_class[c]];
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
 		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
@@ -685,7 +695,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
-		download_to(r, X.d_r.p, ids.size(), getenv("PGA_DP_ON_MAIN") ? st : lane_stream[getenv("PGA_DP_SERIAL") ? 0 : lane_of_class[c]]);
+		download_to(r, X.d_r.p, ids.size(), getenv("PGA_DP_ON_MAIN") ? st : lane_stream[getenv("PGA_DP_SERIAL") ? 0 : (getenv("PGA_DP_THREE_LANES") && lane_of_class[c] == 3) ? 1 : lane_of_class[c]]);
 		if (tm) {
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below.
 			// cells: what the kernel's loops evaluated -- the corridor kernel 32 columns on every diagonal, the register tiles the whole
