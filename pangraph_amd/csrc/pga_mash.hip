@@ -352,38 +352,36 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 		}
 		__syncthreads();
 		// Q and its first minimum in row-major order
-		double bq = INFINITY; unsigned long long bidx = ~0ULL;
-		double q2nd = INFINITY; unsigned long long i2nd = ~0ULL;
+		// (best, runner-up of another pair) <- (best, runner-up) + candidate (q, idx); by value: nothing here may end up addressable
+		struct Two { double b; unsigned long long bi; double s; unsigned long long si; };
+		auto same_pair = [](unsigned long long a, unsigned long long b) {
+			return a != ~0ULL && b != ~0ULL && (a == b || ((unsigned)(a >> 32) == (unsigned)b && (unsigned)a == (unsigned)(b >> 32)));
+		};
+		auto take = [&](Two t, double q, unsigned long long idx) -> Two {
+			if (idx == ~0ULL) return t;
+			if (q < t.b || (q == t.b && idx < t.bi)) { if (!same_pair(idx, t.bi)) { t.s = t.b; t.si = t.bi; } t.b = q; t.bi = idx; }
+			else if (q < t.s && !same_pair(idx, t.bi)) { t.s = q; t.si = idx; }
+			return t;
+		};
+		Two mine{INFINITY, ~0ULL, INFINITY, ~0ULL};
 		const double mm2 = (double)m - 2.0;
-		auto same_pair = [&](unsigned long long a, unsigned long long b) {
-			if (a == ~0ULL || b == ~0ULL) return false;
-			const unsigned ar = (unsigned)(a / (unsigned)m), ac = (unsigned)(a % (unsigned)m), br = (unsigned)(b / (unsigned)m), bc = (unsigned)(b % (unsigned)m);
-			return (ar == br && ac == bc) || (ar == bc && ac == br);
-		};
-		// (best, runner-up of another pair) <- (best, runner-up) + candidate (q, idx)
-		auto take = [&](double &b, unsigned long long &bi_, double &s2, unsigned long long &si, double q, unsigned long long idx) {
-			if (idx == ~0ULL) return;
-			if (q < b || (q == b && idx < bi_)) { if (!same_pair(idx, bi_)) { s2 = b; si = bi_; } b = q; bi_ = idx; }
-			else if (q < s2 && !same_pair(idx, bi_)) { s2 = q; si = idx; }
-		};
 		for (int r = tid; r < m; r += NJ_NT) {
 			const double *row = D + (size_t)alive[r] * n;
 			const double sr = s1[r];
 			for (int c = 0; c < m; ++c) {
 				if (c == r) continue;
 				const double q = (mm2 * row[alive[c]] - s0[c]) - sr;
-				const unsigned long long idx = (unsigned long long)r * (unsigned)m + (unsigned)c;
-				if (q < q2nd || q < bq || (q == bq && idx < bidx)) take(bq, bidx, q2nd, i2nd, q, idx);
+				if (q < mine.s) mine = take(mine, q, (unsigned long long)r << 32 | (unsigned)c);     // (mine.s >= mine.b: nothing above the runner-up matters; an equal best comes later in row-major order)
 			}
 		}
-		rq[tid] = bq; ri[tid] = bidx; rq2[tid] = q2nd; ri2[tid] = i2nd;
+		rq[tid] = mine.b; ri[tid] = mine.bi; rq2[tid] = mine.s; ri2[tid] = mine.si;
 		__syncthreads();
 		for (int sft = NJ_NT / 2; sft > 0; sft >>= 1) {
 			if (tid < sft) {
-				double b = rq[tid], s2 = rq2[tid]; unsigned long long bi_ = ri[tid], si = ri2[tid];
-				take(b, bi_, s2, si, rq[tid + sft], ri[tid + sft]);
-				take(b, bi_, s2, si, rq2[tid + sft], ri2[tid + sft]);
-				rq[tid] = b; ri[tid] = bi_; rq2[tid] = s2; ri2[tid] = si;
+				Two t{rq[tid], ri[tid], rq2[tid], ri2[tid]};
+				t = take(t, rq[tid + sft], ri[tid + sft]);
+				t = take(t, rq2[tid + sft], ri2[tid + sft]);
+				rq[tid] = t.b; ri[tid] = t.bi; rq2[tid] = t.s; ri2[tid] = t.si;
 			}
 			__syncthreads();
 		}
@@ -396,7 +394,7 @@ void k_nj(int n, double *__restrict__ D, int32_t *__restrict__ merges, int *__re
 			// so the last two joins of every tree rest on the rounding of the sums; see include/pga_align.h)
 			if (m > 4 && ri2[0] != ~0ULL && rq2[0] - rq[0] <= tol) { if (n_near == 0) first_near = t; ++n_near; }
 		}
-		int bi = (int)(best / (unsigned)m), bj = (int)(best % (unsigned)m);
+		int bi = (int)(best >> 32), bj = (int)(unsigned)best;
 		const int i = bi < bj ? bi : bj, j = bi < bj ? bj : bi;
 		const int pi = alive[i], pj = alive[j];
 		const double dij = D[(size_t)pi * n + pj];
