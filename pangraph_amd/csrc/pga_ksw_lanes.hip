@@ -394,7 +394,9 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				uint2 dd;
 				dd.x = __builtin_amdgcn_perm(dpk[1], dpk[0], 0x06040200u);
 				dd.y = __builtin_amdgcn_perm(dpk[3], dpk[2], 0x06040200u);
-				*reinterpret_cast<uint2*>(prow + (t0 - st)) = dd;
+				// (streamed past the caches: 70 GB of direction bytes per build are written and only the few on a path ever read back -- kept out
+				// of L2 they do not push out what the latency-bound kernels of the other batches in flight live on)
+				__builtin_nontemporal_store(((unsigned long long)dd.y << 32) | dd.x, reinterpret_cast<unsigned long long*>(prow + (t0 - st)));
 			}
 			prow += n_col;
 			// ---- H (exact mode): H[t] += v[t] over [st0, en0), H[en0] = H[en0-1](old) + u[en0] (ksw2_extd2_sse.c:325-340), and the
