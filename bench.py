@@ -258,6 +258,8 @@ def main():
     single = os.environ.get("PGA_BENCH_SINGLE_DEVICE") == "1"
     if single:
         local = 0
+        os.environ.setdefault("PGA_MEM_SHARE", str(1.0 / world))      # the ranks share one device's memory: each caches and reserves its part only
+        args.slots = max(1, args.slots // world)
     if local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, the node exposes {torch.cuda.device_count()} (one rank per GPU; PGA_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 for debugging)")
     torch.cuda.set_device(local)

@@ -556,7 +556,9 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// ~100 concurrent 10 kb x 10 kb direction matrices; concurrent parts and query sets each hold a lane set, so four of them stay inside HBM
 	size_t budget = (size_t)(getenv("PGA_SLAB_GB") ? atof(getenv("PGA_SLAB_GB")) : 24.0) << 30;
 	{ static const size_t dev_total = [] { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0; return tot; }();   // (once: the query is a driver call)
-	  if (dev_total && dev_total / 8 < budget) budget = dev_total / 8; }
+	  if (dev_total && dev_total / 8 < budget) budget = dev_total / 8;
+	  static const double share = [] { const char *e = getenv("PGA_MEM_SHARE"); const double v = e ? atof(e) : 1.0; return v > 0.0 && v <= 1.0 ? v : 1.0; }();
+	  budget = (size_t)((double)budget * share); }
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_begin = now();

@@ -43,7 +43,10 @@ size_t cache_limit()                               // (called with g_mu held)
 {
 	static size_t cap = [] { const char *e = getenv("PGA_CACHE_GB"); double g = e ? atof(e) : 200.0; return (size_t)(g * (double)(1ull << 30)); }();
 	static size_t dev_total = [] { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = (size_t)256 << 30; return tot; }();
-	const size_t room = dev_total / 100 * 85;
+	// PGA_MEM_SHARE: the part of the device this process may fill (several processes on one device, e.g. the single-device debugging mode of
+	// bench.py: each keeps a cache of its own, and the runtime aborts a queue when nothing is left for its own needs)
+	static const double share = [] { const char *e = getenv("PGA_MEM_SHARE"); const double v = e ? atof(e) : 1.0; return v > 0.0 && v <= 1.0 ? v : 1.0; }();
+	const size_t room = (size_t)((double)(dev_total / 100 * 85) * share);
 	const size_t lim = room > g_live_total ? room - g_live_total : 0;
 	return lim < cap ? lim : cap;
 }
