@@ -163,7 +163,11 @@ hipStream_t stream_lease()
 		if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
 	}
 	hipStream_t s = nullptr;
-	PGA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	static const char *prio = getenv("PGA_MAIN_PRIO");                 // experiment: h / l = the batches' own streams on the high / low priority queue pool
+	if (prio && (prio[0] == 'h' || prio[0] == 'l')) {
+		int lo = 0, hi = 0; PGA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+		PGA_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio[0] == 'h' ? hi : lo));
+	} else PGA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 	return s;
 }
 void stream_release(hipStream_t s)

@@ -233,3 +233,28 @@ def test_calls_take_their_inputs_from_a_resident_library(gpu_lib):
         host.close(); dev.close()
     assert total > 20
     lib.close()
+
+
+@pytest.mark.gpu
+def test_busy_interval_log_and_stream_pool(gpu_lib):
+    """Measurement helpers of include/pga_align.h: between pga_busy_begin and pga_busy_end every event-bracketed launch leaves its interval;
+    the union per kernel family cannot exceed the union over all families, nor the sum of the family's device times.  pga_warm_streams
+    fills the pool the batch handles lease their streams from."""
+    from pangraph_amd import batch
+    assert batch.lib().pga_warm_streams(3) == 0
+    pop = Population(7, 4, 40_000)
+    waves = pop.build_waves()
+    _, groups, names = waves[0]
+    pb = batch.PreparedBatch(groups, names)
+    batch.busy_begin()
+    rb = batch.ResidentBatch(pb)
+    res = rb.align(sensitivity=10, want_raw=True)
+    st = res.stats
+    busy = batch.busy_end()
+    assert busy["intervals"] > 5 and busy["any"] > 0.0
+    for i, name in enumerate(batch.KERNELS):
+        if name in busy:
+            assert busy[name] <= busy["any"] * 1.001 + 1e-3
+            assert busy[name] <= st["kern_ms"][i] * 1.001 + 1e-3, name      # one batch, launches of a family do not overlap themselves much
+    res.close(); rb.close()
+    assert batch.busy_end()["intervals"] == 0                             # closed: nothing is logged any more
