@@ -741,6 +741,11 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 				sq += j.qlen, stl += j.tlen, sw += j.w, zd += r[i].zdropped != 0, mt += r[i].max_t + r[i].max_q, ext += (j.flag & 0x40) != 0, big += need[ids[i]] > (8u << 20);
 				dg += r[i].pad;
 			}
+			{
+				// what the launch waits for is its longest problem: the tail of the diagonal counts
+				int mx = 0; size_t n4k = 0, n10k = 0; for (size_t i = 0; i < ids.size(); ++i) { mx = std::max(mx, (int)r[i].pad); n4k += r[i].pad > 4000; n10k += r[i].pad > 10000; }
+				fprintf(stderr, "[pga]       class %d: longest problem %d diagonals; %zu above 4 k, %zu above 10 k\n", c, mx, n4k, n10k);
+			}
 			const double m = (double)ids.size();
 			fprintf(stderr, "[pga]       class %d: mean qlen %.0f tlen %.0f w %.0f; extension-only %.0f%%, z-dropped %.0f%%, mean max_q+max_t %.0f, ~diagonals %.0f, slab > 8 MB: %.0f\n", c, sq / m, stl / m, sw / m,
 			        100 * ext / m, 100 * zd / m, mt / m, dg / m, big);
