@@ -550,6 +550,7 @@ static int batch_align_impl(pga_batch_t *B, const pga_params_t *params, int shar
 		int threads_each = params->n_threads > 0 ? params->n_threads : usable_cpus();
 		threads_each = std::max(1, threads_each / std::max(1, std::min(n_parts, 3)));
 		std::vector<std::string> errs((size_t)n_parts);
+		require_device();                                    // a fresh host thread sits on device 0: every entry point applies pga_set_device()'s device
 		int dev = 0; PGA_HIP(hipGetDevice(&dev));
 		auto work = [&](int p) {
 			try {
@@ -637,11 +638,11 @@ extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
 // ---- busy intervals (pga_common.h: busy_note) ----
 static_assert(pga::K_COUNT == PGA_N_KERNELS, "pga_stats_t and the busy log number the kernel families alike");
 namespace pga {
-struct BusyLog { std::mutex mu; bool open = false; hipEvent_t ref = nullptr; int dev = -1; std::vector<std::array<float, 3>> iv; };   // (kernel, start ms, end ms) since `ref`
+struct BusyLog { std::mutex mu; std::atomic<bool> open{false}; hipEvent_t ref = nullptr; int dev = -1; std::vector<std::array<float, 3>> iv; };   // (kernel, start ms, end ms) since `ref`
 static BusyLog g_busy;
 void busy_note(int kern, hipEvent_t a, hipEvent_t b)
 {
-	if (!g_busy.open) return;                                       // (racy read: an interval next to begin / end may be missed, none is corrupted)
+	if (!g_busy.open.load(std::memory_order_acquire)) return;      // (an interval next to begin / end may be missed, none is corrupted)
 	float t0 = 0, t1 = 0;
 	std::lock_guard<std::mutex> lk(g_busy.mu);
 	if (!g_busy.open || !g_busy.ref) return;
@@ -651,6 +652,7 @@ void busy_note(int kern, hipEvent_t a, hipEvent_t b)
 }
 extern "C" int pga_busy_begin(void)
 {
+	apply_default_device();
 	std::lock_guard<std::mutex> lk(pga::g_busy.mu);
 	if (pga::g_busy.ref) { (void)hipEventDestroy(pga::g_busy.ref); pga::g_busy.ref = nullptr; }
 	if (hipEventCreate(&pga::g_busy.ref) != hipSuccess || hipEventRecord(pga::g_busy.ref, nullptr) != hipSuccess || hipEventSynchronize(pga::g_busy.ref) != hipSuccess) { set_err("pga_busy_begin: no reference event"); return -1; }

@@ -20,6 +20,7 @@
 //     LDS only (direction bytes are fire-and-forget 8-byte stores, fenced before the backtrack).
 // Reference semantics, 16-lane rounding of the ranges, stale score bytes beyond the profile span and the traceback are the
 // ones of pga_ksw_wide.hip (see there and pga_ksw.hip); the parity suites of tests/test_gpu_parity.py run both.
+#include <mutex>
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_wave.h"
@@ -608,8 +609,12 @@ size_t lanes_chunk_bytes(int nt) { return lanes_chunk_of(nt); }
 template <int NT> static void launch_lanes_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab,
                                               size_t cig_bytes, uint32_t n_chunks, int q_cap, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
 {
-	static bool attr_set = false;
-	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_lanes<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
+	{	// a per-DEVICE function attribute, set once per device whatever thread comes first
+		static std::mutex mu; static bool attr_set[64] = {};
+		int dev = 0; PGA_HIP(hipGetDevice(&dev));
+		std::lock_guard<std::mutex> lk(mu);
+		if (!attr_set[dev & 63]) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_lanes<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set[dev & 63] = true; }
+	}
 	hipLaunchKernelGGL(k_extd2_lanes<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, bases, P, counter, slab, cig_bytes, n_chunks, q_cap, res, pool, cursor, pool_cap);
 }
 

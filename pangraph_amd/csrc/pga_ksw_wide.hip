@@ -15,6 +15,7 @@
 //   * 3 workgroup barriers per diagonal (5 in exact-max mode); the exact maximum with the reference's tie order
 //     is a wave reduction + 4 LDS partials;
 //   * wave 0 walks the direction matrix back through a 64x64 LDS window (fences only, as in the fast kernel).
+#include <mutex>
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_wave.h"
@@ -502,8 +503,12 @@ size_t wide_lds_bytes(int r_cap, int seq_cap, bool exact) { return (size_t)r_cap
 template <int NT> static void launch_wide_nt(unsigned n_blocks, size_t lds, hipStream_t st, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab,
                                              size_t slab_bytes, int r_cap, int seq_cap, int exact, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap)
 {
-	static bool attr_set = false;
-	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_MAX)); attr_set = true; }
+	{	// a per-DEVICE function attribute, set once per device whatever thread comes first
+		static std::mutex mu; static bool attr_set[64] = {};
+		int dev = 0; PGA_HIP(hipGetDevice(&dev));
+		std::lock_guard<std::mutex> lk(mu);
+		if (!attr_set[dev & 63]) { PGA_HIP(hipFuncSetAttribute((const void*)k_extd2_wide<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_MAX)); attr_set[dev & 63] = true; }
+	}
 	hipLaunchKernelGGL(k_extd2_wide<NT>, dim3(n_blocks), dim3(NT), lds, st, jobs, n_jobs, bases, P, counter, slab, slab_bytes, r_cap, seq_cap, exact, res, pool, cursor, pool_cap);
 }
 

@@ -17,6 +17,7 @@
 // replaces read five int16 values per cell from LDS and took 2.3 us per diagonal of a 10 kb x 10 kb problem; this one 1.0 us per
 // column step).  Scores are int32 here; they never leave the int16 range for the sizes accepted (the launcher checks
 // a * qlen < 32000), so the reference's saturating arithmetic is the plain one.
+#include <mutex>
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_wave.h"
@@ -139,8 +140,12 @@ size_t ll_lds_bytes(int t_cap) { return (size_t)t_cap + 64; }
 void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter,
                    unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st)
 {
-	static bool attr_set = false;
-	if (!attr_set) { PGA_HIP(hipFuncSetAttribute((const void*)k_ll_i16, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
+	{	// a per-DEVICE function attribute, set once per device whatever thread comes first
+		static std::mutex mu; static bool attr_set[64] = {};
+		int dev = 0; PGA_HIP(hipGetDevice(&dev));
+		std::lock_guard<std::mutex> lk(mu);
+		if (!attr_set[dev & 63]) { PGA_HIP(hipFuncSetAttribute((const void*)k_ll_i16, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set[dev & 63] = true; }
+	}
 	hipLaunchKernelGGL(k_ll_i16, dim3(n_blocks), dim3(LL_NT), ll_lds_bytes(t_cap), st, jobs, n_jobs, bases, P, counter, rowkey, rowkey_stride, t_cap, res);
 }
 

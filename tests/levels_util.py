@@ -11,8 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmm2ref.so")
 
 
-def digest(rows) -> str:
-    return hashlib.sha256(json.dumps(rows, separators=(",", ":")).encode()).hexdigest()
+from pangraph_amd.digest import digest  # noqa: E402,F401
 
 
 def _as_str(s):
@@ -97,16 +96,4 @@ def high_occ_groups(seed=5):
     return [[a.tobytes().decode() for a in g] for g in groups], names
 
 
-def records_to_lists(rec, pool, names):
-    """packed pga_match_t records (pangraph_amd.dist.MATCH_DTYPE) + CIGAR pool of a whole wave -> per group, the plain lists of
-    util.rows_to_lists (the 17 observable fields in the reference's order), so that gathered match lists can be digested like PafRows"""
-    ops = "MIDNSHP=XB"
-    out = [[] for _ in names]
-    for r in rec:
-        g = int(r["group"])
-        o, n = int(r["cigar_off"]), int(r["n_cigar"])
-        cg = "".join(f"{int(c) >> 4}{ops[int(c) & 0xf]}" for c in pool[o:o + n])
-        out[g].append([names[g][int(r["qry"])], int(r["qry_len"]), int(r["qry_start"]), int(r["qry_end"]), "-" if r["reverse"] else "+",
-                       names[g][int(r["ref"])], int(r["ref_len"]), int(r["ref_start"]), int(r["ref_end"]), int(r["matches"]), int(r["length"]),
-                       int(r["quality"]), int(r["align"]), repr(float(r["divergence"])), cg, int(r["n_ambi"]), int(r["inv"])])
-    return out
+from pangraph_amd.digest import records_to_lists  # noqa: E402,F401  (moved: bench.py digests the step it timed with the same code)

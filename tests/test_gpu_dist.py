@@ -237,3 +237,23 @@ def test_bench_two_ranks_on_one_device_gathers_every_match():
     a = json.loads(one.stdout.strip().splitlines()[-1]); b = json.loads(two.stdout.strip().splitlines()[-1])
     assert a["n_matches_gathered"] == b["n_matches_gathered"] > 50
     assert b["n_gpus"] == 2 and abs(a["config"]["genomes"] - b["config"]["genomes"]) == 0
+
+
+def test_bench_c5_two_ranks_on_one_device_every_call_vs_reference_digests():
+    """bench.py's own multi-rank path at the BASELINE configuration: two ranks (gloo) on GPU 0 -- subtrees per rank under the ready-set schedule,
+    one gather, the merges above the cut by both ranks together (queries split, pga_batch_align_shard), one more gather -- and bench.py digests
+    the gathered list of the step it timed: all 1998 calls against the compiled reference's digests, or it prints no value (exit 3)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGA_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--no-next-rows",
+           "--detail", os.path.join(root, "gpurun_out", "bench_detail_2ranks.json")]
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    two = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-2000:])
+    line = two.stdout.strip().splitlines()[-1]
+    assert len(line) < 4096
+    b = json.loads(line)
+    assert b["n_gpus"] == 2 and b["parity_checked_calls"] == 1998 and b["n_matches_gathered"] == 104928, b

@@ -258,3 +258,61 @@ def test_busy_interval_log_and_stream_pool(gpu_lib):
             assert busy[name] <= st["kern_ms"][i] * 1.001 + 1e-3, name      # one batch, launches of a family do not overlap themselves much
     res.close(); rb.close()
     assert batch.busy_end()["intervals"] == 0                             # closed: nothing is logged any more
+
+
+def _run_build_ready_set(pop, tasks, slots, resident):
+    """the benchmark's execution mode (bench.py:step_ready): the find_matches calls of the build under the ready-set schedule, `slots` batches in
+    flight from `slots` host threads, inputs handed over as host strings (pga_batch_create) or derived from a resident library (pga_batch_derive)"""
+    from pangraph_amd import batch
+    from pangraph_amd import schedule as sched
+    from pangraph_amd.dist import MATCH_DTYPE
+    lib, first = None, None
+    if resident:
+        first, n = {}, 0
+        for t in tasks:
+            first[t.tid] = n
+            n += len(t.seqs)
+        lib = batch.ResidentBatch(sched.TaskBatch(tasks))
+    results, lock = [], threading.Lock()
+
+    def run_batch(ts):
+        batch.set_device(0)
+        rb = batch.ResidentBatch(sched.TaskBatch(ts, first), derive_from=lib)
+        res = rb.align(sensitivity=10, want_raw=True, n_threads=8)
+        rb.close()
+        return res
+
+    def on_result(ts, res, t0, t1):
+        m = np.array(res.raw_matches, copy=True).view(MATCH_DTYPE)
+        cg = np.array(res.raw_cigars, copy=True).view(np.uint32)
+        res.close()
+        with lock:
+            results.append((ts, m, cg, None))
+
+    log = sched.run_ready_set(tasks, run_batch, slots=slots, cap_bases=1.2e9, on_result=on_result)
+    if lib is not None:
+        lib.close()
+    return results, log
+
+
+@pytest.mark.parametrize("resident", [False, True], ids=["inputs_host", "inputs_resident"])
+def test_c5_ready_set_six_slots_every_call_vs_reference_digests(gpu_lib, resident):
+    """The execution mode bench.py times -- NOT level-synchronous waves: the 1998 find_matches calls of the BASELINE build (config C5) in
+    dependency order (graph_merging.rs:26-69, build_run.rs:111-128: round 0 of a merge needs the last round of both children, round r needs
+    round r - 1), SIX batches in flight from six host threads (own stream, own arena, shared DP lane pools), inputs as host strings and, second
+    run, device-to-device out of a resident library.  Every call against the digest the compiled reference produced for it."""
+    from pangraph_amd import batch
+    from pangraph_amd import digest as dg
+    from pangraph_amd import schedule as sched
+    gold = load_golden("builds_expected.json.gz")["c5"]
+    p = gold["params"]
+    pop = Population(p["seed"], p["n"], p["length"])
+    tasks = sched.build_tasks(pop)
+    assert len(tasks) == 1998
+    want = dg.expected_by_call(pop, gold)
+    batch.lib().pga_warm_streams(6)
+    results, log = _run_build_ready_set(pop, tasks, 6, resident)
+    assert max(sum(1 for a, b, _, _ in log if a <= t < b) for t, _, _, _ in log) >= 4          # batches really were in flight together
+    n, bad = dg.check_calls(results, want)
+    assert n == 1998 and not bad, (n, bad[:10], len(bad))
+    assert sum(len(m) for _, m, _, _ in results) == sum(x["n"] for w in gold["waves"] for x in w["groups"])
