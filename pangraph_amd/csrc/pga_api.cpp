@@ -215,14 +215,14 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	SeedResult SR;
 	{
 		EventTimer et(ix.st);
-		seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm, ix.sharded ? ix.d_own.p : nullptr);
+		seed_all(ix.S, ix.M, ix.I, ix.grp, opt, ix.d_name_rank, ix.d_mid_occ, SR, ix.st, &ix.tm, ix.sharded ? ix.d_own.p : nullptr, exact_sorts_forced());
 		KernelStat &ks = ix.tm.kern[K_SEED];         // query minimizers probe the table, anchors written, read and written by the sort
 		ks.ms += et.stop(K_SEED); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
 	}
 	double t1 = now_s();
 	mem_log("after seed");
 	ChainResult CR;
-	chain_all(ix.S, SR.a, SR.q_aoff, SR.n_a, opt, ix.I.k, CR, ix.st, &ix.tm);
+	chain_all(ix.S, SR, opt, ix.I.k, CR, ix.st, &ix.tm, exact_sorts_forced());
 	double t2 = now_s();
 	mem_log("after chain");
 	if (n_threads <= 0) { n_threads = usable_cpus(); }
@@ -708,12 +708,15 @@ extern "C" int pga_stage_chain(const pga_params_t *params, int32_t n, const char
 		*mid_occ = mo.mid_occ;
 		check_supported(mo, io.k, io.w);
 		ix->d_mid_occ.upload(group_mid_occ(*ix, mo), ix->st);
-		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, ix->d_mid_occ, SR, ix->st);
+		// the tap shows the reference's anchor order (PGA_STAGE_SPECULATIVE=1: the anchors in stable order and the chains by the tie-order-independent
+		// route of chain_all, as a batch computes them)
+		const bool spec_tap = getenv("PGA_STAGE_SPECULATIVE") != nullptr;
+		SeedResult SR; seed_all(ix->S, ix->M, ix->I, ix->grp, mo, ix->d_name_rank, ix->d_mid_occ, SR, ix->st, nullptr, nullptr, !spec_tap);
 		std::vector<u128> a = SR.a.download(ix->st); a.resize(SR.n_a);
 		std::vector<uint64_t> flat(a.size() * 2);
 		for (size_t i = 0; i < a.size(); ++i) flat[2 * i] = a[i].x, flat[2 * i + 1] = a[i].y;
 		*anchors_xy = dup_out(flat); *anchor_off = dup_out(SR.h_q_aoff); *rep_len = dup_out(SR.h_rep_len);
-		ChainResult CR; chain_all(ix->S, SR.a, SR.q_aoff, SR.n_a, mo, io.k, CR, ix->st);
+		ChainResult CR; chain_all(ix->S, SR, mo, io.k, CR, ix->st, nullptr, !spec_tap);
 		*n_u = dup_out(CR.n_u); *n_v = dup_out(CR.n_v);
 		std::vector<uint64_t> uu(CR.u.begin(), CR.u.end()); uu.resize(SR.n_a);
 		*u = dup_out(uu);

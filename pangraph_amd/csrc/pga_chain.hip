@@ -856,14 +856,21 @@ __global__ __launch_bounds__(64)
 void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__restrict__ a, const int32_t *__restrict__ f_all,
                const int32_t *__restrict__ p_all, int32_t *__restrict__ t_all, int32_t *__restrict__ v_all, const u128 *__restrict__ z_all, const int64_t *__restrict__ n_z_in,
                uint64_t *__restrict__ u_all, u128 *__restrict__ w_all, uint64_t *__restrict__ u2_all, u128 *__restrict__ out_all,
-               ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out, unsigned long long *__restrict__ prof)
+               ChainParams P, int32_t *__restrict__ n_u_out, int32_t *__restrict__ n_v_out, unsigned long long *__restrict__ prof, uint32_t *__restrict__ ev_out)
 {
 	const int q = blockIdx.x, lane = threadIdx.x;
 	if (q >= n_seq) return;
 	const uint64_t b = q_aoff[q];
 	const int64_t n = (int64_t)(q_aoff[q + 1] - b);
 	const int64_t n_z = n_z_in[q];
+	if (ev_out && lane == 0) ev_out[q] = 0;
 	if (n == 0 || n_z == 0) return;
+	// ORDER EVENTS: the places where the order of candidates with EQUAL scores can change the result (see chain_all).  A mark carries the score of
+	// the candidate whose chain set it; bit 0: a walk stopped at a mark of its own score, bit 1: a candidate was found marked by a chain of its own
+	// score, bit 2: two chains start at the same target position (equal keys in compact_a's sort), bit 3: two chains were emitted by candidates of equal
+	// score (the order in which compact_a's sort receives the chains is then the candidate sort's tie order), bit 4: bits 2 and 3 together in a way that
+	// shows in the sorted chain list.
+	uint32_t ev = 0; int32_t last_emit = -1;
 	const unsigned long long c0 = wall_clock64(), c1 = c0;
 	const u128 *A = a + b; const int32_t *f = f_all + b, *p = p_all + b;
 	int32_t *t = t_all + b, *v = v_all + b;
@@ -887,9 +894,12 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 		if (zi1 >= 0) tm1 = t[zi1];                                  // (early: re-read below whenever it says "unmarked")
 		load_z(kb - 128, zf2, zi2);
 		unsigned long long todo = __ballot(zi >= 0 && tm == 0);
+		if (__ballot(zi >= 0 && tm != 0 && tm == zf)) ev |= 2;
 		while (todo) {
 			// marks of the remaining candidates as of now (the previous chain may have covered some of them)
-			const bool open = zi >= 0 && ((todo >> lane) & 1) && t[zi] == 0;
+			const int32_t tnow = zi >= 0 && ((todo >> lane) & 1) ? t[zi] : 0;
+			const bool open = zi >= 0 && ((todo >> lane) & 1) && tnow == 0;
+			if (__ballot(tnow != 0 && tnow == zf)) ev |= 2;
 			todo = __ballot(open);
 			if (!todo) break;
 			const int src = __ffsll((long long)todo) - 1;
@@ -937,15 +947,15 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 				}
 				if (sv > max_s) max_s = sv, kept = m;
 				else if (max_s - sv > max_drop) break;
-				if (nxt < 0 || tn != 0) break;
+				if (nxt < 0 || tn != 0) { if (nxt >= 0 && tn == zx) ev |= 1; break; }
 				cur = nxt;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");              // the path was stored by whichever lanes held it
 			// kept part: the first `kept` path elements (the walk stops before max_i, lchain.c:72); marks stay even if the chain is dropped
-			for (int32_t c = lane; c < kept; c += 64) t[v[n_v0 + c]] = 1;
+			for (int32_t c = lane; c < kept; c += 64) t[v[n_v0 + c]] = zx;          // (nonzero: min_sc > 0) the claimant's score
 			// score of the chain: z.x - f[max_i]; max_i is the path element number `kept` (or -1 past the root)
 			const int32_t sc = max_s;
-			if (kept > 0 && sc >= P.min_sc && kept >= P.min_cnt) { if (lane == 0) u[n_u] = (uint64_t)sc << 32 | (uint64_t)kept; ++n_u; n_v += kept; }
+			if (kept > 0 && sc >= P.min_sc && kept >= P.min_cnt) { if (lane == 0) u[n_u] = (uint64_t)sc << 32 | (uint64_t)kept, u2[n_u] = (uint64_t)zx; ++n_u; n_v += kept; if (zx == last_emit) ev |= 8; last_emit = zx; }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		}
 	}
@@ -957,6 +967,10 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 		int64_t kk = 0;
 		for (int32_t i = 0; i < n_u; ++i) { const int32_t ni = (int32_t)u[i]; w[i].x = A[v[kk + ni - 1]].x; w[i].y = (uint64_t)kk << 32 | (uint64_t)i; kk += ni; }
 		if (n_u > 0) { uint32_t h2[256], t2[256]; radix_sort_128x_exact(w, w + n_u, h2, t2); }
+		// equal keys: up to 64 chains the reference's sort is an insertion sort (ksort.h:107-117, 140), i.e. stable -- two chains of equal key stand in
+		// emission order, which is the descending order of their candidates' scores unless those are equal too (u2 still holds them)
+		for (int32_t i = 1; i < n_u; ++i) if (w[i].x == w[i - 1].x) { ev |= 4; if (u2[(int32_t)w[i].y] == u2[(int32_t)w[i - 1].y]) ev |= 16; }
+		if (n_u > 64 && (ev & 4) && (ev & 8)) ev |= 16;                        // a cycle-leader pass: any two chains emitted in tie order can move the equal keys
 		// output offsets of the chains in their final order, stashed in w.x next to the chain word
 		kk = 0;
 		for (int32_t i = 0; i < n_u; ++i) { const int32_t j = (int32_t)w[i].y; u2[i] = u[j]; w[i].x = (uint64_t)kk; kk += (int32_t)u[j]; }
@@ -969,6 +983,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	for (int32_t c = lane; c < n_u; c += 64) u[c] = u2[c];
+	if (ev_out && lane == 0) ev_out[q] = ev;
 	if (prof && lane == 0) {
 		const unsigned long long c3 = wall_clock64();
 		atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2);
@@ -1008,7 +1023,7 @@ __global__ void k_z_take_sorted(u128 *__restrict__ z, const uint64_t *__restrict
 	if (i >= n) return;
 	int lo = 0, hi = n_seq;
 	while (lo < hi) { int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= i) lo = m + 1; else hi = m; }
-	if (q_tie[lo] || (int64_t)(i - q_aoff[lo]) >= n_z[lo]) return;
+	if ((q_tie && q_tie[lo]) || (int64_t)(i - q_aoff[lo]) >= n_z[lo]) return;
 	u128 v; v.x = sx[i]; v.y = sy[i]; z[i] = v;
 }
 
@@ -1020,9 +1035,42 @@ __global__ void k_gather_chains(const uint64_t *__restrict__ u, const uint64_t *
 	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = u[b + i];
 }
 
-void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm)
+// ---- which queries need the reference's tie order (speculative mode of chain_core) ----
+__global__ void k_seg_query_flag(const uint32_t *__restrict__ seg_flag, const uint64_t *__restrict__ seg_start, uint32_t n_seg, const uint64_t *__restrict__ q_aoff, int n_seq, uint32_t *__restrict__ out)
 {
-	const int n_seq = S.n_seq;
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_seg || !seg_flag[s]) return;
+	const uint64_t i = seg_start[s];
+	int lo = 0, hi = n_seq;
+	while (lo < hi) { int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= i) lo = m + 1; else hi = m; }
+	out[lo] = 1;
+}
+__global__ void k_need_exact(int n_seq, const uint32_t *__restrict__ q_tie_x, const uint32_t *__restrict__ q_tie_f, const uint32_t *__restrict__ ev, const uint32_t *__restrict__ seg_q, uint32_t *__restrict__ need)
+{
+	const int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_seq) return;
+	const uint32_t e = ev[q];
+	const bool order_f = q_tie_f[q] && (e & (1u | 2u | 16u));                      // equal scores whose order shows
+	const bool order_x = q_tie_x && q_tie_x[q] && seg_q && seg_q[q];               // equal anchor keys under the tree re-enactment (its shape is the insertion order)
+	need[q] = order_f || order_x ? 1u : 0u;
+}
+__global__ void k_gather_queries(int n_sub, const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ dst_off, const u128 *__restrict__ a, u128 *__restrict__ out)
+{
+	const int q = blockIdx.x;
+	if (q >= n_sub) return;
+	const uint64_t s = src_off[q], d = dst_off[q], n = dst_off[q + 1] - d;
+	for (uint64_t i = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.y * blockDim.x) out[d + i] = a[s + i];
+}
+
+// One pass of the stage over the anchors a[0..n_a) of n_seq queries.
+//   spec == false  the reference's procedure: the candidate ends of every query go through the replay of the unstable sort (lchain.c:52) where they hold
+//                  equal scores; `a` must be in the reference's order.
+//   spec == true   `a` may hold equal keys in stable order and the candidates are taken in STABLE order of their scores.  That is the reference's result
+//                  whenever no ORDER EVENT shows (k_bt_walk) -- proof in chain_all -- and need_out[q] says for which queries one did.
+static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const int n_seq, uint64_t n_a, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm,
+                       bool spec, const uint32_t *d_q_tie_x, std::vector<uint32_t> *need_out)
+{
+	if (need_out) need_out->assign((size_t)n_seq, 0u);
 	O.n_u.assign((size_t)n_seq, 0); O.n_v.assign((size_t)n_seq, 0); O.u.clear(); O.a.clear();
 	if (n_a == 0) return;
 	if (n_a >= (1ULL << 31)) throw std::runtime_error("pga: more than 2^31 anchors in one batch");
@@ -1075,11 +1123,13 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	}
 	mark("segments");
 	DBuf<CNode> nd_main, nd_inner;                        // the tree re-enactment's nodes (64 B per anchor): only when a segment needs it
+	DBuf<uint32_t> seg_q;                                 // queries with a segment the fast kernel handed to the tree re-enactment
 	DBuf<int32_t> f(n_a), pp(n_a), t(n_a), v(n_a);
 	t.zero(st);
 	mark("buffers");
 	{
 		DBuf<uint32_t> seg_flag(n_seg);
+		seg_q.alloc((size_t)n_seq); seg_q.zero(st);
 		EventTimer et(st);
 		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
 		DBuf<unsigned long long> cprof(16); cprof.zero(st);
@@ -1102,6 +1152,7 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 			any_flagged = n_fl.download(st)[0] != 0;
 		}
 		if (any_flagged) {
+			if (use_fast) hipLaunchKernelGGL(k_seg_query_flag, dim3((n_seg + 255) / 256), dim3(256), 0, st, seg_flag.p, seg_start.p, n_seg, q_aoff.p, n_seq, seg_q.p);
 			nd_main.alloc(n_a); nd_inner.alloc(n_a);
 			hipLaunchKernelGGL(k_chain_segments, dim3((n_seg + 63) / 64), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq,
 			                   use_fast ? seg_flag.p : (const uint32_t*)nullptr, P, nd_main.p, nd_inner.p, f.p, pp.p, t.p);
@@ -1129,16 +1180,18 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 		EventTimer et(st);
 		DBuf<unsigned long long> prof(12); prof.zero(st);
 		DBuf<int64_t> n_z((size_t)n_seq);
+		DBuf<uint32_t> ev((size_t)n_seq), q_tie_f;
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 		hipLaunchKernelGGL(k_bt_list, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, f.p, t.p, z.p, P, n_z.p, n_u.p, n_v.p);
 		double ms_list = 0, ms_sort = 0;
 		ms_list = et.stop(K_BACKTRACK);
 		EventTimer et2(st);
 		static const bool z_hint = getenv("PGA_NO_Z_HINT") == nullptr;
-		if (!z_hint) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st, tm);
+		if (!z_hint && !spec) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st, tm);
 		else {
 			DBuf<uint64_t> key0(n_a), key1(n_a), sx(n_a), sy(n_a);
-			DBuf<uint32_t> idx0(n_a), idx1(n_a), dupc(n_a), q_tie((size_t)n_seq);
+			DBuf<uint32_t> idx0(n_a), idx1(n_a), dupc(n_a);
+			DBuf<uint32_t> &q_tie = q_tie_f; q_tie.alloc((size_t)n_seq);
 			q_tie.zero(st);
 			hipLaunchKernelGGL(k_z_keys, dim3(nba), dim3(256), 0, st, z.p, q_aoff.p, n_z.p, n_seq, n_a, key0.p, idx0.p);
 			int bits = 1; while ((1LL << bits) < n_seq) ++bits;
@@ -1156,16 +1209,26 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 				DBuf<uint8_t> tmp2(tb2 ? tb2 : 1);
 				PGA_HIP(rocprim::inclusive_scan(tmp2.p, tb2, flag_it, dupc.p, n_a, rocprim::plus<uint32_t>(), st));
 			}
-			hipLaunchKernelGGL(k_z_take_sorted, dim3(nba), dim3(256), 0, st, z.p, sx.p, sy.p, q_aoff.p, n_z.p, n_seq, q_tie.p, n_a);
+			hipLaunchKernelGGL(k_z_take_sorted, dim3(nba), dim3(256), 0, st, z.p, sx.p, sy.p, q_aoff.p, n_z.p, n_seq, spec ? (const uint32_t*)nullptr : q_tie.p, n_a);
 			const RsHint hint{sx.p, sy.p, dupc.p};
-			replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint);
+			if (!spec) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint);
 			PGA_HIP(hipStreamSynchronize(st));                               // (the hint's buffers go out of scope)
 		}
 		ms_sort = et2.stop();
 		EventTimer et3(st);
 		hipLaunchKernelGGL(k_bt_walk, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, n_z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
-		                   verbose ? prof.p : (unsigned long long*)nullptr);
+		                   verbose ? prof.p : (unsigned long long*)nullptr, ev.p);
 		const double ms_walk = et3.stop(K_BACKTRACK);
+		if (verbose) {
+			std::vector<uint32_t> he = ev.download(st), hq = q_tie_f.n ? q_tie_f.download(st) : std::vector<uint32_t>();
+			size_t c[4] = {0, 0, 0, 0}, ft = 0; for (size_t i = 0; i < he.size(); ++i) { c[0] += he[i] & 1; c[1] += (he[i] >> 1) & 1; c[2] += (he[i] >> 2) & 1; c[3] += he[i] != 0; ft += i < hq.size() && hq[i]; }
+			fprintf(stderr, "[pga]   backtrack order events: %zu of %d queries (%zu with equal scores): walk stopped at an equal-score mark %zu, candidate marked by an equal score %zu, equal chain starts %zu\n", c[3], n_seq, ft, c[0], c[1], c[2]);
+		}
+		if (spec && need_out) {
+			DBuf<uint32_t> need((size_t)n_seq);
+			hipLaunchKernelGGL(k_need_exact, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, st, n_seq, d_q_tie_x, q_tie_f.p, ev.p, seg_q.p, need.p);
+			*need_out = need.download(st);
+		}
 		const double ms = ms_list + ms_walk;                 // the sort replay is accounted under K_SORT
 		if (verbose) {
 			std::vector<unsigned long long> pr = prof.download(st);   // wall_clock64 ticks at 100 MHz
@@ -1197,6 +1260,66 @@ void chain_all(const SeqSet &S, const DBuf<u128> &a, const DBuf<uint64_t> &q_aof
 	download_to(O.a, out.p, out.n, st);
 	mark("anchors to host");
 	if (vmarks) fprintf(stderr, "[pga]   chain stage, host ms:%s\n", marks.c_str());
+}
+
+// The stage.  minimap2 sorts twice with an UNSTABLE in-place radix sort whose arrangement of equal keys is the outcome of its sequential walk
+// (ksort.h:101-151): the anchors by target position before chaining (map.c:202) and the candidate chain ends by score before backtracking
+// (lchain.c:52).  Replaying those walks (pga_sort_replay.hip) is exact and is what a batch used to wait for twice.  For almost every query the
+// chains do NOT depend on either arrangement, and that is decidable while computing them in a stable order:
+//   (1) Anchors with equal x (same strand, target, position) differ in their query position y.  mg_lchain_rmq inserts the anchors of one x
+//       together, after all of them have been evaluated (lchain.c:285-292), so they are never one another's predecessors; trees are keyed by
+//       (y, index) and two anchors with the same y differ in x, so no comparison between tree keys is decided by the index of a permuted anchor;
+//       f[], and p[] as a relation between anchors, are the same for every arrangement -- as long as no range-min query meets a tied minimum
+//       priority (then the answer is a function of the tree's shape, i.e. of the insertion order: those segments run the tree re-enactment, and a
+//       query that holds equal keys AND such a segment needs the reference's order).
+//   (2) mg_chain_backtrack visits the candidates in descending score.  Candidates of different scores are ordered whatever the sort does.  Take
+//       the candidates of one score in any order: a walk only ever reads marks (lchain.c:14,17) and a finished walk only sets the marks of its
+//       kept part, so two candidates c, c' of equal score can influence each other only if the later one's walk stops at a mark of the earlier
+//       one's chain, or the later one is itself marked by it.  (If c's walk runs THROUGH anchors c' will keep, they lie behind c's cut: stopping
+//       there instead changes neither its maximum nor its kept part.)  k_bt_walk stores the claimant's score in every mark and raises an order
+//       event in exactly those two cases; none raised in the stable order = none can be raised in any order = the same set of chains.
+//   (3) What still differs is the ORDER in which chains are emitted, i.e. the input order of compact_a's own unstable sort (lchain.c:96-99, key:
+//       target position of the first anchor).  Distinct keys end up sorted whatever the input order; equal keys only matter if, in addition, two
+//       chains were emitted by candidates of equal score (otherwise the emission order is the descending score order and is exact).
+// Queries with an order event go through the reference's procedure: exact anchor order (seed_exact_order), chained again, exact candidate order.
+// On the BASELINE build: no event of kind (2) at all, ~37 queries per step (of 230 000) with (3).
+void chain_all(const SeqSet &S, SeedResult &SR, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm, bool exact_order)
+{
+	const int n_seq = S.n_seq;
+	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
+	if (exact_order || exact_sorts_forced()) {
+		if (!SR.exact) seed_exact_order(SR, nullptr, n_seq, st, tm);
+		chain_core(SR.a, SR.q_aoff, n_seq, SR.n_a, opt, k, O, st, tm, false, nullptr, nullptr);
+		return;
+	}
+	std::vector<uint32_t> need;
+	chain_core(SR.a, SR.q_aoff, n_seq, SR.n_a, opt, k, O, st, tm, true, SR.exact ? nullptr : SR.q_tie.p, &need);
+	std::vector<int> F;
+	for (int q = 0; q < n_seq; ++q) if (need[(size_t)q]) F.push_back(q);
+	if (verbose) fprintf(stderr, "[pga]   chain: %zu of %d queries need the reference's tie order\n", F.size(), n_seq);
+	if (F.empty()) return;
+	const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	// the reference's procedure for the queries of F, as a batch of their own
+	if (!SR.exact) { DBuf<uint32_t> d_need; d_need.upload(need, st); seed_exact_order(SR, d_need.p, n_seq, st, tm); }
+	const int n_sub = (int)F.size();
+	std::vector<uint64_t> src((size_t)n_sub), dst((size_t)n_sub + 1, 0);
+	for (int i = 0; i < n_sub; ++i) { src[(size_t)i] = SR.h_q_aoff[(size_t)F[(size_t)i]]; dst[(size_t)i + 1] = dst[(size_t)i] + (SR.h_q_aoff[(size_t)F[(size_t)i] + 1] - src[(size_t)i]); }
+	const uint64_t n_sub_a = dst[(size_t)n_sub];
+	DBuf<uint64_t> d_src, d_dst; d_src.upload(src, st); d_dst.upload(dst, st);
+	DBuf<u128> a_sub(n_sub_a ? n_sub_a : 1);
+	hipLaunchKernelGGL(k_gather_queries, dim3((unsigned)n_sub, 64), dim3(256), 0, st, n_sub, d_src.p, d_dst.p, SR.a.p, a_sub.p);
+	ChainResult R;
+	chain_core(a_sub, d_dst, n_sub, n_sub_a, opt, k, R, st, tm, false, nullptr, nullptr);
+	for (int i = 0; i < n_sub; ++i) {
+		const int q = F[(size_t)i];
+		const size_t n = (size_t)(dst[(size_t)i + 1] - dst[(size_t)i]);
+		O.n_u[(size_t)q] = R.n_u[(size_t)i]; O.n_v[(size_t)q] = R.n_v[(size_t)i];
+		if (n == 0) continue;
+		if (R.n_u[(size_t)i] > 0) memcpy(O.u.data() + src[(size_t)i], R.u.data() + dst[(size_t)i], (size_t)R.n_u[(size_t)i] * sizeof(uint64_t));
+		memcpy(O.a.data() + src[(size_t)i], R.a.data() + dst[(size_t)i], n * sizeof(u128));
+	}
+	if (verbose) fprintf(stderr, "[pga]   chain: the reference's procedure for those %d queries (%llu anchors): %.1f ms\n", n_sub, (unsigned long long)n_sub_a,
+	                     (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3);
 }
 
 } // namespace pga

@@ -295,7 +295,7 @@ template <class T> static void excl_scan(const T *in, uint64_t *out, size_t n, h
 }
 
 void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<uint32_t> &grp_of_mz, const mm_mapopt_t &opt,
-              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st, Timers *tm, const uint8_t *d_own)
+              const DBuf<int32_t> &d_name_rank, const DBuf<int32_t> &d_mid_occ, SeedResult &O, hipStream_t st, Timers *tm, const uint8_t *d_own, bool exact_order)
 {
 	const int n_seq = S.n_seq;
 	const uint64_t n = M.n;
@@ -385,7 +385,8 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	// 4. sort each query's anchors by x.  Parallel stable segmented sort first; queries that contain equal keys
 	//    are then re-sorted from the raw order by the sequential replay of radix_sort_128x (pga_sort_exact.h).
 	const unsigned nba = (unsigned)((n_a + 255) / 256);
-	DBuf<uint64_t> x0(n_a), y0(n_a), x1(n_a), y1(n_a);
+	DBuf<uint64_t> &x0 = O.raw_x, &y0 = O.raw_y, &x1 = O.srt_x, &y1 = O.srt_y;
+	x0.alloc(n_a); y0.alloc(n_a); x1.alloc(n_a); y1.alloc(n_a);
 	hipLaunchKernelGGL(k_anchor_pack, dim3(nbk), dim3(256), 0, st, n_kept, cnt.p, ub_off.p, ub.p, a_off.p, x0.p, y0.p);
 	{
 		// anchors are already grouped by query, so a device-wide stable sort by x followed by a stable sort by the
@@ -419,11 +420,10 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 		}
 	}
 	hipLaunchKernelGGL(k_join128, dim3(nba), dim3(256), 0, st, x1.p, y1.p, n_a, O.a.p);
-	DBuf<uint32_t> q_tie((size_t)n_seq); q_tie.zero(st);
+	DBuf<uint32_t> &q_tie = O.q_tie; q_tie.alloc((size_t)n_seq); q_tie.zero(st);
 	hipLaunchKernelGGL(k_tie_flags, dim3(nba), dim3(256), 0, st, x1.p, O.q_aoff.p, n_seq, n_a, (const u128*)nullptr, q_tie.p);
-	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, q_tie.p, O.q_aoff.p, x0.p, y0.p, O.a.p);
 	// the stable sort above doubles as a hint for the replay: buckets without equal keys are copied from it instead of being walked
-	DBuf<uint32_t> dupc(n_a);
+	DBuf<uint32_t> &dupc = O.dupc; dupc.alloc(n_a);
 	{
 		struct Dp { const uint64_t *x; };
 		Dp dp{x1.p};
@@ -433,14 +433,37 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 		DBuf<uint8_t> tmp(tb ? tb : 1);
 		PGA_HIP(rocprim::inclusive_scan(tmp.p, tb, flag_it, dupc.p, n_a, rocprim::plus<uint32_t>(), st));
 	}
-	const RsHint hint{x1.p, y1.p, dupc.p};
-	replay_sort_segments(O.a.p, n_a, O.q_aoff.p, nullptr, n_seq, q_tie.p, st, tm, getenv("PGA_NO_SORT_HINT") ? nullptr : &hint);
+	O.exact = false;
+	if (exact_order) seed_exact_order(O, nullptr, n_seq, st, tm);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipStreamSynchronize(st));
 	if (getenv("PGA_VERBOSE")) {
 		std::vector<uint32_t> tf = q_tie.download(st); size_t nt = 0; for (uint32_t v : tf) nt += v;
-		fprintf(stderr, "[pga]   seed: %llu anchors, %zu of %d queries hold equal anchor keys (sequential sort replay)\n", (unsigned long long)n_a, nt, n_seq);
+		fprintf(stderr, "[pga]   seed: %llu anchors, %zu of %d queries hold equal anchor keys (%s)\n", (unsigned long long)n_a, nt, n_seq,
+		        exact_order ? "sequential sort replay" : "stable order for now: the chaining stage asks for the reference's order where it matters");
 	}
 }
+
+__global__ void k_need_tied(const uint32_t *__restrict__ q_tie, const uint32_t *__restrict__ need, int n_seq, uint32_t *__restrict__ out)
+{
+	const int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n_seq) out[q] = q_tie[q] && (!need || need[q]) ? 1u : 0u;
+}
+
+void seed_exact_order(SeedResult &O, const uint32_t *d_need, int n_seq, hipStream_t st, Timers *tm)
+{
+	if (O.n_a == 0 || !O.q_tie.p || !O.raw_x.p) return;
+	DBuf<uint32_t> fl((size_t)n_seq);
+	hipLaunchKernelGGL(k_need_tied, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, st, O.q_tie.p, d_need, n_seq, fl.p);
+	// queries whose anchors hold equal keys restart from the raw order and go through the replay of radix_sort_128x (pga_sort_replay.hip); the stable
+	// sort doubles as its hint: buckets without equal keys are copied from it instead of being walked
+	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, fl.p, O.q_aoff.p, O.raw_x.p, O.raw_y.p, O.a.p);
+	const RsHint hint{O.srt_x.p, O.srt_y.p, O.dupc.p};
+	replay_sort_segments(O.a.p, O.n_a, O.q_aoff.p, nullptr, n_seq, fl.p, st, tm, getenv("PGA_NO_SORT_HINT") ? nullptr : &hint);
+	PGA_HIP(hipStreamSynchronize(st));
+	if (!d_need) O.exact = true;
+}
+
+bool exact_sorts_forced() { const char *e = getenv("PGA_EXACT_SORTS"); return e && *e && *e != '0'; }
 
 } // namespace pga
