@@ -460,6 +460,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     batch.busy_begin()                                         # union of the launch intervals per kernel family over the timed steps
+    cpu0 = os.times()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
@@ -469,6 +470,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    cpu1 = os.times()
+    host_cpu_s = (cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)
     if world > 1:
         dt = max_over_ranks(dt, cdev)
 
@@ -582,6 +585,7 @@ def main():
         "waves_rank0": [{"wave": w, "Mbp": b / 1e6, "hand_over_s": round(c, 4), "align_s": round(a, 4), "matches": int(m)} for w, b, c, a, m in last["per_wave"]],
         "batches_rank0": [{"t0": round(a, 4), "t1": round(b, 4), "calls": n, "Mbp": round(bs / 1e6, 1), "matches": m} for a, b, n, bs, m in sorted(last.get("batches", []))],
         "workload_generation_s": t_gen,
+        "host_cpu": {"cpu_s_per_step": host_cpu_s / args.steps, "mean_busy_cores": host_cpu_s / dt, "usable_cores": usable_cpus(), "threads_per_batch": slot_threads},
         "resident_inputs": resident,
         "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run); bytes per launch in the unit of alg_bytes_per_launch",
     }

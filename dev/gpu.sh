@@ -18,6 +18,9 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r = d.get("roofline", {})
+    try:
+        hc = json.load(open(sys.argv[1].replace(".json", "_detail.json")))["host_cpu"]; print("   host cpu: %.1f cores busy on average of %d" % (hc["mean_busy_cores"], hc["usable_cores"]))
+    except Exception: pass
     print(sys.argv[1], "value", round(d["value"], 3), "ms", round(d["ms_per_step"]), "resident", d.get("resident_gbp_s"), "parity", d.get("parity_checked_calls"),
           "| kernel", r.get("kernel"), "frac", r.get("frac"), "busy", r.get("busy_ms_per_step"), "any", r.get("any_kernel_busy_ms_per_step"), "| cpu", (d.get("cpu_baseline") or {}).get("value"), "| line bytes", len(json.dumps(d)))
 except Exception as e:

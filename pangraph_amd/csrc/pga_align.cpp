@@ -382,7 +382,8 @@ static void append_ops(Reg &r, uint32_t n, const uint32_t *ops)
 // ---------------------------------------------------------------- the per-region state machine
 struct Seg {
 	int32_t i, rs, qs, re, qe, bw1;
-	int job1 = -1, job2 = -1, zcode = -1, ll_job = -1;
+	int job1 = -1, job2 = -1, zcode = -1, ll_job = -1;   // job1 == -2: a first pass that is an identity probe without a problem record (pm: its answer)
+	int32_t pm = -1;                    // mismatches the probe counted (-1: not asked yet)
 	int walk = 0;                       // z-drop walk: 0 not asked, 1 asked, 2 answered
 	bool ll_deferred = false;           // the inversion query only decides split_inv of a split-off region: nobody waits for it here
 	int32_t max_zdrop = 0, wt0 = -1, wt1 = -1, wq0 = -1, wq1 = -1;
@@ -420,6 +421,7 @@ struct QueryCtx {
 	// DP problems of this query (ids are per query; filled between the threaded phases)
 	std::vector<DpJob> jobs; std::vector<DpRes> res; std::vector<const uint32_t*> cig; std::vector<int> pending;   // cig[id] points into a per-round CIGAR pool
 	std::unique_ptr<std::deque<uint32_t>> own_cig;   // one-operation CIGARs of the gap fills answered by the identity probe (stable addresses; made on first use: an empty deque already owns 0.5 KB)
+	std::vector<RegTask*> probe_tasks; // regions whose plan left segments with job1 == -2 that have not been probed yet
 	std::vector<WalkAsk> walks;       // device requests raised by the last advance pass
 	std::vector<RegTask*> fins;
 };
@@ -435,7 +437,11 @@ struct Driver {
 		for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[i * 5 + j] = (int8_t)((i == 4 || j == 4) ? amb : i == j ? a : b);
 		const int64_t lim = (int64_t)a + 2 * std::min(o.q + o.e, o.q2 + o.e2);
 		if (a > 0 && b < 0) probe_m_max = (int)((lim - 1) / (a - b));
+		// a probed segment needs no problem record at all when its answer can never reach the z-drop test: nM with m <= probe_m_max mismatches falls
+		// (a + |b|) * m short of all-matches, and zdrop_impossible() says "no drop" iff that is within both thresholds
+		lean_probes = probe_m_max >= 0 && (int64_t)(a - b) * probe_m_max <= std::min(o.zdrop, o.zdrop_inv) && !getenv("PGA_NO_LEAN_PROBES");
 	}
+	bool lean_probes = false;
 
 	static bool have(const QueryCtx &Q, int id) { return id >= 0 && (size_t)id < Q.res.size() && Q.res[(size_t)id].pad == 1; }
 
@@ -540,6 +546,7 @@ struct Driver {
 			T.left_job = request(Q, T.rev, T.rid, qs0, qs - qs0, rs0, rs - rs0, 1, bw, opt.end_bonus, r.split_inv ? opt.zdrop_inv : opt.zdrop, DP_EXTZ_ONLY | DP_RIGHT | DP_REV_CIGAR);
 		else T.left_done = true, T.rs1 = rs, T.qs1 = qs;
 		// gap-fill segments (align.c:726-745): determined by the anchors alone
+		bool any_lean = false;
 		for (i = 1; i < cnt1; ++i) {
 			if (A.flagged(as1 + i, A_IGNORE | A_TANDEM) && i != cnt1 - 1) continue;
 			re = A.tpos(as1 + i) - half_k, qe = A.qpos(as1 + i) - half_k;
@@ -547,6 +554,10 @@ struct Driver {
 				Seg sg; sg.i = i, sg.rs = rs, sg.qs = qs, sg.re = re, sg.qe = qe, sg.bw1 = bw_long;
 				if (A.flagged(as1 + i, A_LONG_JOIN)) sg.bw1 = std::max(qe - qs, re - rs);
 				const bool probe = qe - qs == re - rs && sg.bw1 >= qe - qs;
+				// 99.9 % of the segments of a whole-genome chain are equally long windows that the identity probe answers "nM": they get no
+				// problem record (48 + 56 bytes and three vector pushes each, a million per leaf batch) -- the probe reads the segment itself
+				if (probe && lean_probes && qe - qs > 0 && !(opt.max_sw_mat > 0 && (int64_t)(qe - qs) * (re - rs) > opt.max_sw_mat)) { sg.job1 = -2; any_lean = true; }
+				else
 				sg.job1 = request(Q, T.rev, T.rid, qs, qe - qs, rs, re - rs, 0, sg.bw1, -1, opt.zdrop, DP_APPROX_MAX, probe);
 				// a long segment without seeds is where chains break: its exact second pass (needed whenever the z-drop test fires,
 				// with the same parameters whatever the test's return code when both thresholds agree) is launched WITH the first
@@ -557,6 +568,7 @@ struct Driver {
 				rs = re, qs = qe;
 			}
 		}
+		if (any_lean) Q.probe_tasks.push_back(&T);
 		T.re = re, T.qe = qe;   // the last adjusted anchor (what the right extension starts from when nothing dropped)
 		if (cnt1 == 1) T.re = A.tpos(as1) - half_k, T.qe = A.qpos(as1) - half_k;
 		// right extension (align.c:789-805), speculative: only used when no segment z-drops
@@ -602,6 +614,16 @@ struct Driver {
 		if (T.seg_k == 0) T.re1 = T.rs, T.qe1 = T.qs;
 		while (T.seg_k < T.segs.size() && !T.dropped) {
 			Seg &sg = T.segs[T.seg_k];
+			if (sg.job1 == -2) {                                   // a probed segment: nM, no z-drop possible (Driver::lean_probes)
+				if (sg.pm < 0) return false;
+				T.re1 = sg.re, T.qe1 = sg.qe;
+				const uint32_t op = (uint32_t)(sg.qe - sg.qs) << 4;
+				append_ops(r, 1u, &op);
+				r.dp_score += mat[0] * (sg.qe - sg.qs - sg.pm) + mat[1] * sg.pm;
+				sg.zcode = 0;
+				++T.seg_k;
+				continue;
+			}
 			if (!have(Q, sg.job1)) return false;
 			// results and CIGARs of the following segments lie wherever their kernels finished: start fetching them now
 			for (size_t ahead = 2; ahead <= 4; ahead += 2) if (T.seg_k + ahead < T.segs.size()) {
@@ -625,7 +647,7 @@ struct Driver {
 						// whatever the answer, the second pass runs when both thresholds agree (they do in every asm preset): the return
 						// code is 1 or 2 (max_zdrop > zdrop_inv == zdrop), and 2 only sets split_inv of the piece split off here --
 						// so this region goes on with the second pass and leaves the query's answer to that piece
-						if (opt.zdrop == opt.zdrop_inv) { if (sg.job2 < 0) sg.job2 = second_pass(Q, T, sg, opt.zdrop); sg.zcode = 1; sg.ll_deferred = true; }
+						if (opt.zdrop == opt.zdrop_inv) { if (sg.job2 < 0) sg.job2 = second_pass(Q, T, sg, opt.zdrop); sg.zcode = 1; sg.ll_deferred = true; Q.jobs[(size_t)sg.ll_job].pad[1] = 1; }
 					} else {
 						int q_end, t_end;
 						sg.zcode = zcode_of(sg, ll_on_host(Q, 1 - T.rev, qlen - (sg.qs + sg.wq1), q_len, T.rid, sg.rs + sg.wt0, t_len, false, &q_end, &t_end));
@@ -794,13 +816,64 @@ struct RoundRunner {
 	const std::vector<int> &qs; int set_id, n_threads; hipStream_t st; Timers *tm; DpParams P;
 	bool verbose;
 	std::list<PinVec<uint32_t>> pools;        // CIGAR pools of the DP rounds: results point into them until the set is done
+	// Inversion queries nobody waits for (Seg::ll_deferred: the answer only sets split_inv of the piece split off there, which is read when that piece
+	// has been aligned, a round or more later): a 10 kb x 10 kb ksw_ll_i16 takes 13-21 ms, four times a round of end extensions.  They run BESIDE
+	// the rounds -- own host thread, stream, arena and launch lanes -- and are collected when they are done or when nothing else is left to do.
+	struct AsyncLL { std::thread th; std::atomic<bool> done{false}; std::vector<DpJob> jb; std::vector<std::pair<int,int>> owner; std::vector<DpRes> rs; PinVec<uint32_t> cg; Timers tm; std::string err; };
+	std::list<AsyncLL> asyncs;
+	void launch_async_ll(std::vector<DpJob> &&jb, std::vector<std::pair<int,int>> &&owner)
+	{
+		asyncs.emplace_back();
+		AsyncLL &A = asyncs.back();
+		A.jb = std::move(jb); A.owner = std::move(owner);
+		int dev = 0; PGA_HIP(hipGetDevice(&dev));
+		const PkBases bases = S.bases(); const DpParams Pc = P; const bool keep_tm = tm != nullptr;
+		A.th = std::thread([&A, dev, bases, Pc, keep_tm] {
+			hipStream_t ss = nullptr; int arena = -1;
+			try {
+				PGA_HIP(hipSetDevice(dev));
+				arena = dev_lease_arena();
+				ArenaScope arena_scope(arena);
+				set_thread_budget(1);
+				ss = stream_lease();
+				dp_run(bases, A.jb, Pc, A.rs, A.cg, ss, keep_tm ? &A.tm : nullptr);
+				PGA_HIP(hipStreamSynchronize(ss));
+			} catch (std::exception &e) { A.err = e.what(); if (A.err.empty()) A.err = "unknown error"; }
+			if (ss) stream_release(ss);
+			if (arena >= 0) dev_release_arena(arena);
+			A.done.store(true, std::memory_order_release);
+		});
+	}
+	// results of the finished asynchronous queries into their queries' records (wait = true: of all of them); returns how many arrived
+	size_t harvest_async(bool wait)
+	{
+		size_t got = 0;
+		for (auto it = asyncs.begin(); it != asyncs.end();) {
+			AsyncLL &A = *it;
+			if (!wait && !A.done.load(std::memory_order_acquire)) { ++it; continue; }
+			A.th.join();
+			if (!A.err.empty()) { const std::string e = A.err; for (auto &B : asyncs) if (B.th.joinable()) B.th.join(); asyncs.clear(); throw std::runtime_error(e); }
+			for (size_t i = 0; i < A.rs.size(); ++i) { QueryCtx &q = Q[(size_t)A.owner[i].first]; const int id = A.owner[i].second; q.res[(size_t)id] = A.rs[i]; q.res[(size_t)id].pad = 1; q.cig[(size_t)id] = nullptr; }
+			if (tm) { tm->dp_bases += A.tm.dp_bases; for (int i = 0; i < K_COUNT; ++i) { tm->kern[i].ms += A.tm.kern[i].ms; tm->kern[i].launches += A.tm.kern[i].launches; tm->kern[i].alg_bytes += A.tm.kern[i].alg_bytes; tm->kern[i].cells += A.tm.kern[i].cells; } }
+			got += A.rs.size();
+			it = asyncs.erase(it);
+		}
+		return got;
+	}
+	~RoundRunner() { for (auto &A : asyncs) if (A.th.joinable()) A.th.join(); }
 
-	// identity probes of the pending problems: answered ones leave the pending lists
+	// identity probes: of the pending problems (answered ones leave the pending lists) and of the segments that have no problem record (Seg::job1 == -2:
+	// answered ones keep their count, the others become problems now)
 	void run_probes()
 	{
 		const size_t n_q = qs.size();
 		std::vector<size_t> off(n_q + 1, 0);
-		parallel_for(n_q, n_threads, [&](size_t k) { size_t c = 0; const QueryCtx &q = Q[(size_t)qs[k]]; for (int id : q.pending) c += q.jobs[(size_t)id].pad[0]; off[k + 1] = c; });
+		parallel_for(n_q, n_threads, [&](size_t k) {
+			size_t c = 0; const QueryCtx &q = Q[(size_t)qs[k]];
+			for (int id : q.pending) c += q.jobs[(size_t)id].pad[0];
+			for (const RegTask *T : q.probe_tasks) for (const Seg &sg : T->segs) c += sg.job1 == -2 && sg.pm < 0;
+			off[k + 1] = c;
+		});
 		for (size_t k = 0; k < n_q; ++k) off[k + 1] += off[k];
 		const size_t n = off[n_q];
 		if (!n) return;
@@ -808,6 +881,11 @@ struct RoundRunner {
 		parallel_for(n_q, n_threads, [&](size_t k) {
 			const QueryCtx &q = Q[(size_t)qs[k]]; size_t o = off[k];
 			for (int id : q.pending) { const DpJob &j = q.jobs[(size_t)id]; if (j.pad[0]) pr[o++] = PostProbe{j.t_off, j.q_off, j.qlen_full, j.qs, j.qlen, (int32_t)j.q_rev}; }
+			const uint64_t q_off = S.off[(size_t)q.qid];
+			for (const RegTask *T : q.probe_tasks) {
+				const uint64_t t0 = S.off[(size_t)(q.base + T->rid)];
+				for (const Seg &sg : T->segs) if (sg.job1 == -2 && sg.pm < 0) pr[o++] = PostProbe{t0 + (uint64_t)sg.rs, q_off, q.qlen, sg.qs, sg.qe - sg.qs, (int32_t)T->rev};
+			}
 		});
 		PinVec<int32_t> m;
 		const double t0 = wall_s();
@@ -821,7 +899,15 @@ struct RoundRunner {
 				if (j.pad[0]) { j.pad[0] = 0; const int mm = m[o++]; if (mm >= 0) { D.answer_probe(q, id, mm); ++yes; continue; } }
 				q.pending[w++] = id;
 			}
-			q.pending.resize(w); n_yes += yes;
+			q.pending.resize(w);
+			for (RegTask *T : q.probe_tasks)
+				for (Seg &sg : T->segs) if (sg.job1 == -2 && sg.pm < 0) {
+					const int mm = m[o++];
+					if (mm >= 0) { sg.pm = mm; ++yes; }
+					else sg.job1 = D.request(q, T->rev, T->rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, opt.zdrop, DP_APPROX_MAX, false);    // (the probe has spoken)
+				}
+			q.probe_tasks.clear();
+			n_yes += yes;
 		});
 		if (verbose) fprintf(stderr, "[pga]   set %d: %zu identity probes, %zu answered without a matrix, %.3f s\n", set_id, n, n_yes.load(), wall_s() - t0);
 	}
@@ -843,6 +929,17 @@ struct RoundRunner {
 			q.pending.clear();
 			cells_of[k] = cells;
 		});
+		static const bool async_ll = getenv("PGA_LL_ASYNC") != nullptr;     // measured: no gain (6.1-5.7 against 6.2-6.5 Gbp/s): one more stream and lane set per batch crowd the hardware queues
+		if (async_ll) {
+			std::vector<DpJob> ajb; std::vector<std::pair<int,int>> aown; size_t w = 0;
+			for (size_t i = 0; i < jb.size(); ++i) {
+				if ((jb[i].flag & PGA_JOB_LL) && jb[i].pad[1]) { ajb.push_back(jb[i]); aown.push_back(owner[i]); }
+				else { if (w != i) { jb[w] = jb[i]; owner[w] = owner[i]; } ++w; }
+			}
+			jb.resize(w); owner.resize(w);
+			if (!ajb.empty()) { if (verbose) fprintf(stderr, "[pga]   set %d round %d: %zu inversion queries run beside the rounds\n", set_id, round, ajb.size()); launch_async_ll(std::move(ajb), std::move(aown)); }
+			if (jb.empty()) return;
+		}
 		std::vector<DpRes> rs;
 		pools.emplace_back();
 		PinVec<uint32_t> &cg = pools.back();
@@ -1022,10 +1119,17 @@ struct RoundRunner {
 			if (verbose) fprintf(stderr, "[pga]   set %d round %d: probes %.4f s, dp %.4f s\n", set_id, round, t_r1 - t_r0, wall_s() - t_r1);
 			const double t_adv0 = wall_s();
 			int unfinished;
-			for (;;) { unfinished = advance_pass(); if (!run_post()) break; }
+			harvest_async(false);
+			for (;;) {
+				for (;;) { unfinished = advance_pass(); if (!run_post()) break; }
+				if (unfinished == 0) break;
+				bool pend = false; for (int qi : qs) pend |= !Q[(size_t)qi].pending.empty() || !Q[(size_t)qi].probe_tasks.empty();
+				if (pend || asyncs.empty()) break;
+				harvest_async(true);                               // nothing else to do: the queries that are still open wait for an inversion query
+			}
 			if (verbose) fprintf(stderr, "[pga]   set %d round %d: host advance + device post-processing %.3f s\n", set_id, round, wall_s() - t_adv0);
-			if (unfinished == 0) break;
-			bool any_pending = false; for (int qi : qs) any_pending |= !Q[(size_t)qi].pending.empty();
+			if (unfinished == 0) { harvest_async(true); break; }       // (a query whose split left no piece never reads its answer: rare)
+			bool any_pending = false; for (int qi : qs) any_pending |= !Q[(size_t)qi].pending.empty() || !Q[(size_t)qi].probe_tasks.empty();
 			if (!any_pending) throw std::runtime_error("pga: alignment driver stalled");
 			if (!tail && unfinished > 1 && unfinished <= tail_max) {
 				std::vector<int> open;
