@@ -478,6 +478,17 @@ def main():
     # ---- parity of the step that was timed: every find_matches call of the LAST timed step against the digests the compiled reference
     # produced for this build (tests/golden/builds_expected.json.gz).  A differing call means the number is not a measurement of the path.
     parity = {"parity_checked_calls": 0, "parity": "not checked"}
+    build_sha = None
+    if rank == 0 and args.schedule == "ready" and not args.leaf_only and last.get("results"):
+        # one digest of the whole build's record lists (sha256 over the per-call digests in call order): equal for any number of ranks
+        import hashlib
+        from pangraph_amd import digest as dg
+        per_call = {}
+        for ts, rec, pool, covered in last["results"]:
+            lists = dg.records_to_lists(rec, pool, [t.names for t in ts])
+            for i in (range(len(ts)) if covered is None else covered):
+                per_call[ts[i].tid] = (len(lists[i]), dg.digest(lists[i]))
+        build_sha = hashlib.sha256(json.dumps([per_call[k] for k in sorted(per_call)]).encode()).hexdigest() if len(per_call) == len(tasks) else None
     if rank == 0 and args.schedule == "ready" and not args.no_parity_check and not args.leaf_only:
         from pangraph_amd import digest as dg
         gold = dg.expected_build(args.seed, args.genomes, args.length)
@@ -564,6 +575,7 @@ def main():
                      "whole_path": {"alg_bytes_per_step": alg_step, "achieved": alg_step / (ms_step * 1e-3) / 1e9, "frac": alg_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      "note": "kernel = largest summed HIP-event time (own stream); batches overlap, see busy_ms; traffic: profiles/ PMC passes, same unit as alg_bytes_per_launch"},
         "n_matches_gathered": last["n_matches"],
+        "build_sha256": build_sha,
         "resident_gbp_s": resident["gbp_s"] if resident else (units * args.steps / dt / 1e9 if inp["lib"] is not None else None),
     }
     out.update(parity)
@@ -587,6 +599,7 @@ def main():
         "workload_generation_s": t_gen,
         "host_cpu": {"cpu_s_per_step": host_cpu_s / args.steps, "mean_busy_cores": host_cpu_s / dt, "usable_cores": usable_cpus(), "threads_per_batch": slot_threads},
         "resident_inputs": resident,
+        "predicted_scaling": (sched.predict_scaling(pop, tasks, (1, 2, 4, 8), units * args.steps / dt / 1e9, args.slots) if world == 1 and args.schedule == "ready" and not args.leaf_only else None),
         "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run); bytes per launch in the unit of alg_bytes_per_launch",
     }
     if rank == 0:

@@ -15,8 +15,10 @@ one call).  The batches are ordinary pga_batch_create / pga_batch_align calls fr
 its own stream and device-memory arena.  Results do not depend on how tasks are batched (groups are independent problems).
 
 Multi-GPU (`world` > 1): the tree is cut into subtrees (`partition_subtrees`), every rank builds its subtrees with its own ready-set
-scheduler and no communication, the match lists are gathered once, and the merges above the cut run on rank 0 (they need the graphs of
-subtrees that live on different ranks).
+scheduler and no communication, the match lists are gathered once; the merges above the cut (owner -1) are few, large and hang one
+below the other: ALL ranks run them together, level by level -- every rank indexes the whole call and maps a contiguous range of the
+queries of every group (pga_batch_align_shard) -- and a second gather ends the step (bench.py:step_ready).  `predict_scaling` turns the
+partition and a cost model calibrated on one GPU into the step time to expect at N ranks.
 """
 from __future__ import annotations
 
@@ -60,9 +62,10 @@ class Task:
 
 
 def cost_estimate(bases: int, n_seqs: int) -> float:
-    """seconds a task takes alone on the device (rough: a whole-genome pair is bound by its dependency chains, a block set by throughput)"""
+    """seconds a task takes alone on the device (rough: a whole-genome pair is bound by its dependency chains, a block set by throughput;
+    round 4, dev/path_probe.py: a spine call of two block sets 15-30 ms, its second round 5-8 ms, a whole-genome pair ~0.2 s)"""
     big = bases / max(1, n_seqs)
-    return 0.02 + bases * 2.5e-10 + (0.25 if big > 1e6 else 0.0)
+    return 0.006 + bases * 2.5e-10 + (0.2 if big > 1e6 else 0.0)
 
 
 def build_tasks(pop, min_block: int = 100, rounds: int = 2) -> List[Task]:
@@ -276,3 +279,31 @@ def partition_subtrees(pop, tasks: List[Task], world: int, per_rank: int = 4):
                 stack += list(pop.nodes[x].children)
     owner = [(-1 if t.node in top else owner_of_node[t.node]) for t in tasks]
     return owner, per
+
+
+def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu: float, slots: int = 6) -> Dict[str, dict]:
+    """What the subtree partition lets N ranks do, from ONE GPU's measurements: a rank cannot finish phase 1 before (a) its share of the bases
+    has gone through at the single-GPU throughput and (b) the longest dependency chain of its subtrees has run (cost_estimate per call, the
+    calls of a chain one after the other); phase 2 is the chain of merges above the cut, each shortened by the query split only as far as its
+    per-call floor allows.  A MODEL to hold the first real multi-GPU run against -- not a measurement."""
+    out = {}
+    total = float(sum(t.bases for t in tasks))
+    for n in worlds:
+        owner, _ = partition_subtrees(pop, tasks, n)
+        load = [0.0] * max(1, n)
+        order = topo_order(tasks)
+        longest = [0.0] * len(tasks)
+        for tid in order:
+            t = tasks[tid]
+            if owner[tid] < 0:
+                continue
+            longest[tid] = cost_estimate(t.bases, len(t.seqs)) + max((longest[d] for d in t.deps if owner[d] == owner[tid]), default=0.0)
+            load[owner[tid]] += t.bases
+        crit = [max((longest[t.tid] for t in tasks if owner[t.tid] == r), default=0.0) for r in range(max(1, n))]
+        phase1 = max(max(load[r] / 1e9 / gbp_s_one_gpu, crit[r]) for r in range(max(1, n)))
+        top = [t for t in tasks if owner[t.tid] < 0]
+        phase2 = sum(max(0.006, cost_estimate(t.bases, len(t.seqs)) / n) for t in top)
+        step = phase1 + phase2
+        out[str(n)] = {"per_rank_gbp": [round(x / 1e9, 6) for x in load], "per_rank_critical_path_s": [round(x, 3) for x in crit], "calls_above_the_cut": len(top),
+                       "phase1_s": round(phase1, 3), "phase2_s": round(phase2, 3), "step_s": round(step, 3), "gbp_s": round(total / 1e9 / step, 2) if step > 0 else None}
+    return out

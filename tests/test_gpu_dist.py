@@ -257,3 +257,25 @@ def test_bench_c5_two_ranks_on_one_device_every_call_vs_reference_digests():
     assert len(line) < 4096
     b = json.loads(line)
     assert b["n_gpus"] == 2 and b["parity_checked_calls"] == 1998 and b["n_matches_gathered"] == 104928, b
+
+
+def test_bench_eight_ranks_on_one_device_equals_the_single_rank_build():
+    """N = 8 without an 8-GPU node: eight gloo ranks share GPU 0 (PGA_BENCH_SINGLE_DEVICE=1, an eighth of the memory each) on a tree too small for
+    eight heavy subtrees -- ranks that own little or nothing in phase 1, most merges above the cut and mapped by all ranks together (queries of
+    every group split eight ways), both gathers -- and the digest of the whole build's record lists equals the single-rank build's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGA_BENCH_SINGLE_DEVICE="1")
+    common = ["--genomes", "40", "--length", "60000", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--no-next-rows", "--no-resident-rate"]
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    outs = {}
+    for n in (1, 8):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--detail", os.path.join(root, "gpurun_out", f"bench_detail_{n}ranks_small.json")] + common,
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (n, r.stdout[-1500:], r.stderr[-2500:])
+        outs[n] = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = outs[1], outs[8]
+    assert b["n_gpus"] == 8 and a["n_matches_gathered"] == b["n_matches_gathered"] > 100
+    assert a["build_sha256"] and a["build_sha256"] == b["build_sha256"]

@@ -100,3 +100,30 @@ def test_subtree_partition_covers_every_call_once():
         sched.run_ready_set(tasks, lambda ts: ran.extend(t.tid for t in ts), slots=2, only={t.tid for t in tasks if owner[t.tid] == -1},
                             done={t.tid for t in tasks if owner[t.tid] != -1})
         assert sorted(ran) == list(range(len(tasks)))
+
+
+def test_more_ranks_than_subtrees_and_the_scaling_model():
+    """8 ranks on a 10-genome tree: some ranks own nothing, most merges sit above the cut -- the plan must still cover every call once; and the
+    scaling model (schedule.predict_scaling) reports, per N, loads that add up to the build and a step that is never shorter than its parts."""
+    pop = _pop(10)
+    tasks = sched.build_tasks(pop)
+    owner, per = sched.partition_subtrees(pop, tasks, 8)
+    assert len(per) == 8 and any(len(p) == 0 for p in per)               # empty ranks exist
+    assert set(owner) <= set(range(8)) | {-1}
+    ran = []
+    for r in range(8):
+        mine = {t.tid for t in tasks if owner[t.tid] == r}
+        if mine:
+            sched.run_ready_set(tasks, lambda ts: ran.extend(t.tid for t in ts), slots=2, only=mine)
+    sched.run_ready_set(tasks, lambda ts: ran.extend(t.tid for t in ts), slots=2, only={t.tid for t in tasks if owner[t.tid] == -1},
+                        done={t.tid for t in tasks if owner[t.tid] != -1})
+    assert sorted(ran) == list(range(len(tasks)))
+    big = _pop(60)
+    bt = sched.build_tasks(big)
+    model = sched.predict_scaling(big, bt, (1, 2, 4, 8), gbp_s_one_gpu=0.01)
+    total = sum(t.bases for t in bt) / 1e9
+    for n, m in model.items():
+        above = sum(t.bases for t, o in zip(bt, sched.partition_subtrees(big, bt, int(n))[0]) if o == -1) / 1e9
+        assert abs(sum(m["per_rank_gbp"]) + above - total) < 1e-2 * max(total, 1e-9) + 1e-3
+        assert m["step_s"] >= m["phase1_s"] and m["step_s"] >= m["phase2_s"] and len(m["per_rank_gbp"]) == int(n)
+    assert model["1"]["calls_above_the_cut"] == 0 and model["8"]["calls_above_the_cut"] > 0
