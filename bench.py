@@ -347,19 +347,27 @@ def main():
         recs, pools, pool_len = [], [], [0]
 
         def run_batch(ts):
+            tp0 = time.perf_counter()
             batch.set_device(local)                               # HIP's current device belongs to the host thread: every worker says which one it means
             tb = sched.TaskBatch(ts, inp["first"])
             t0 = time.perf_counter()
+            with lock:
+                agg["py_s"] = agg.get("py_s", 0.0) + (t0 - tp0)
             rb = batch.ResidentBatch(tb, derive_from=inp["lib"])  # --inputs host: hand-over (H2D + encoding) inside the timed region; resident: device-to-device
             t1 = time.perf_counter()
             res = rb.align(sensitivity=10, want_raw=True, n_threads=slot_threads)
             t2 = time.perf_counter()
             rb.close()
+            with lock:
+                agg["close_s"] = agg.get("close_s", 0.0) + (time.perf_counter() - t2)
+                agg["lib_align_total_s"] = agg.get("lib_align_total_s", 0.0) + float(res.stats["total"])
             return res, t1 - t0, t2 - t1
 
         def on_result(ts, out, ta, tb_):
             res, c, a = out
+            tr0 = time.perf_counter()
             with lock:
+                agg["slot_s"] = agg.get("slot_s", 0.0) + (tb_ - ta)
                 agg["create_s"] += c; agg["align_s"] += a
                 st = res.stats
                 agg["n_matches"] += int(st["n_matches"])
@@ -374,6 +382,7 @@ def main():
                         m["group"] = np.asarray([t.tid for t in ts], dtype=np.int32)[m["group"]]
                         m["cigar_off"] += np.uint64(pool_len[0])
                     recs.append(m); pools.append(cg); pool_len[0] += len(cg)
+                agg["on_result_s"] = agg.get("on_result_s", 0.0) + (time.perf_counter() - tr0)
             res.close()
 
         if world == 1:
@@ -582,6 +591,8 @@ def main():
     detail = {
         "bench_line": None,
         "rank0_seconds_per_step": {"hand_over": last["create_s"], "align": last["align_s"], "gather": last["gather_s"],
+                                   "python_before_create": last.get("py_s"), "batch_close": last.get("close_s"), "on_result": last.get("on_result_s"), "slot_time_run_batch": last.get("slot_s"),
+                                   "library_stage_total": last.get("lib_align_total_s"),
                                    "note": "summed over the batches in flight at the same time (ready-set schedule): not a decomposition of ms_per_step"},
         "roofline_note": "device_ms_per_step are HIP-event times on each kernel's own stream, summed over all launches; streams and batches overlap, so they do "
                          "not add up to ms_per_step -- busy_ms_per_step is the UNION of a family's launch intervals on the device clock (what the step spent with "

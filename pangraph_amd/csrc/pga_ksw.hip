@@ -378,6 +378,12 @@ size_t strips_bnd_words(const DpJob &j);
 void launch_approx_strips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                           uint32_t *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 
+bool wstrips_on();
+bool wstrips_eligible(const DpJob &j, const DpParams &P);
+int wstrips_count(const DpJob &j);
+size_t wstrips_bnd_words(const DpJob &j);
+void launch_wstrips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
+                    unsigned long long *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 bool lanes_eligible(const DpJob &j, int nt);
 size_t lanes_cig_bytes(int q_cap, int t_cap);
 size_t lanes_chunk_bytes(int nt);
@@ -388,7 +394,7 @@ static int dp_class(const DpJob &j, bool allow_band, const DpParams &P)
 {
 	static const bool no_lanes = getenv("PGA_NO_LANES") != nullptr;     // A/B: the workgroup kernel takes the banded problems again
 	if (j.flag & PGA_JOB_LL) return 6;
-	if (strips_eligible(j, P) && (allow_band || (j.flag & EZ_APPROX_MAX))) return 9;      // (exact problems the strips handed back go to the workgroup kernel)
+	if ((wstrips_on() ? wstrips_eligible(j, P) : strips_eligible(j, P)) && (allow_band || (j.flag & EZ_APPROX_MAX))) return 9;      // (exact problems the strips handed back go to the workgroup kernel)
 	if (allow_band && j.flag == EZ_APPROX_MAX && j.w >= j.qlen && j.w >= j.tlen && j.qlen >= 1 && j.tlen >= 1 && j.qlen <= BAND_MAXLEN && j.tlen <= BAND_MAXLEN &&
 	    j.tlen - j.qlen <= 12 && j.qlen - j.tlen <= 12) return 8;
 	const bool unbanded = j.w >= j.qlen && j.w >= j.tlen;
@@ -644,15 +650,18 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		if (c == 9) {
 			std::vector<uint32_t> bj, bs; std::vector<uint64_t> so(ids.size()), bo(ids.size());
 			uint64_t s_acc = 0, b_acc = 0;
+			const bool ws = wstrips_on();                                   // wave strips (pga_ksw_wstrips.hip): 64-bit boundary words
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
 				so[i] = s_acc; s_acc += need[ids[i]];
-				bo[i] = b_acc; b_acc += strips_bnd_words(j);
-				for (int k2 = 0; k2 < strips_count(j); ++k2) { bj.push_back((uint32_t)i); bs.push_back((uint32_t)k2); }
+				bo[i] = b_acc; b_acc += ws ? wstrips_bnd_words(j) : strips_bnd_words(j);
+				for (int k2 = 0; k2 < (ws ? wstrips_count(j) : strips_count(j)); ++k2) { bj.push_back((uint32_t)i); bs.push_back((uint32_t)k2); }
 			}
 			X.d_blk_job.upload(bj, cs); X.d_blk_strip.upload(bs, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs);
-			X.d_bnd.alloc((size_t)b_acc + 1); X.d_bnd.zero(cs);
+			X.d_bnd.alloc(((size_t)b_acc + 1) * (ws ? 2 : 1)); X.d_bnd.zero(cs);
 			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
+			if (ws) launch_wstrips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			else
 			launch_approx_strips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
