@@ -18,6 +18,7 @@
 #include "pga_common.h"
 #include "pga_dp.h"
 #include "pga_post.h"
+#include "pga_plan.h"
 #include "pga_sort_exact.h"
 #include "pga_pipeline.h"
 #include <cmath>
@@ -91,14 +92,16 @@ static inline uint32_t mix32(uint32_t k) { k += ~(k << 15); k ^= k >> 10; k += k
 
 // One region per chain, ordered by descending (score<<32 | cnt) ^ salt(first anchor, query) -- hit.c:52-88.  The order of equal keys
 // is the one minimap2's radix sort leaves, so the keys go through its exact replay.
-static void regions_from_chains(uint32_t query_salt, int qlen, int n_chains, const uint64_t *u, const Anchors &A, std::vector<Reg> &regs)
+static void regions_from_chains(uint32_t query_salt, int qlen, int n_chains, const uint64_t *u, const Anchors &A, std::vector<Reg> &regs, const u128 *heads = nullptr)
 {
+	// heads: the first anchor of every chain, gathered on the device (then A holds no anchors and the extents are left to the planner)
 	regs.clear();
 	if (n_chains == 0) return;
 	std::vector<u128> key((size_t)n_chains);
 	int32_t start = 0;
 	for (int c = 0; c < n_chains; ++c) {
-		const uint32_t salt = (uint32_t)mix64((mix64(A.a[start].x) + mix64(A.a[start].y)) ^ query_salt);
+		const u128 h0 = heads ? heads[c] : A.a[start];
+		const uint32_t salt = (uint32_t)mix64((mix64(h0.x) + mix64(h0.y)) ^ query_salt);
 		const int32_t cnt = (int32_t)u[c];
 		key[(size_t)c].x = u[c] ^ salt;
 		key[(size_t)c].y = (uint64_t)start << 32 | (uint32_t)cnt;
@@ -112,12 +115,12 @@ static void regions_from_chains(uint32_t query_salt, int qlen, int n_chains, con
 		r.id = c, r.parent = -1;                                   // -X: no primary/secondary selection, parents stay unset
 		r.score = r.score0 = (int32_t)(k.x >> 32), r.hash = (uint32_t)k.x;
 		r.cnt = (int32_t)(uint32_t)k.y, r.as = (int32_t)(k.y >> 32);
-		chain_extent(r, qlen, A);
+		if (!heads) chain_extent(r, qlen, A);
 	}
 }
 
 // The tail of `head` from its anchor `n_keep` on becomes its own region (hit.c:106-123); scores are shared out by anchor counts.
-static void cut_region(Reg &head, Reg &tail, int n_keep, int qlen, const Anchors &A)
+static void cut_region(Reg &head, Reg &tail, int n_keep, int qlen, const Anchors &A, bool extents = true)
 {
 	if (n_keep <= 0 || n_keep >= head.cnt) return;
 	const int total = head.cnt;
@@ -128,8 +131,8 @@ static void cut_region(Reg &head, Reg &tail, int n_keep, int qlen, const Anchors
 	tail.score = (int32_t)(head.score * ((float)tail.cnt / total) + .499);
 	if (head.parent == head.id) tail.parent = -2;                 // MM_PARENT_TMP_PRI
 	head.cnt = n_keep, head.score -= tail.score;
-	chain_extent(tail, qlen, A);
-	chain_extent(head, qlen, A);
+	// (device-side planning: the tail's extent comes back with its plan; the head's is overwritten by what its alignment found)
+	if (extents) { chain_extent(tail, qlen, A); chain_extent(head, qlen, A); }
 	head.split |= 1, tail.split |= 2;
 }
 
@@ -384,6 +387,7 @@ struct Seg {
 	int32_t i, rs, qs, re, qe, bw1;
 	int job1 = -1, job2 = -1, zcode = -1, ll_job = -1;   // job1 == -2: a first pass that is an identity probe without a problem record (pm: its answer)
 	int32_t pm = -1;                    // mismatches the probe counted (-1: not asked yet)
+	int32_t i_prev = -1;                // device-side planning: the anchor the segment starts at (chain-relative), for the split after a z-drop
 	int walk = 0;                       // z-drop walk: 0 not asked, 1 asked, 2 answered
 	bool ll_deferred = false;           // the inversion query only decides split_inv of a split-off region: nobody waits for it here
 	int32_t max_zdrop = 0, wt0 = -1, wt1 = -1, wq0 = -1, wq1 = -1;
@@ -422,6 +426,8 @@ struct QueryCtx {
 	std::vector<DpJob> jobs; std::vector<DpRes> res; std::vector<const uint32_t*> cig; std::vector<int> pending;   // cig[id] points into a per-round CIGAR pool
 	std::unique_ptr<std::deque<uint32_t>> own_cig;   // one-operation CIGARs of the gap fills answered by the identity probe (stable addresses; made on first use: an empty deque already owns 0.5 KB)
 	std::vector<RegTask*> probe_tasks; // regions whose plan left segments with job1 == -2 that have not been probed yet
+	uint64_t a_off = 0;               // device-side planning: index of the query's first compacted anchor in the device array
+	std::vector<RegTask*> to_plan;    // ... regions split off by the last advance pass, waiting for their plan
 	std::vector<WalkAsk> walks;       // device requests raised by the last advance pass
 	std::vector<RegTask*> fins;
 };
@@ -442,6 +448,55 @@ struct Driver {
 		lean_probes = probe_m_max >= 0 && (int64_t)(a - b) * probe_m_max <= std::min(o.zdrop, o.zdrop_inv) && !getenv("PGA_NO_LEAN_PROBES");
 	}
 	bool lean_probes = false;
+	// device-side planning (pga_plan.hip): the anchors stay where the chaining stage left them
+	u128 *d_anchors = nullptr; bool dev_plan = false;
+	PlanParams plan_params() const
+	{
+		PlanParams P; memset(&P, 0, sizeof(P));
+		P.k = k; P.bw = opt.bw; P.bw_long = std::max((int)(opt.bw_long * 1.5 + 1.), (int)(opt.bw * 1.5 + 1.)); P.max_gap = opt.max_gap; P.min_cnt = opt.min_cnt; P.min_chain_score = opt.min_chain_score;
+		P.min_ksw_len = opt.min_ksw_len; P.a = opt.a; P.q = opt.q; P.e = opt.e; P.no_end_flt = (opt.flag & MM_F_NO_END_FLT) ? 1 : 0; P.probe_m_max = lean_probes ? probe_m_max : -1;
+		P.max_sw_mat = opt.max_sw_mat;
+		return P;
+	}
+	// what plan() leaves in a RegTask, from the planner's records (same order of requests: left extension, segments, right extension)
+	void apply_plan(QueryCtx &Q, RegTask &T, const PlanOut &O, const PlanItem *items)
+	{
+		Reg &r = T.r;
+		T.planned = true;
+		if (O.status == 3 || r.cnt == 0) { T.done = true; return; }
+		r.rev = (uint32_t)O.rev, r.rid = O.rid, r.rs = O.r_rs, r.re = O.r_re, r.qs = O.r_qs, r.qe = O.r_qe, r.mlen = O.r_mlen, r.blen = O.r_blen;
+		T.rid = O.rid, T.rev = O.rev;
+		int32_t bw = (int)(opt.bw * 1.5 + 1.);
+		T.bw = bw;
+		T.as1 = O.as1, T.cnt1 = O.cnt1, T.rs = O.rs, T.qs = O.qs, T.rs0 = O.rs0, T.qs0 = O.qs0, T.re0 = O.re0, T.qe0 = O.qe0;
+		if (O.qs > 0 && O.rs > 0)
+			T.left_job = request(Q, T.rev, T.rid, O.qs0, O.qs - O.qs0, O.rs0, O.rs - O.rs0, 1, bw, opt.end_bonus, r.split_inv ? opt.zdrop_inv : opt.zdrop, DP_EXTZ_ONLY | DP_RIGHT | DP_REV_CIGAR);
+		else T.left_done = true, T.rs1 = O.rs, T.qs1 = O.qs;
+		T.segs.reserve(O.n_items);
+		for (uint32_t k2 = 0; k2 < O.n_items; ++k2) {
+			const PlanItem &it = items[k2];
+			Seg sg; sg.i = it.i, sg.rs = it.rs, sg.qs = it.qs, sg.re = it.re, sg.qe = it.qe, sg.i_prev = it.i_prev;
+			if (it.kind == 0) { sg.bw1 = 0; sg.job1 = -2; sg.pm = it.m; }
+			else {
+				sg.bw1 = it.bw1;
+				sg.job1 = request(Q, T.rev, T.rid, sg.qs, sg.qe - sg.qs, sg.rs, sg.re - sg.rs, 0, sg.bw1, -1, opt.zdrop, DP_APPROX_MAX, false);
+				if (it.kind == 1 && spec_len > 0 && opt.zdrop == opt.zdrop_inv && std::max(sg.qe - sg.qs, sg.re - sg.rs) >= spec_len && !have(Q, sg.job1))
+					sg.job2 = second_pass(Q, T, sg, opt.zdrop);
+			}
+			T.segs.push_back(sg);
+		}
+		T.re = O.T_re, T.qe = O.T_qe;
+		if (T.qe < T.qe0 && T.re < T.re0)
+			T.right_job = request(Q, T.rev, T.rid, T.qe, T.qe0 - T.qe, T.re, T.re0 - T.re, 0, bw, opt.end_bonus, opt.zdrop, DP_EXTZ_ONLY);
+	}
+	// target positions of the anchors [from, to) of a query (chain-relative to its first anchor), straight from the device (rare: a z-drop inside a segment)
+	void fetch_tpos(const QueryCtx &Q, int from, int to, std::vector<int32_t> &tp) const
+	{
+		std::vector<u128> tmp((size_t)std::max(0, to - from));
+		if (!tmp.empty()) PGA_HIP(hipMemcpy(tmp.data(), d_anchors + Q.a_off + (uint64_t)from, tmp.size() * sizeof(u128), hipMemcpyDeviceToHost));
+		tp.resize(tmp.size());
+		for (size_t i = 0; i < tmp.size(); ++i) tp[i] = (int32_t)tmp[i].x;
+	}
 
 	static bool have(const QueryCtx &Q, int id) { return id >= 0 && (size_t)id < Q.res.size() && Q.res[(size_t)id].pad == 1; }
 
@@ -667,13 +722,21 @@ struct Driver {
 			if (ez.zdropped) {
 				r.has_p = true;
 				int j = sg.i - 1;
-				while (j >= 0 && A.tpos(T.as1 + j) > sg.rs + ez.max_t) --j;
+				if (!dev_plan) { while (j >= 0 && A.tpos(T.as1 + j) > sg.rs + ez.max_t) --j; }
+				else {
+					// the anchors stayed on the device: the walk looks at those inside the segment and, when the maximum sits in its first bases, at a
+					// few before it (consecutive anchors of a chain are at least one base apart, and the segment starts half a seed behind its first)
+					const int lo = std::max(0, std::max(0, sg.i_prev) - (k >> 1) - 2);
+					std::vector<int32_t> tp; fetch_tpos(Q, T.as1 + lo, T.as1 + sg.i, tp);
+					while (j >= lo && tp[(size_t)(j - lo)] > sg.rs + ez.max_t) --j;
+					if (j < lo && lo > 0) throw std::runtime_error("pga: z-drop split walked past the anchors it fetched");
+				}
 				T.dropped = true;
 				if (j < 0) j = 0;
 				r.dp_score += ez.max;
 				T.re1 = sg.rs + (ez.max_t + 1), T.qe1 = sg.qs + (ez.max_q + 1);
 				if (T.cnt1 - (j + 1) >= opt.min_cnt) {
-					cut_region(r, r2, T.as1 + j + 1 - r.as, qlen, A);
+					cut_region(r, r2, T.as1 + j + 1 - r.as, qlen, A, !dev_plan);
 					if (r2.cnt > 0) { if (sg.ll_deferred) r2_split_inv_ll = sg.ll_job; else if (sg.zcode == 2) r2.split_inv = 1; }
 				}
 				break;
@@ -808,6 +871,39 @@ template <class F> static void parallel_for(size_t n, int n_threads, F f)
 		P.cv_done.wait(lk, [&] { return job.active == 0; });
 	}
 	if (job.err) std::rethrow_exception(job.err);
+}
+
+// ---------------------------------------------------------------- device-side planning of a list of regions (pga_plan.hip)
+static void plan_list(const SeqSet &S, Driver &D, std::vector<std::pair<QueryCtx*, RegTask*>> &list, hipStream_t st, bool verbose)
+{
+	const double t0 = wall_s();
+	std::vector<PlanIn> in(list.size());
+	for (size_t i = 0; i < list.size(); ++i) {
+		const QueryCtx &q = *list[i].first; const Reg &r = list[i].second->r;
+		PlanIn &p = in[i]; memset(&p, 0, sizeof(p));
+		p.a_off = q.a_off; p.n_a = q.n_a; p.as = r.as; p.cnt = r.cnt; p.qlen = q.qlen; p.qid = q.qid; p.base = q.base;
+	}
+	std::vector<PlanOut> out; std::vector<PlanItem> items;
+	plan_regions(in, D.d_anchors, S.bases(), S.d_off.p, S.d_len.p, D.plan_params(), out, items, st);
+	size_t off = 0, n_fb = 0, n_it = 0;
+	for (size_t i = 0; i < list.size(); ++i) {
+		QueryCtx &q = *list[i].first; RegTask &T = *list[i].second;
+		if (out[i].status == 2) {
+			// more long gaps than the kernel keeps: this one region is planned by the host code on a copy of its query's anchors, and the flags it
+			// sets go back to the device (a piece split off later is planned from them)
+			std::vector<u128> tmp((size_t)q.n_a);
+			PGA_HIP(hipMemcpy(tmp.data(), D.d_anchors + q.a_off, tmp.size() * sizeof(u128), hipMemcpyDeviceToHost));
+			q.a = tmp.data();
+			D.plan(q, T);
+			q.a = nullptr;
+			PGA_HIP(hipMemcpy(D.d_anchors + q.a_off + (uint64_t)T.r.as, tmp.data() + T.r.as, (size_t)T.r.cnt * sizeof(u128), hipMemcpyHostToDevice));
+			++n_fb;
+			continue;
+		}
+		D.apply_plan(q, T, out[i], items.data() + off);
+		if (out[i].status == 0) off += out[i].n_items, n_it += out[i].n_items;
+	}
+	if (verbose) fprintf(stderr, "[pga]   plans on the device: %zu regions, %zu records back (%zu regions by the host code), %.4f s\n", list.size(), n_it, n_fb, wall_s() - t0);
 }
 
 // ---------------------------------------------------------------- one set of queries through its rounds
@@ -973,7 +1069,7 @@ struct RoundRunner {
 			for (size_t i = 0; i < q.list.size(); ++i) {
 				RegTask &T = *q.list[i];
 				if (T.is_inv) { if (!T.done) { if (T.fin == 2) T.done = true; else waiting = true; } continue; }
-				if (!T.planned) D.plan(q, T);
+				if (!T.planned) { if (D.dev_plan) { q.to_plan.push_back(&T); waiting = true; continue; } D.plan(q, T); }
 				if (!T.done) {
 					Reg r2; int r2_ll = -1;
 					const bool complete = D.advance(q, T, r2, r2_ll);
@@ -1012,6 +1108,18 @@ struct RoundRunner {
 			q.finished = true; q.pool.clear(); q.list.clear();
 		});
 		return unfinished.load();
+	}
+
+	// device-side planning of the regions the last advance pass split off; returns false if there were none
+	bool run_plans()
+	{
+		if (!D.dev_plan) return false;
+		std::vector<std::pair<QueryCtx*, RegTask*>> list;
+		for (int qi : qs) { QueryCtx &q = Q[(size_t)qi]; for (RegTask *t : q.to_plan) if (!t->planned) list.emplace_back(&q, t); q.to_plan.clear(); }
+		if (list.empty()) return false;
+		std::sort(list.begin(), list.end()); list.erase(std::unique(list.begin(), list.end()), list.end());
+		plan_list(S, D, list, st, verbose);
+		return true;
 	}
 
 	// the device requests the last advance pass raised; returns false if there were none
@@ -1086,7 +1194,7 @@ struct RoundRunner {
 					set_thread_budget(1);
 					ss = stream_lease();
 					one[k].assign(1, open[k]);
-					Driver Dq(S, opt, D.k, ss);
+					Driver Dq(S, opt, D.k, ss); Dq.dev_plan = D.dev_plan; Dq.d_anchors = D.d_anchors;
 					RoundRunner R{S, opt, Dq, Q, out, one[k], set_id * 1000 + (int)k + 1, 1, ss, tm ? &tms[k] : nullptr, P, verbose, {}};
 					R.tail = true;
 					R.run();
@@ -1121,7 +1229,7 @@ struct RoundRunner {
 			int unfinished;
 			harvest_async(false);
 			for (;;) {
-				for (;;) { unfinished = advance_pass(); if (!run_post()) break; }
+				for (;;) { unfinished = advance_pass(); bool more = run_plans(); more |= run_post(); if (!more) break; }
 				if (unfinished == 0) break;
 				bool pend = false; for (int qi : qs) pend |= !Q[(size_t)qi].pending.empty() || !Q[(size_t)qi].probe_tasks.empty();
 				if (pend || asyncs.empty()) break;
@@ -1151,26 +1259,48 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	out.assign((size_t)n_seq, {});
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	Driver D(S, opt, k, st);
+	// planning on the device (pga_plan.hip) whenever the compacted anchors are there and the lean identity probes apply; PGA_HOST_PLAN=1: the
+	// round-3 path (anchors downloaded, planned by the host threads)
+	D.dev_plan = C.d_a.p != nullptr && !C.want_host_anchors && D.lean_probes && (opt.flag & MM_F_CIGAR);
+	D.d_anchors = C.d_a.p;
 	std::vector<QueryCtx> Q((size_t)n_seq);
 	if (verbose) fprintf(stderr, "[pga]   align: contexts of %d queries %.4f s\n", n_seq, wall_s() - t_align0);
 	// ---- regions (mm_gen_regs) and plans ----
+	std::vector<u128> heads; std::vector<uint64_t> head_off((size_t)n_seq + 1, 0);
+	if (D.dev_plan) {
+		// the first anchor of every chain (it salts the region order, hit.c:64-65): gathered on the device
+		std::vector<uint64_t> idx;
+		for (int qi = 0; qi < n_seq; ++qi) {
+			head_off[(size_t)qi] = idx.size();
+			uint64_t start = q_aoff[(size_t)qi];
+			for (int c = 0; c < C.n_u[(size_t)qi]; ++c) { idx.push_back(start); start += (uint32_t)C.u[q_aoff[(size_t)qi] + (uint64_t)c]; }
+		}
+		head_off[(size_t)n_seq] = idx.size();
+		gather_anchors(idx, C.d_a.p, heads, st);
+	}
 	parallel_for((size_t)n_seq, n_threads, [&](size_t qi) {
 		QueryCtx &q = Q[qi];
 		q.qid = (int)qi, q.qlen = (int32_t)S.len[qi], q.rep_len = rep_len[qi]; q.base = (int)S.grp_off[S.grp_of_seq[qi]];
 		const int n_u = C.n_u[qi];
 		if (q.qlen == 0 || n_u == 0) { q.finished = true; return; }
 		const uint64_t b = q_aoff[qi];
-		q.a = C.a.data() + b;
+		q.a = D.dev_plan ? nullptr : C.a.data() + b;
+		q.a_off = b;
 		q.n_a = C.n_v[qi];                          // chains are contiguous and every chain becomes a region: nothing to squeeze (hit.c:311-329)
 		uint32_t salt = !(opt.flag & MM_F_NO_HASH_NAME) ? name_hash31(S.name[qi]) : 0;
 		salt = mix32(salt ^ (mix32((uint32_t)q.qlen) + mix32((uint32_t)opt.seed)));
 		std::vector<Reg> regs;
-		regions_from_chains(salt, q.qlen, n_u, C.u.data() + b, Anchors{q.a, q.n_a}, regs);
+		regions_from_chains(salt, q.qlen, n_u, C.u.data() + b, Anchors{q.a, q.n_a}, regs, D.dev_plan ? heads.data() + head_off[qi] : nullptr);
 		for (auto &r : regs) { q.pool.emplace_back(new RegTask()); q.pool.back()->r = r; q.list.push_back(q.pool.back().get()); }
-		if (!(opt.flag & MM_F_CIGAR)) return;
+		if (!(opt.flag & MM_F_CIGAR) || D.dev_plan) return;
 		for (RegTask *t : q.list) D.plan(q, *t);
 	});
-	if (verbose) fprintf(stderr, "[pga]   align: regions+plans %.3f s (%d threads)\n", wall_s() - t_align0, n_threads);
+	if (D.dev_plan) {
+		std::vector<std::pair<QueryCtx*, RegTask*>> list;
+		for (int qi = 0; qi < n_seq; ++qi) for (RegTask *t : Q[(size_t)qi].list) list.emplace_back(&Q[(size_t)qi], t);
+		plan_list(S, D, list, st, verbose);
+	}
+	if (verbose) fprintf(stderr, "[pga]   align: regions+plans %.3f s (%d threads%s)\n", wall_s() - t_align0, n_threads, D.dev_plan ? ", plans on the device" : "");
 	if (!(opt.flag & MM_F_CIGAR)) {
 		for (int qi = 0; qi < n_seq; ++qi) {
 			QueryCtx &q = Q[(size_t)qi];
@@ -1214,7 +1344,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 			PGA_HIP(hipSetDevice(dev));
 			set_thread_budget(std::max(1, n_threads / n_sets));
 			ss = stream_lease();
-			Driver Ds(S, opt, k, ss);
+			Driver Ds(S, opt, k, ss); Ds.dev_plan = D.dev_plan; Ds.d_anchors = D.d_anchors;
 			RoundRunner R{S, opt, Ds, Q, out, sets[(size_t)s], s, std::max(1, n_threads / n_sets), ss, tm ? &tms[(size_t)s] : nullptr, P, verbose, {}};
 			R.run();
 		} catch (std::exception &e) { errs[(size_t)s] = e.what(); if (errs[(size_t)s].empty()) errs[(size_t)s] = "unknown error"; }

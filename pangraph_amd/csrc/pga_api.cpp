@@ -222,6 +222,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 	double t1 = now_s();
 	mem_log("after seed");
 	ChainResult CR;
+	CR.want_host_anchors = getenv("PGA_HOST_PLAN") != nullptr;            // (default: the anchors stay on the device and the regions are planned there, pga_plan.hip)
 	chain_all(ix.S, SR, opt, ix.I.k, CR, ix.st, &ix.tm, exact_sorts_forced());
 	double t2 = now_s();
 	mem_log("after chain");

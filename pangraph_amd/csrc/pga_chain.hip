@@ -1071,7 +1071,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
                        bool spec, const uint32_t *d_q_tie_x, std::vector<uint32_t> *need_out)
 {
 	if (need_out) need_out->assign((size_t)n_seq, 0u);
-	O.n_u.assign((size_t)n_seq, 0); O.n_v.assign((size_t)n_seq, 0); O.u.clear(); O.a.clear();
+	O.n_u.assign((size_t)n_seq, 0); O.n_v.assign((size_t)n_seq, 0); O.u.clear(); O.a.clear(); O.d_a.release();
 	if (n_a == 0) return;
 	if (n_a >= (1ULL << 31)) throw std::runtime_error("pga: more than 2^31 anchors in one batch");
 	ChainParams P;
@@ -1257,7 +1257,8 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 		}
 	}
 	mark("chains to host");
-	download_to(O.a, out.p, out.n, st);
+	if (O.want_host_anchors) download_to(O.a, out.p, out.n, st);
+	O.d_a = std::move(out);
 	mark("anchors to host");
 	if (vmarks) fprintf(stderr, "[pga]   chain stage, host ms:%s\n", marks.c_str());
 }
@@ -1308,7 +1309,7 @@ void chain_all(const SeqSet &S, SeedResult &SR, const mm_mapopt_t &opt, int k, C
 	DBuf<uint64_t> d_src, d_dst; d_src.upload(src, st); d_dst.upload(dst, st);
 	DBuf<u128> a_sub(n_sub_a ? n_sub_a : 1);
 	hipLaunchKernelGGL(k_gather_queries, dim3((unsigned)n_sub, 64), dim3(256), 0, st, n_sub, d_src.p, d_dst.p, SR.a.p, a_sub.p);
-	ChainResult R;
+	ChainResult R; R.want_host_anchors = O.want_host_anchors;
 	chain_core(a_sub, d_dst, n_sub, n_sub_a, opt, k, R, st, tm, false, nullptr, nullptr);
 	for (int i = 0; i < n_sub; ++i) {
 		const int q = F[(size_t)i];
@@ -1316,8 +1317,10 @@ void chain_all(const SeqSet &S, SeedResult &SR, const mm_mapopt_t &opt, int k, C
 		O.n_u[(size_t)q] = R.n_u[(size_t)i]; O.n_v[(size_t)q] = R.n_v[(size_t)i];
 		if (n == 0) continue;
 		if (R.n_u[(size_t)i] > 0) memcpy(O.u.data() + src[(size_t)i], R.u.data() + dst[(size_t)i], (size_t)R.n_u[(size_t)i] * sizeof(uint64_t));
-		memcpy(O.a.data() + src[(size_t)i], R.a.data() + dst[(size_t)i], n * sizeof(u128));
+		if (O.want_host_anchors) memcpy(O.a.data() + src[(size_t)i], R.a.data() + dst[(size_t)i], n * sizeof(u128));
+		PGA_HIP(hipMemcpyAsync(O.d_a.p + src[(size_t)i], R.d_a.p + dst[(size_t)i], n * sizeof(u128), hipMemcpyDeviceToDevice, st));
 	}
+	PGA_HIP(hipStreamSynchronize(st));
 	if (verbose) fprintf(stderr, "[pga]   chain: the reference's procedure for those %d queries (%llu anchors): %.1f ms\n", n_sub, (unsigned long long)n_sub_a,
 	                     (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3);
 }

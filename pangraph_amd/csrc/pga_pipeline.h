@@ -19,7 +19,9 @@ struct Reg {
 struct ChainResult {
 	std::vector<int32_t> n_u, n_v;   // per query
 	PinVec<uint64_t> u;              // chain i of query q at q_aoff[q]+i: score<<32|cnt
-	PinVec<u128> a;                  // compacted anchors of query q at q_aoff[q] .. +n_v[q]
+	PinVec<u128> a;                  // compacted anchors of query q at q_aoff[q] .. +n_v[q] (only when the host asked for them: want_host_anchors)
+	DBuf<u128> d_a;                  // the same on the device: what the alignment stage plans from (pga_plan.hip)
+	bool want_host_anchors = true;
 };
 
 struct SeedResult {
