@@ -154,10 +154,16 @@ class TaskBatch:
 
 def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], slots: int = 6, cap_bases: float = 1.2e9,
                   min_batch_bases: float = 0.0, done: Optional[set] = None, only: Optional[set] = None,
-                  on_result: Optional[Callable[[List[Task], object, float, float], None]] = None):
+                  on_result: Optional[Callable[[List[Task], object, float, float], None]] = None, express: int = 0, express_eps: float = 0.05,
+                  express_cap: float = 60e6):
     """Runs `tasks` (all of them, or the subset `only`) in dependency order; `run_batch(list of tasks)` is called from up to `slots` host
     threads.  `done`: tids that count as finished from the start (results that arrived from elsewhere).  Returns the batch log
-    [(t_start, t_end, n_tasks, bases)] relative to the start."""
+    [(t_start, t_end, n_tasks, bases)] relative to the start.
+
+    express > 0: that many of the slots are an EXPRESS LANE for the critical path.  A call whose remaining path (Task.prio) is within
+    `express_eps` seconds of the longest remaining path of the whole run is critical; it goes out the moment it is ready, alone or with the
+    few other calls that are just as critical (at most `express_cap` bases), instead of waiting for a slot to come free and then sharing a batch
+    -- and its latency -- with hundreds of Mbp of bulk work.  The bulk uses the other slots as before."""
     want = set(range(len(tasks))) if only is None else set(only)
     fin = set(done or ())
     indeg = {}
@@ -169,16 +175,35 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
     ready = [tid for tid in want if indeg[tid] == 0]
     left = len(want)
     in_flight = 0
+    express = max(0, min(int(express), max(0, slots - 1)))
+    n_express = 0                                   # express batches in flight
+    unfinished = sorted(want - fin, key=lambda tid: -tasks[tid].prio)   # for the longest remaining path
+    pos_top = [0]
+
+    def crit_level():
+        while pos_top[0] < len(unfinished) and unfinished[pos_top[0]] in fin:
+            pos_top[0] += 1
+        return tasks[unfinished[pos_top[0]]].prio if pos_top[0] < len(unfinished) else 0.0
     cv = threading.Condition()
     log, errs = [], []
     t_origin = time.perf_counter()
 
-    def take():
-        nonlocal in_flight
+    def take(kind):
+        nonlocal in_flight, n_express
         # largest remaining path first; stop at the cap (one oversized task still goes alone)
         ready.sort(key=lambda tid: -tasks[tid].prio)
+        if kind == "express":
+            lvl = crit_level() - express_eps
+            got, b = [], 0
+            for tid in ready:
+                if tasks[tid].prio < lvl or (got and b + tasks[tid].bases > express_cap):
+                    break
+                got.append(tid); b += tasks[tid].bases
+            ready[:] = [tid for tid in ready if tid not in set(got)]
+            in_flight += 1; n_express += 1
+            return got
         total = sum(tasks[tid].bases for tid in ready)
-        free = max(1, slots - in_flight)
+        free = max(1, (slots - express) - (in_flight - n_express))
         cap = max(min(cap_bases, total / free if free > 1 else cap_bases), min_batch_bases, 1.0)
         got, b = [], 0
         rest = []
@@ -191,15 +216,27 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
         in_flight += 1
         return got
 
+    def can_take():
+        # what may start now: "express" (a critical call is ready and an express slot is free), "bulk" (a bulk slot is free), or None
+        if not ready:
+            return None
+        if express and n_express < express and max(tasks[tid].prio for tid in ready) >= crit_level() - express_eps:
+            return "express"
+        if in_flight - n_express < slots - express:
+            return "bulk"
+        return None
+
     def worker():
-        nonlocal left, in_flight
+        nonlocal left, in_flight, n_express
         while True:
             with cv:
-                while not ready and left > 0 and not errs:
+                kind = can_take()
+                while kind is None and left > 0 and not errs:
                     cv.wait()
+                    kind = can_take()
                 if left <= 0 or errs:
                     return
-                ids = take()
+                ids = take(kind)
             t0 = time.perf_counter()
             try:
                 res = run_batch([tasks[i] for i in ids])
@@ -210,11 +247,13 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
                 with cv:
                     errs.append(e)
                     in_flight -= 1
+                    n_express -= kind == "express"
                     cv.notify_all()
                 return
             with cv:
                 log.append((t0 - t_origin, t1 - t_origin, len(ids), sum(tasks[i].bases for i in ids)))
                 in_flight -= 1
+                n_express -= kind == "express"
                 for i in ids:
                     fin.add(i)
                     left -= 1
