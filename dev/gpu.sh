@@ -55,6 +55,8 @@ profile)
   stats)
     ( cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o p -- python $R/bench.py $BA --steps 1 --warmup 1 --detail $R/gpurun_out/profiles_out/${ROUND}_${TAG}_bench_under_rocprof_detail.json > $R/gpurun_out/profiles_out/${ROUND}_${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_$TAG.err ); echo "stats rc=$?"
     f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/profiles_out/${ROUND}_${TAG}_c5_kernel_stats.csv
+    kt=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
+    [ -n "$kt" ] && python dev/concurrency.py "$kt" gpurun_out/profiles_out/${ROUND}_${TAG}_kernel_concurrency.json
     find gpurun_out/prof_$TAG \( -name "*.db" -o -name "*kernel_trace.csv" \) -size +20M -delete
     head -22 gpurun_out/profiles_out/${ROUND}_${TAG}_c5_kernel_stats.csv | cut -c1-160 ;;
   traffic)

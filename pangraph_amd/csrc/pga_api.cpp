@@ -635,6 +635,12 @@ extern "C" int pga_warm_streams(int32_t n)
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
+extern "C" void pga_mem_stats(int64_t out[6])
+{
+	long long a[4], b[2]; pga::dev_mem_stats(a); pga::dev_mem_levels(b);
+	for (int i = 0; i < 4; ++i) out[i] = a[i];
+	out[4] = b[0], out[5] = b[1];
+}
 
 // ---- busy intervals (pga_common.h: busy_note) ----
 static_assert(pga::K_COUNT == PGA_N_KERNELS, "pga_stats_t and the busy log number the kernel families alike");

@@ -24,6 +24,7 @@ namespace pga {
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_trim();        // release every idle block
+void dev_mem_levels(long long out[2]);   // bytes handed out, bytes idle in the cache
 void dev_mem_stats(long long out[4]);   // hipMalloc calls, ns spent in them, hipFree calls, ns (since the library was loaded)
 void dev_set_arena(int arena);
 int dev_get_arena();   // calling thread: recycle device blocks only within this arena (one per concurrent sub-batch)

@@ -180,6 +180,7 @@ void stream_release(hipStream_t s)
 }
 
 void dev_mem_stats(long long out[4]) { out[0] = g_n_malloc; out[1] = g_ns_malloc; out[2] = g_n_free; out[3] = g_ns_free; }
+void dev_mem_levels(long long out[2]) { std::lock_guard<std::mutex> lk(g_mu); out[0] = (long long)g_live_total; out[1] = (long long)g_idle_total; }
 
 void dev_trim()
 {
