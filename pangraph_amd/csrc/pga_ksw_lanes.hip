@@ -242,8 +242,18 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 		int sat = 0;
 
 		uint4 nrec = make_uint4(0u, nb_init, (uint32_t)KSW_NEG_INF, 0u);   // the left neighbour wave's record of the previous diagonal
+#ifdef PGA_LANES_PROF
+		// (development: -DPGA_LANES_PROF splits a wave's cycles per diagonal into bookkeeping / cells / maximum / barrier / after-barrier and prints them)
+		long long pf[5] = {0, 0, 0, 0, 0}, pt = 0;
+#define PF_MARK(i) { const long long c_ = clock64(); pf[i] += c_ - pt; pt = c_; }
+#else
+#define PF_MARK(i)
+#endif
 		auto diag_loop = [&](auto EXACT_T, auto RIGHT_T) {
 		constexpr bool EXACT = decltype(EXACT_T)::value, RIGHT = decltype(RIGHT_T)::value;
+#ifdef PGA_LANES_PROF
+		pt = clock64();
+#endif
 		for (int r = 0; r < n_diag; ++r) {
 			r_done = r + 1;
 			int st0, en0;
@@ -295,6 +305,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				S0 = (S0 & ~m0) | (__builtin_amdgcn_perm(0u, sc_tab, nz0 | nn0 << 1) & m0);
 				S1 = (S1 & ~m1) | (__builtin_amdgcn_perm(0u, sc_tab, nz1 | nn1 << 1) & m1);
 			}
+			PF_MARK(0)
 			if (t0 >= st && t0 <= en) {
 				// the column that joins on this diagonal starts from the first-row values
 				if (en >= r && r >= t0 && r < t0 + 8) {
@@ -400,6 +411,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				__builtin_nontemporal_store(((unsigned long long)dd.y << 32) | dd.x, reinterpret_cast<unsigned long long*>(prow + (t0 - st)));
 			}
 			prow += n_col;
+			PF_MARK(1)
 			// ---- H (exact mode): H[t] += v[t] over [st0, en0), H[en0] = H[en0-1](old) + u[en0] (ksw2_extd2_sse.c:325-340), and the
 			// maximum with the reference's tie order (H[en0] first, then four int32 lanes by (t - st0) & 3 over [st0, en1), then the
 			// tail; the first maximum wins) as ONE unsigned key per column:
@@ -449,6 +461,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 					if (h0t + 1 >= t0 && h0t + 1 < t0 + 8) s_h0u[r & 1] = hu;
 				}
 			}
+			PF_MARK(2)
 			{
 				// the wave's record: its key, and x, v, x2, H of its last column for lane 0 of the next wave
 				const uint32_t mine_new = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
@@ -456,6 +469,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				if (lane == 0) *reinterpret_cast<uint4*>(&recs[wave]) = make_uint4(kbest, p63, h63, 0u);
 			}
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			PF_MARK(3)
 			// ---- uniform bookkeeping of the diagonal (every wave, from the records) ----
 			bool stop = false;
 			uint32_t k = 0;
@@ -499,12 +513,17 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 			}
 			if (stop) break;
 			last_st = st, last_en = en;
+			PF_MARK(4)
 		}
 		};
 		if (!approx_max) { if (right) diag_loop(std::true_type{}, std::true_type{}); else diag_loop(std::true_type{}, std::false_type{}); }
 		else { if (right) diag_loop(std::false_type{}, std::true_type{}); else diag_loop(std::false_type{}, std::false_type{}); }
 
 
+#ifdef PGA_LANES_PROF
+		if (lane == 0 && jid == 0) printf("[lanes prof] wave %d: %d diagonals; cycles per diagonal: bookkeeping %lld cells %lld maximum %lld record+barrier %lld after %lld\n", wave, r_done,
+		                                  pf[0] / r_done, pf[1] / r_done, pf[2] / r_done, pf[3] / r_done, pf[4] / r_done);
+#endif
 		// ---- backtrack by wave 0 (ksw2.h:127-159) through a 64x64 LDS window of the direction matrix ----
 		int n_cigar = 0, bi = -1, bj = -1;
 		if (sat) {}                                                 // (no traceback: the problem is redone)
