@@ -72,7 +72,7 @@ def pmc_traffic(kernel: str, launches_per_step: float):
 
 def pmc_issue():
     """VALU / LDS issue fractions of the DP kernels (SQ_ACTIVE_INST_VALU|LDS / SQ_WAVE_CYCLES) from the committed rocprofv3 --pmc passes of this
-    same workload (profiles/r*_pmc_issue_dp_kernels.json, dev/r02_pmc_issue.sh).  NOT measured in this run; None if absent."""
+    same workload (profiles/r*_pmc_issue*kernels.json, dev/gpu.sh profile <tag> issue).  NOT measured in this run; None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue*kernels.json")))
     if not files:
