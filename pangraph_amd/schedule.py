@@ -63,9 +63,10 @@ class Task:
 
 def cost_estimate(bases: int, n_seqs: int) -> float:
     """seconds a task takes alone on the device (rough: a whole-genome pair is bound by its dependency chains, a block set by throughput;
-    round 4, dev/path_probe.py: a spine call of two block sets 15-30 ms, its second round 5-8 ms, a whole-genome pair ~0.2 s)"""
+    round 4, dev/path_probe.py, every call alone on the device: a spine call of two block sets 12-48 ms, its second round 6-10 ms, a
+    whole-genome pair 63 ms; the longest chain of the BASELINE build measures 0.71 s, 0.51 s of it above tree height 4)"""
     big = bases / max(1, n_seqs)
-    return 0.006 + bases * 2.5e-10 + (0.2 if big > 1e6 else 0.0)
+    return 0.006 + bases * 2.5e-10 + (0.05 if big > 1e6 else 0.0)
 
 
 def build_tasks(pop, min_block: int = 100, rounds: int = 2) -> List[Task]:
@@ -323,8 +324,8 @@ def partition_subtrees(pop, tasks: List[Task], world: int, per_rank: int = 4):
 def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu: float, slots: int = 6) -> Dict[str, dict]:
     """What the subtree partition lets N ranks do, from ONE GPU's measurements: a rank cannot finish phase 1 before (a) its share of the bases
     has gone through at the single-GPU throughput and (b) the longest dependency chain of its subtrees has run (cost_estimate per call, the
-    calls of a chain one after the other); phase 2 is the chain of merges above the cut, each shortened by the query split only as far as its
-    per-call floor allows.  A MODEL to hold the first real multi-GPU run against -- not a measurement."""
+    calls of a chain one after the other); phase 2 is the merges above the cut level by level, each level shortened by the query split only as far
+    as the per-call floor allows.  A MODEL to hold the first real multi-GPU run against -- not a measurement."""
     out = {}
     total = float(sum(t.bases for t in tasks))
     for n in worlds:
@@ -340,8 +341,20 @@ def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu
             load[owner[tid]] += t.bases
         crit = [max((longest[t.tid] for t in tasks if owner[t.tid] == r), default=0.0) for r in range(max(1, n))]
         phase1 = max(max(load[r] / 1e9 / gbp_s_one_gpu, crit[r]) for r in range(max(1, n)))
+        # phase 2 as bench.py runs it: the calls above the cut level by level (a level = the calls whose dependencies are done, ONE batch that
+        # all ranks work on with the queries split): a level waits for its slowest call's floor, its bases go through n ranks
         top = [t for t in tasks if owner[t.tid] < 0]
-        phase2 = sum(max(0.006, cost_estimate(t.bases, len(t.seqs)) / n) for t in top)
+        done = {t.tid for t in tasks if owner[t.tid] >= 0}
+        left = [t.tid for t in top]
+        phase2 = 0.0
+        while left:
+            level = [i for i in left if all(d in done for d in tasks[i].deps)]
+            if not level:
+                break
+            floor = max(cost_estimate(0, 1) + (cost_estimate(tasks[i].bases, len(tasks[i].seqs)) - cost_estimate(0, 1)) / n for i in level)
+            phase2 += max(floor, sum(tasks[i].bases for i in level) * 2.5e-10 / n + cost_estimate(0, 1))
+            done.update(level)
+            left = [i for i in left if i not in done]
         step = phase1 + phase2
         out[str(n)] = {"per_rank_gbp": [round(x / 1e9, 6) for x in load], "per_rank_critical_path_s": [round(x, 3) for x in crit], "calls_above_the_cut": len(top),
                        "phase1_s": round(phase1, 3), "phase2_s": round(phase2, 3), "step_s": round(step, 3), "gbp_s": round(total / 1e9 / step, 2) if step > 0 else None}
