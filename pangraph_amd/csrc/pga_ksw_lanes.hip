@@ -244,7 +244,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 		uint4 nrec = make_uint4(0u, nb_init, (uint32_t)KSW_NEG_INF, 0u);   // the left neighbour wave's record of the previous diagonal
 #ifdef PGA_LANES_PROF
 		// (development: -DPGA_LANES_PROF splits a wave's cycles per diagonal into bookkeeping / cells / maximum / barrier / after-barrier and prints them)
-		long long pf[5] = {0, 0, 0, 0, 0}, pt = 0;
+		long long pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
 #define PF_MARK(i) { const long long c_ = clock64(); pf[i] += c_ - pt; pt = c_; }
 #else
 #define PF_MARK(i)
@@ -259,8 +259,9 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 			int st0, en0;
 			diag_range_l(r, qlen, tlen, w, st0, en0);
 			if (st0 > en0) { ez_zdropped = 1; break; }
-			const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
-			const int span = ((en0 - st0) / 16 + 1) * 16;
+			const int st = st0 & ~15, en = ((en0 + 16) & ~15) - 1;         // (0 <= st0 <= en0: the reference's divisions by 16 are shifts)
+			const int span = ((en0 - st0) & ~15) + 16;
+			PF_MARK(8)
 			if (row_o == 0) {
 				if (tid == 0) want_chunk(row_c + 1);                 // one chunk ahead: visible behind this diagonal's barrier
 				const uint32_t chunk_id = s_chunk[row_c];
@@ -268,6 +269,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				prow = pool_base + (size_t)chunk_id * CHUNK;
 			}
 			if (++row_o == rpc) row_o = 0, ++row_c;
+			PF_MARK(5)
 			int need_hi = en > st0 + span - 1 ? en : st0 + span - 1;
 			if (need_hi > T - 1) need_hi = T - 1;
 			// a lane whose block fell out of the band on the left takes the block one ring further right (fresh rows)
@@ -282,6 +284,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 			// query byte of the block's first column (requested one diagonal ahead: its LDS latency hides behind the barrier)
 			W1 = W1 << 8 | W0 >> 24; W0 = W0 << 8 | q_next;
 			{ const int j = r + 1 - t0; const uint32_t qb = qq[j < 0 ? 0 : j >= qlen ? qlen - 1 : j]; q_next = (unsigned)j < (unsigned)qlen ? qb : 0u; }
+			PF_MARK(6)
 			// left neighbour: x, v, x2 and H of column t0-1 as the previous diagonal left them (an int8 is the top byte of its half)
 			const uint32_t mine = __builtin_amdgcn_perm((uint32_t)as_i(X2[3]), __builtin_amdgcn_perm((uint32_t)as_i(V[3]), (uint32_t)as_i(X[3]), 0x0c0c0703u), 0x0c070100u);
 			uint32_t inc = (uint32_t)wave_shr1((int)mine, (int)nrec.y);
@@ -292,6 +295,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				const bool fresh_edge = st == 0 || !(st - 1 >= last_st && st - 1 <= last_en);     // (uniform)
 				inc = (t0 == st && fresh_edge) ? (c1 | v1 << 8 | c2 << 16) : inc;
 			}
+			PF_MARK(7)
 			// score bytes of the columns in [st0, st0+span) (the others keep what an earlier diagonal left there)
 			{
 				int lo = st0 - t0, hi = (st0 + span < T ? st0 + span : T) - t0;
@@ -424,21 +428,41 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 					const int e1 = st0 + (en0 - st0) / 4 * 4 - t0;           // class of column i: (i - lo) & 3 below e1, 4 from there on
 					const uint32_t lowbase = 4095u - (uint32_t)(t0 - st) + (32768u << 16);
 					const uint32_t span_u = (uint32_t)(hi - lo);
-					const bool r0 = r == 0, e0 = en0 == 0;
+					// (the first diagonal and en0 == 0 -- the same diagonal unless the target is one base long -- take H[en0] from elsewhere: a
+					// uniform case of its own, so that the eight columns of every other diagonal are straight-line selects: written as one loop
+					// with the three-way choice inside, the compiler emitted six scalar branches per column)
 					int prev_old = hp_in;
+					if (r != 0 && en0 != 0) {
 #pragma unroll
-					for (int i = 0; i < 8; ++i) {
-						const uint32_t rel = (uint32_t)(i - lo);
-						const bool in = rel < span_u, is_en = i == hi;
-						const int hold = H[i], vn = col8(V, i);
-						const int hen = r0 ? vn - qe_h : e0 ? hold + vn : prev_old + col8(U, i);
-						const int h = is_en ? hen : in ? hold + vn : hold;
-						H[i] = h;
-						prev_old = hold;
-						const uint32_t field = is_en ? 8u : 7u - (i < e1 ? (rel & 3u) : 4u);
-						const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;        // (v_med3_i32)
-						const uint32_t key = ((uint32_t)hc << 16) + (lowbase - (uint32_t)i + (field << 12));
-						kbest = (in | is_en) && key > kbest ? key : kbest;
+						for (int i = 0; i < 8; ++i) {
+							const uint32_t rel = (uint32_t)(i - lo);
+							const bool in = rel < span_u, is_en = i == hi;
+							const int hold = H[i];
+							const int hin = hold + col8(V, i), hen = prev_old + col8(U, i);
+							const int h = is_en ? hen : in ? hin : hold;
+							H[i] = h;
+							prev_old = hold;
+							const uint32_t field = is_en ? 8u : 7u - (i < e1 ? (rel & 3u) : 4u);
+							const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;        // (v_med3_i32)
+							const uint32_t key = ((uint32_t)hc << 16) + (lowbase - (uint32_t)i + (field << 12));
+							kbest = (in | is_en) && key > kbest ? key : kbest;
+						}
+					} else {
+						const bool r0 = r == 0;
+#pragma unroll
+						for (int i = 0; i < 8; ++i) {
+							const uint32_t rel = (uint32_t)(i - lo);
+							const bool in = rel < span_u, is_en = i == hi;
+							const int hold = H[i], vn = col8(V, i);
+							const int hen = r0 ? vn - qe_h : hold + vn;
+							const int h = is_en ? hen : in ? hold + vn : hold;
+							H[i] = h;
+							prev_old = hold;
+							const uint32_t field = is_en ? 8u : 7u - (i < e1 ? (rel & 3u) : 4u);
+							const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;
+							const uint32_t key = ((uint32_t)hc << 16) + (lowbase - (uint32_t)i + (field << 12));
+							kbest = (in | is_en) && key > kbest ? key : kbest;
+						}
 					}
 					// the two values the end-of-sequence scores need, while the diagonal runs along the last target column / query row
 					if (en0 == tlen - 1 || r - st0 == qlen - 1) {          // (uniform: only while the diagonal runs along an edge of the matrix)
@@ -521,8 +545,8 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 
 
 #ifdef PGA_LANES_PROF
-		if (lane == 0 && jid == 0) printf("[lanes prof] wave %d: %d diagonals; cycles per diagonal: bookkeeping %lld cells %lld maximum %lld record+barrier %lld after %lld\n", wave, r_done,
-		                                  pf[0] / r_done, pf[1] / r_done, pf[2] / r_done, pf[3] / r_done, pf[4] / r_done);
+		if (lane == 0 && jid == 0) printf("[lanes prof] wave %d: %d diagonals; cycles per diagonal: ranges %lld chunk %lld ring+window %lld neighbour %lld score bytes %lld | cells %lld maximum %lld record+barrier %lld after %lld\n", wave, r_done,
+		                                  pf[8] / r_done, pf[5] / r_done, pf[6] / r_done, pf[7] / r_done, pf[0] / r_done, pf[1] / r_done, pf[2] / r_done, pf[3] / r_done, pf[4] / r_done);
 #endif
 		// ---- backtrack by wave 0 (ksw2.h:127-159) through a 64x64 LDS window of the direction matrix ----
 		int n_cigar = 0, bi = -1, bj = -1;
