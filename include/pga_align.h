@@ -195,8 +195,10 @@ void pga_free(void *p);
  * Output (freed with pga_rc_free): per block its kind, its consensus afterwards and its majority edits; per member (input order) its edits
  * against that consensus as a pga_mapvar_res_t (offsets into out->subs / dels / inss; kind 0: the input edits).  A negative kind is the
  * reference's error for that block (-2 a majority letter equals the consensus letter, -3 empty consensus, -4 no aligned position,
- * -5 a member holds a substitution and a deletion, or two substitutions, at one position); member status 7: no aligned position
- * (map_variations.rs:32), otherwise the codes of pga_map_variations.  Returns 0, or -1 with the message in pga_last_error(). */
+ * -5 a member holds a substitution and a deletion, or two substitutions, at one position); a block with a negative kind comes back with its
+ * ORIGINAL consensus and the original edits of every member (status: the member's own code).  Member status 7: no aligned position
+ * (map_variations.rs:32), otherwise the codes of pga_map_variations -- a caller checks the member status also when kind == 2 (a member
+ * without an aligned position does not fail its block).  Returns 0, or -1 with the message in pga_last_error(). */
 typedef struct { const char *consensus; uint32_t cons_len, n_members; } pga_rc_block_t;
 typedef struct { uint32_t n_subs, n_dels, n_inss; } pga_rc_member_t;
 typedef struct {

@@ -130,6 +130,9 @@ static void check_supported(const mm_mapopt_t &o, int k, int w)
 	if (-(-o.b) > 2 * (o.q + o.e) && o.b > 2 * (o.q + o.e)) throw std::runtime_error("pga: mismatch penalty larger than 2*(q+e) disables the reference DP");
 	if (k > 28 || k < 1 || w < 1 || w > 255) throw std::runtime_error("pga: k must be in [1,28] and w in [1,255]");
 	if (o.sdust_thres > 0) throw std::runtime_error("pga: SDUST masking is not implemented");
+	// the inversion test (ksw_ll_i16, align.c:845-855) runs over windows of up to max_gap bases and the device kernel holds 10 240: refused
+	// here, by name, instead of in the middle of a batch (every asm preset has max_gap = 5 000 or 10 000)
+	if (o.max_gap > 10240) throw std::runtime_error("pga: max_gap = " + std::to_string(o.max_gap) + " is larger than the 10240 bases the ksw_ll_i16 kernel holds (pangraph's presets: at most 10000)");
 }
 
 static void idx_sketch_index(PgaIdx &ix)

@@ -466,6 +466,11 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 	for (size_t i = 0; i < mvj_member.size(); ++i) mv_of_member[mvj_member[i]] = i;
 	for (int64_t b = 0; b < n_blocks; ++b) {
 		pga_rc_block_res_t &r = R[b];
+		// a block whose reconciliation failed for ANY member is an error as a whole (the reference returns Err for the call): decided before
+		// anything of the block is packed, so that it comes back with its ORIGINAL consensus and the original edits of every member
+		if (r.kind == 1)
+			for (uint64_t m = mem_first[b]; m < mem_first[b + 1] && r.kind == 1; ++m)
+				if (rj_of_member[m] != (size_t)-1 && r_st[rj_of_member[m]] != 0) r.kind = -5;
 		r.cons_off = o_cons.size();
 		if (r.kind == 2) { r.cons_len = nc[b].len; o_cons.insert(o_cons.end(), new_cons_all.begin() + nc[b].off, new_cons_all.begin() + nc[b].off + nc[b].len); }
 		else {
@@ -484,7 +489,6 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 			if (r.kind == 1 && rj_of_member[m] != (size_t)-1) {
 				const size_t i = rj_of_member[m];
 				o.status = r_st[i];
-				if (r_st[i] != 0) { r.kind = -5; copy_in(true); continue; }
 				o.n_subs = r_n[i]; o_subs.insert(o_subs.end(), r_subs.begin() + rj[i].out_off, r_subs.begin() + rj[i].out_off + r_n[i]);
 				copy_in(false);
 			} else if (r.kind == 2 && mv_of_member[m] != (size_t)-1) {
@@ -496,7 +500,7 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 				o_dels.insert(o_dels.end(), v_dels.begin() + v.del_off, v_dels.begin() + v.del_off + v.n_dels);
 				for (uint32_t t = 0; t < v.n_inss; ++t) { const pga_ins_t &x = v_inss[v.ins_off + t]; o_inss.push_back(pga_ins_t{x.pos, x.len, (uint64_t)o_iseq.size()}); o_iseq.insert(o_iseq.end(), v_iseq.begin() + x.seq_off, v_iseq.begin() + x.seq_off + x.len); }
 			} else if (r.kind == 2) { /* status already set: the member has no aligned position */ }
-			else copy_in(true);
+			else { if (r.kind == -5 && rj_of_member[m] != (size_t)-1) o.status = r_st[rj_of_member[m]]; copy_in(true); }
 		}
 	}
 	out->blocks = dup_pool(R); out->members = dup_pool(MR);

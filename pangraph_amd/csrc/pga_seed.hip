@@ -388,6 +388,7 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	DBuf<uint64_t> &x0 = O.raw_x, &y0 = O.raw_y, &x1 = O.srt_x, &y1 = O.srt_y;
 	x0.alloc(n_a); y0.alloc(n_a); x1.alloc(n_a); y1.alloc(n_a);
 	hipLaunchKernelGGL(k_anchor_pack, dim3(nbk), dim3(256), 0, st, n_kept, cnt.p, ub_off.p, ub.p, a_off.p, x0.p, y0.p);
+	ub.release();            // (the upper-bound layout holds every occurrence, about twice the anchors: back to the arena -- in stream order -- before the sort's buffers are taken)
 	{
 		// anchors are already grouped by query, so a device-wide stable sort by x followed by a stable sort by the
 		// query id (LSD order) equals a per-query sort, without the one-block-per-segment cost of a segmented sort

@@ -131,3 +131,19 @@ def test_random_blocks_vs_restatement(gpu_lib, oracle_lib):
         for e, old in zip(g[2], members):                                          # the members are still the same sequences
             assert rc.apply_edit(new_cons, _norm(e)) == rc.apply_edit(cons, old)
     assert min(kinds) > 5, kinds
+
+
+def test_a_block_whose_reconciliation_fails_comes_back_untouched(gpu_lib):
+    """apply_substitutions_to_block (edits.rs:196-238) fails for a member that holds two substitutions at one position: the reference returns Err
+    for the call; here the block reports kind -5 with its ORIGINAL consensus and every member's original edits (decided before anything of the
+    block is packed), the member carries its own status, and the other blocks of the call are unaffected."""
+    from pangraph_amd.reconsensus import reconsensus
+    bad = ("ATCGAATTCC", [E(subs=[(2, "G")]), E(subs=[(2, "G")]), E(subs=[(2, "T"), (2, "A")]), E(subs=[(2, "G")])])
+    ok = ("ATCGAATTCC", [E(subs=[(2, "G")]), E(subs=[(2, "G")]), E(subs=[(5, "C")])])
+    got = reconsensus([ok, bad, ok], dll=gpu_lib.dll)
+    assert got[1][0] == -5 and got[1][1] == bad[0]
+    assert [_norm(e) for e in got[1][2]] == bad[1]
+    assert got[1][4][2] != 0 and got[1][4][0] == 0
+    for g in (got[0], got[2]):
+        assert g[0] == 1 and g[1] == "ATGGAATTCC" and all(s == 0 for s in g[4])
+        assert [_norm(e) for e in g[2]] == [E(), E(), E(subs=[(2, "C"), (5, "C")])]
