@@ -1,7 +1,7 @@
 """What is the CRITICAL PATH of the build?  Every find_matches call of tree height >= HMIN alone on the device (one batch per call, inputs
 resident), its wall time and stage split; then the longest dependency chain through those calls with the measured times, and the slowest
 calls (set VERBOSE_TOP=k to re-run the k slowest under PGA_VERBOSE=1 on stderr).
-    HMIN=5 python dev/path_probe.py
+    HMIN=5 python dev/path_probe.py          (VERBOSE_TOP=k: the k slowest calls of the chain again under PGA_VERBOSE=1; VERBOSE_CALL=h17r1: that one)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,6 +59,15 @@ for tid in path:
     print(f"  h{pop.nodes[t.node].height:2d} r{t.round} n_seq={len(t.seqs):6d} Mbp={t.bases / 1e6:6.1f} matches={int(st['n_matches']):5d} anchors={int(st['n_anchors']):8d} dp_jobs={int(st['n_dp_jobs']):6d} | {1e3 * dt:7.1f} ms | " +
           " ".join(f"{k} {1e3 * st[k]:.1f}" for k in keys))
 k = int(os.environ.get("VERBOSE_TOP", "0"))
+want = os.environ.get("VERBOSE_CALL")                      # e.g. "h17r1": that call of the chain again under PGA_VERBOSE=1
+if want:
+    os.environ["PGA_VERBOSE"] = "1"
+    for tid in path:
+        t = tasks[tid]
+        if f"h{pop.nodes[t.node].height}r{t.round}" == want:
+            sys.stderr.write(f"==== call {want} n_seq={len(t.seqs)} Mbp={t.bases / 1e6:.1f}: {1e3 * solo[tid][0]:.1f} ms alone\n"); sys.stderr.flush()
+            run(t)
+    os.environ.pop("PGA_VERBOSE")
 if k:
     os.environ["PGA_VERBOSE"] = "1"
     for tid in sorted(path, key=lambda i: -solo[i][0])[:k]:

@@ -352,7 +352,7 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //   11     like 10 with ONE wave per problem: rings of up to 512 columns (end extensions next to a block end, narrow banded fills)
 //   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
 //          first passes of class 4 keep room for their sequences in LDS)
-#define DP_NCLASS 12
+#define DP_NCLASS 13
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -384,6 +384,16 @@ int wstrips_count(const DpJob &j);
 size_t wstrips_bnd_words(const DpJob &j);
 void launch_wstrips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, const uint32_t *blk_strip, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                     unsigned long long *bnd, const uint64_t *bnd_off, uint32_t *done_ctr, DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
+int bstrips_mode();
+int bstrips_max_problems();
+int bstrips_long_diagonals();
+bool bstrips_eligible(const DpJob &j, const DpParams &P);
+size_t bstrips_slab_bytes(const DpJob &j);
+size_t bstrips_words(const DpJob &j);
+uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab);
+void launch_bstrips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
+                    unsigned long long *bnd, const uint64_t *bnd_off, const uint32_t *tab, const uint64_t *tab_off, DpRes *res, uint32_t *pool, unsigned long long *cursor,
+                    unsigned long long pool_cap, hipStream_t st);
 bool lanes_eligible(const DpJob &j, int nt);
 size_t lanes_cig_bytes(int q_cap, int t_cap);
 size_t lanes_chunk_bytes(int nt);
@@ -544,6 +554,35 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		};
 		{ std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(fill, t); fill(0); for (auto &x : th) x.join(); }
 	}
+	// class 12 (banded wave strips, pga_ksw_bstrips.hip): a launch that holds only a few banded exact problems is bound by the latency of ONE
+	// of them on one CU -- those go over several CUs each; a launch that holds thousands fills the device with the lane kernel and keeps them,
+	// but for its few longest (an extension that runs its band out: 20 k diagonals)
+	if (allow_band && bstrips_mode() > 0) {
+		std::vector<uint32_t> &from = cls[10];
+		std::vector<uint32_t> elig, keep;
+		for (uint32_t id : from) (bstrips_eligible(jobs[id], P) ? elig : keep).push_back(id);
+		const size_t cap = (size_t)std::max(1, bstrips_max_problems());
+		std::vector<uint32_t> take;
+		if (bstrips_mode() == 2 || elig.size() <= cap) take = elig;
+		else {
+			// the longest ones only, as far as a z-drop can let them run: nominal diagonals above the threshold, largest first
+			std::vector<uint32_t> lg;
+			for (uint32_t id : elig) if (jobs[id].qlen + jobs[id].tlen - 1 >= bstrips_long_diagonals()) lg.push_back(id);
+			std::stable_sort(lg.begin(), lg.end(), [&](uint32_t a, uint32_t b) { return jobs[a].qlen + jobs[a].tlen > jobs[b].qlen + jobs[b].tlen; });
+			if (lg.size() > cap / 4) lg.resize(cap / 4);                  // (most of a bulk round's extensions are long by this measure and z-drop early: a handful, not all)
+			take = lg;
+		}
+		if (!take.empty()) {
+			std::vector<uint8_t> mark(n, 0);
+			for (uint32_t id : take) mark[id] = 1;
+			std::vector<uint32_t> rest;
+			for (uint32_t id : from) if (!mark[id]) rest.push_back(id);
+			from.swap(rest);
+			std::sort(take.begin(), take.end());
+			cls[12] = take;
+			for (uint32_t id : take) { cls_of[id] = 12; need[id] = bstrips_slab_bytes(jobs[id]); slab_max[12] = std::max(slab_max[12], need[id]); }
+		}
+	}
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
 	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
@@ -552,10 +591,10 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
-	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd; DBuf<uint64_t> d_slab_off, d_bnd_off; };   // (class 9: block tables, strip boundaries)
+	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off; };   // (class 9: block tables, strip boundaries)
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
 	// scratch budget per class: a slab is n_waves x the largest problem of the class, and n_waves is halved until it fits.  24 GB keeps
@@ -581,7 +620,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		size_t n_waves = c == 11 ? 256 * (size_t)(getenv("PGA_C11_WAVES") ? atoi(getenv("PGA_C11_WAVES")) : 10) : c == 10 ? 256 * (size_t)(getenv("PGA_C10_WAVES") ? atoi(getenv("PGA_C10_WAVES")) : 2) : c == 8 ? 256 * (size_t)c8w : (c == 6 || c == 7) ? 256 : c == 5 ? 256 * 2 : c == 4 ? 256 : c == 3 ? 256 * 2 : c == 2 ? 256 * (getenv("PGA_C2_WAVES") ? atoi(getenv("PGA_C2_WAVES")) : 6) : 256 * 16;
 		if (n_waves > cls[c].size()) n_waves = cls[c].size();
 		if (c == 8) n_waves = std::min<size_t>(n_waves, (cls[c].size() + 1) / 2);      // a wave takes two problems at a time
-		if (c == 9) {                                                                   // every problem of the class is in flight at once, each with its whole matrix
+		if (c == 9 || c == 12) {                                                        // every problem of the class is in flight at once, each with its whole matrix
 			size_t tot = 0; for (uint32_t id : cls[c]) tot += need[id];
 			waves_of[c] = cls[c].size();
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], tot);
@@ -618,7 +657,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
-	static const int launch_order[DP_NCLASS] = {9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
+	static const int launch_order[DP_NCLASS] = {12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
 		if (cls[c].empty()) continue;
@@ -634,7 +673,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
 		X.d_jobs.alloc(ids.size());
 		X.d_r.alloc(ids.size());
-		X.d_cnt.alloc(c == 9 ? ids.size() : 2);               // (class 10: [1] is the cursor of its chunk pool)                // (class 9: one completion counter per problem)
+		X.d_cnt.alloc(c == 9 ? ids.size() : 2);               // (class 12 keeps its counters in the problems' control blocks)               // (class 10: [1] is the cursor of its chunk pool)                // (class 9: one completion counter per problem)
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
@@ -663,6 +702,24 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			if (ws) launch_wstrips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 			else
 			launch_approx_strips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else if (c == 12) {
+			std::vector<uint32_t> bj, tab; std::vector<uint64_t> so(ids.size()), bo(ids.size()), to(ids.size());
+			uint64_t s_acc = 0, b_acc = 0;
+			for (size_t i = 0; i < ids.size(); ++i) {
+				const DpJob &j = jobs[ids[i]];
+				so[i] = s_acc; s_acc += need[ids[i]];
+				bo[i] = b_acc; b_acc += bstrips_words(j);
+				to[i] = tab.size();
+				const uint32_t pool_waves = bstrips_table(j, tab);
+				for (uint32_t k2 = 0; k2 < pool_waves; ++k2) bj.push_back((uint32_t)i);
+			}
+			// (blocks of one problem are consecutive: the waves of a pool are dispatched together)
+			X.d_blk_job.upload(bj, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs); X.d_tab.upload(tab, cs); X.d_tab_off.upload(to, cs);
+			X.d_bnd.alloc(((size_t)b_acc + 1) * 2); X.d_bnd.zero(cs);
+			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
+			X.n_waves = bj.size();
+			launch_bstrips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_tab.p, X.d_tab_off.p,
+			               X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
 			int t_cap = 16;
@@ -702,7 +759,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		PGA_HIP(hipEventSynchronize(X.e1));
 		float msf = 0, ms_off = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1)); (void)hipEventElapsedTime(&ms_off, ready, X.e0);
 		const double ms = msf;
-		busy_note(c == 6 ? K_LL : c == 8 ? K_BAND : c == 9 ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE, X.e0, X.e1);
+		busy_note(c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE, X.e0, X.e1);
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
@@ -737,11 +794,11 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 				part_b[(size_t)s] += bases; part_c[(size_t)s] += cells;
 			});
 			double bases = 0, cells = 0; for (double x : part_b) bases += x; for (double x : part_c) cells += x;
-			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : c == 9 ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
+			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->kern[kk].cells += cells; tm->dp_bases += bases;
 		}
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
-		if (((c >= 2 && c <= 4) || c == 7 || c == 10 || c == 11) && verbose) {
+		if (((c >= 2 && c <= 4) || c == 7 || c == 10 || c == 11 || c == 12) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
