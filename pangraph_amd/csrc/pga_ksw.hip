@@ -555,12 +555,13 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		{ std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(fill, t); fill(0); for (auto &x : th) x.join(); }
 	}
 	// class 12 (banded wave strips, pga_ksw_bstrips.hip): a launch that holds only a few banded exact problems is bound by the latency of ONE
-	// of them on one CU -- those go over several CUs each; a launch that holds thousands fills the device with the lane kernel and keeps them,
-	// but for its few longest (an extension that runs its band out: 20 k diagonals)
+	// of them on one CU -- those go over several CUs each; a launch that holds more keeps them on the lane kernels, but for its few longest (an
+	// extension that runs its band out: 20 k diagonals).  "Few" is 8 (PGA_BSTRIPS_MAX): with six batches in flight, 20 or 48 problems per launch
+	// on strips (50 waves each, a zeroed 25 MB of boundary words each) make a step 4 and 9 % SLOWER, 8 leave it where it is; alone on the device
+	// a second self-merge round falls from 6.3 to 3.5 ms and the 20 k-diagonal extension from 48 to 17.5 ms
 	if (allow_band && bstrips_mode() > 0) {
-		std::vector<uint32_t> &from = cls[10];
-		std::vector<uint32_t> elig, keep;
-		for (uint32_t id : from) (bstrips_eligible(jobs[id], P) ? elig : keep).push_back(id);
+		std::vector<uint32_t> elig;
+		for (int c : {10, 11}) for (uint32_t id : cls[c]) if (bstrips_eligible(jobs[id], P)) elig.push_back(id);
 		const size_t cap = (size_t)std::max(1, bstrips_max_problems());
 		std::vector<uint32_t> take;
 		if (bstrips_mode() == 2 || elig.size() <= cap) take = elig;
@@ -569,15 +570,22 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			std::vector<uint32_t> lg;
 			for (uint32_t id : elig) if (jobs[id].qlen + jobs[id].tlen - 1 >= bstrips_long_diagonals()) lg.push_back(id);
 			std::stable_sort(lg.begin(), lg.end(), [&](uint32_t a, uint32_t b) { return jobs[a].qlen + jobs[a].tlen > jobs[b].qlen + jobs[b].tlen; });
-			if (lg.size() > cap / 4) lg.resize(cap / 4);                  // (most of a bulk round's extensions are long by this measure and z-drop early: a handful, not all)
+			if (lg.size() > std::max<size_t>(2, cap / 4)) lg.resize(std::max<size_t>(2, cap / 4));   // (most of a bulk round's extensions are long by this measure and z-drop early: a handful, not all)
 			take = lg;
+		}
+		{	// whatever the policy took: no more than 8 GB of matrices and boundary words per launch (the rest stays with the lane kernels)
+			size_t bytes = 0, kept = 0;
+			for (; kept < take.size(); ++kept) { bytes += bstrips_slab_bytes(jobs[take[kept]]) + 8 * bstrips_words(jobs[take[kept]]); if (bytes > ((size_t)8 << 30)) break; }
+			take.resize(kept);
 		}
 		if (!take.empty()) {
 			std::vector<uint8_t> mark(n, 0);
 			for (uint32_t id : take) mark[id] = 1;
-			std::vector<uint32_t> rest;
-			for (uint32_t id : from) if (!mark[id]) rest.push_back(id);
-			from.swap(rest);
+			for (int c : {10, 11}) {
+				std::vector<uint32_t> rest;
+				for (uint32_t id : cls[c]) if (!mark[id]) rest.push_back(id);
+				cls[c].swap(rest);
+			}
 			std::sort(take.begin(), take.end());
 			cls[12] = take;
 			for (uint32_t id : take) { cls_of[id] = 12; need[id] = bstrips_slab_bytes(jobs[id]); slab_max[12] = std::max(slab_max[12], need[id]); }

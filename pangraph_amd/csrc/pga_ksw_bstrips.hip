@@ -22,11 +22,12 @@
 //     counter: a strip only ever waits for the strip before it, which an earlier taker holds or has finished, so the pipeline cannot deadlock
 //     however few of the pool's waves are resident.
 //   * z-drop while the strips run: the keys of a diagonal (one packed key per strip: clamped H, the reference's tie class, column) are combined
-//     by atomicMax; the wave that completes a block of 64 diagonals last (a counter per block against the number of strips alive in it) takes the
-//     reference's per-diagonal decisions for that block, in order (ksw2_extd2_sse.c:326-366, ksw2.h:167-184; one evaluator at a time, state in the
-//     problem's control block), and raises a stop flag on a z-drop; strips look at the flag once per block.  Strips run at most the pipeline's
-//     depth beyond the stopping diagonal; what they write there nobody reads.
-// The last wave of the pool to leave walks the path back (ksw2.h:127-159) through a 64 x 64 LDS window.  A clamped maximum hands the problem
+//     by atomicMax; every strip counts the blocks of 64 diagonals it has completed, and ONE more wave of the pool, the problem's EVALUATOR, waits
+//     for a block's counter to reach the number of strips alive in it and takes the reference's per-diagonal decisions for that block, in order
+//     (ksw2_extd2_sse.c:326-366, ksw2.h:167-184); a z-drop raises the stop flag, strips look at it once per block.  (The strip that completes a
+//     block last is the rightmost, the one every later strip waits for: when it also evaluated the block, a diagonal cost 1.15 us instead of
+//     0.55.)  Strips run at most the pipeline's depth beyond the stopping diagonal; what they write there nobody reads.
+// The evaluator then walks the path back (ksw2.h:127-159) through a 64 x 64 LDS window.  A clamped maximum hands the problem
 // back (n_cigar = -9: the workgroup kernel redoes it).  Parity: tests/test_gpu_parity.py (PGA_BSTRIPS=force sends every eligible problem here).
 #include "pga_common.h"
 #include "pga_dp.h"
@@ -44,11 +45,8 @@ namespace pga {
 #define EZ_EXTZ_ONLY  0x40
 #define EZ_REV_CIGAR  0x80
 
-struct BsCtl {                         // one per problem, zeroed before the launch
-	uint32_t next_strip, stop, eval_next, eval_lock, done_waves, sat, pad0, pad1;
-	int32_t ez_max, ez_max_t, ez_max_q, ez_mqe, ez_mqe_t, ez_mte, ez_mte_q, ez_score, ez_zdropped, ez_init, r_end, pad2;
-};
-static_assert(sizeof(BsCtl) == 80, "control block: ten 64-bit words");
+struct BsCtl { uint32_t next_strip, stop, roles, pad[5]; };      // one per problem, zeroed before the launch
+static_assert(sizeof(BsCtl) == 32, "control block: four 64-bit words");
 
 __host__ __device__ __forceinline__ void bs_range(int r, int qlen, int tlen, int w, int &st0, int &en0)
 {
@@ -87,19 +85,15 @@ __host__ __device__ inline BsLayout bs_layout(int qlen, int tlen, int w)
 
 // tab (32 bit words) of a problem: [0] waves in its pool, [1] first diagonal with an empty range (or n_diag), then first / last diagonal of every
 // strip (first > last: the band never reaches it), then the number of strips alive in every block of 64 diagonals
-__global__ __launch_bounds__(64)
-void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_job, PkBases bases, DpParams P,
+template <bool RIGHT>
+__device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, uint8_t *s_win, PkBases bases, const DpParams &P,
                uint8_t *__restrict__ slab_all, const uint64_t *__restrict__ slab_off, unsigned long long *__restrict__ bnd_all, const uint64_t *__restrict__ bnd_off,
                const uint32_t *__restrict__ tab_all, const uint64_t *__restrict__ tab_off,
                DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
 {
-	__shared__ __align__(16) uint8_t s_win[64 * 65 * 4];      // the keys of a block ([diagonal][lane], row stride 65 words); at the end the traceback window
 	const int lane = threadIdx.x;
-	const uint32_t jl = blk_job[blockIdx.x];
-	const DpJob J = jobs[jl];
 	const uint64_t t_base = J.t_off, q_base = J.q_off;
 	const int qlen = J.qlen, tlen = J.tlen, flag = J.flag, zdrop = J.zdrop, end_bonus = J.end_bonus;
-	const bool right = flag & EZ_RIGHT;
 	int w = J.w;
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
 	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
@@ -120,7 +114,6 @@ void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_
 	int32_t *hen_arr = (int32_t*)(base_w + Lo.o_hen), *hst_arr = (int32_t*)(base_w + Lo.o_hst);
 	uint32_t *done = (uint32_t*)(base_w + Lo.o_done);
 	const uint32_t *tab = tab_all + tab_off[jl];
-	const uint32_t n_pool = tab[0];
 	const int n_eff = (int)tab[1];                                  // diagonals [0, n_eff) have a range; diagonal n_eff, if it exists, ends the problem (z-dropped)
 	const uint32_t *strip_r = tab + 2, *need = tab + 2 + 2 * (size_t)n_strips;
 	const int nblk_eff = (n_eff + 63) / 64;
@@ -138,73 +131,11 @@ void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_
 	auto first_row = [&](int r) -> int { return bs_sx8(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2); };
 	auto stopped = [&]() -> uint32_t { return __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
-	// ---- the per-diagonal decisions of a completed block, in order: one evaluator at a time ----
-	auto try_eval = [&]() {
-		for (;;) {
-			uint32_t got = 1;
-			if (lane == 0) got = atomicCAS(&ctl->eval_lock, 0u, 1u);
-			got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-			if (got != 0) return;
-			__threadfence();
-			int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF, zdropped = 0, r_end = 0;
-			if (__hip_atomic_load(&ctl->ez_init, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-				ez_max = ctl->ez_max, ez_max_t = ctl->ez_max_t, ez_max_q = ctl->ez_max_q, ez_mqe = ctl->ez_mqe, ez_mqe_t = ctl->ez_mqe_t, ez_mte = ctl->ez_mte, ez_mte_q = ctl->ez_mte_q;
-				ez_score = ctl->ez_score, zdropped = ctl->ez_zdropped, r_end = ctl->r_end;
-			}
-			int sat = 0;
-			uint32_t b = __hip_atomic_load(&ctl->eval_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			bool halt = stopped() != 0;
-			while (!halt && (int)b < nblk_eff) {
-				if (__hip_atomic_load(&done[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need[b]) break;
-				const int r0 = (int)b * 64, r = r0 + lane;
-				unsigned long long bestk = 0; int hen = KSW_NEG_INF, hst = KSW_NEG_INF;
-				if (r < n_eff) {
-					bestk = __hip_atomic_load(&best_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					hen = __hip_atomic_load(&hen_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					hst = __hip_atomic_load(&hst_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				const uint32_t h16 = (uint32_t)(bestk >> 24) & 0xffffu;
-				const int mH_l = (int)h16 - 32768, mt_l = (4095 - (int)((bestk >> 8) & 4095)) * BS_W + (63 - (int)(bestk & 255));
-				const int sat_l = r < n_eff && (h16 == 0 || h16 == 65535u) ? 1 : 0;
-				const int lim = n_eff - r0 < 64 ? n_eff - r0 : 64;
-				for (int ii = 0; ii < lim; ++ii) {
-					const int rr = r0 + ii;
-					const int mH = __builtin_amdgcn_readlane(mH_l, ii), mt = __builtin_amdgcn_readlane(mt_l, ii);
-					const int he = __builtin_amdgcn_readlane(hen, ii), hs = __builtin_amdgcn_readlane(hst, ii);
-					sat |= __builtin_amdgcn_readlane(sat_l, ii);
-					int st0, en0; bs_range(rr, qlen, tlen, w, st0, en0);
-					r_end = rr + 1;
-					if (en0 == tlen - 1) { if (he > ez_mte) ez_mte = he, ez_mte_q = rr - en0; if (rr == n_diag - 1) ez_score = he; }
-					if (rr - st0 == qlen - 1 && hs > ez_mqe) ez_mqe = hs, ez_mqe_t = st0;
-					const bool upd = mH > ez_max;
-					const int tl = mt - ez_max_t, ql = (rr - mt) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-					const bool stop = !upd && tl >= 0 && ql >= 0 && zdrop >= 0 && ez_max - mH > zdrop + l * e2;
-					if (upd) ez_max = mH, ez_max_t = mt, ez_max_q = rr - mt;
-					if (stop) { zdropped = 1, ez_score = KSW_NEG_INF; halt = true; break; }
-				}
-				if (!halt && r0 + lim >= n_eff && n_eff < n_diag) { zdropped = 1; r_end = n_eff + 1; halt = true; }      // the range ran empty (ksw2_extd2_sse.c:172)
-				if (sat) halt = true;
-				++b;
-			}
-			if (lane == 0) {
-				ctl->ez_max = ez_max, ctl->ez_max_t = ez_max_t, ctl->ez_max_q = ez_max_q, ctl->ez_mqe = ez_mqe, ctl->ez_mqe_t = ez_mqe_t, ctl->ez_mte = ez_mte, ctl->ez_mte_q = ez_mte_q;
-				ctl->ez_score = ez_score, ctl->ez_zdropped = zdropped, ctl->r_end = r_end;
-				if (sat) ctl->sat = 1;
-				__hip_atomic_store(&ctl->ez_init, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(&ctl->eval_next, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__threadfence();
-				if (halt) __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				__threadfence();
-				__hip_atomic_store(&ctl->eval_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			__threadfence();
-			// a block may have completed while the lock was held (its last strip found the lock taken and left): look again
-			const uint32_t b2 = __hip_atomic_load(&ctl->eval_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (halt || stopped() || (int)b2 >= nblk_eff) return;
-			if (__hip_atomic_load(&done[b2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need[b2]) return;
-		}
-	};
-
+	// ---- roles: the first wave of the pool to arrive is the problem's EVALUATOR, the others take strips ----
+	uint32_t role = 0;
+	if (lane == 0) role = atomicAdd(&ctl->roles, 1u);
+	role = (uint32_t)__builtin_amdgcn_readfirstlane((int)role);
+	if (role != 0) {
 	// ---- strips, in ascending order from the problem's counter ----
 	for (;;) {
 		uint32_t k = 0;
@@ -223,53 +154,75 @@ void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_
 		uint32_t PK = PK_INI;
 		int qb = query_at(r_first - 1 - t);                         // query[(r - 1) - t] for r = r_first: what the slide below starts from
 		bool gone = false;
+#ifdef PGA_BS_PROF
+		long long pf_poll = 0, pf_comp = 0, pf_blk = 0, pf_n = 0; const long long pf_t0 = clock64();
+#endif
+		// ranges of the diagonal before the strip's first (what column st's edge rule looks at, ksw2_extd2_sse.c:176-183)
+		int last_st = -1, last_en = -1;
+		if (r_first > 0) { int a0, a1; bs_range(r_first - 1, qlen, tlen, w, a0, a1); last_st = a0 & ~15, last_en = ((a1 + 16) & ~15) - 1; }
 		for (int b = r_first >> 6; b <= r_last >> 6 && !gone; ++b) {
 			if (stopped()) { gone = true; break; }
 			const int r_lo = b * 64 > r_first ? b * 64 : r_first, r_hi = b * 64 + 63 < r_last ? b * 64 + 63 : r_last;
-			const int qwin = query_at(b * 64 + lane - c0);              // the base that enters lane 0 on diagonal 64 b + lane
+			// what a diagonal needs that does not depend on the column, a diagonal per lane: its range, the first-row value, the query base that
+			// enters lane 0 (the loop below takes them by v_readlane: a dozen scalar instructions per diagonal less)
+			int v_st0, v_en0;
+			bs_range(b * 64 + lane, qlen, tlen, w, v_st0, v_en0);
+			const int v_fr = first_row(b * 64 + lane);
+			const int qwin = query_at(b * 64 + lane - c0);
 			unsigned long long inw = (unsigned long long)(uint32_t)KSW_NEG_INF << 32 | PK_INI;
-			{
-				const int d = b * 64 + lane - 1;                          // the cell of diagonal d + 1 in column c0 reads the left strip's state after diagonal d
-				if (bnd_in && d >= rf_left && d <= rl_left && d + 1 >= r_lo && d + 1 <= r_hi) {
-					for (;;) {
-						inw = __hip_atomic_load(&bnd_in[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if (inw >> 31 & 1ULL) break;
-						if (stopped()) { gone = true; break; }
-						__builtin_amdgcn_s_sleep(2);
+			unsigned long long outw = 0;
+			int hen_acc = 0, hst_acc = 0; bool hen_set = false, hst_set = false;
+			uint8_t *prow = pmat + (size_t)r_lo * n_col;               // row of the direction matrix of the current diagonal
+			// four sub-blocks of sixteen diagonals: the strip on the left publishes its last column after every sixteen, so this strip runs sixteen
+			// (not sixty-four) diagonals behind it
+			for (int sub = 0; sub < 4 && !gone; ++sub) {
+				const int s_lo = b * 64 + 16 * sub > r_lo ? b * 64 + 16 * sub : r_lo, s_hi = b * 64 + 16 * sub + 15 < r_hi ? b * 64 + 16 * sub + 15 : r_hi;
+				if (s_lo > s_hi) continue;
+#ifdef PGA_BS_PROF
+				const long long pf0 = clock64();
+#endif
+				{
+					const int d = b * 64 + lane - 1;                      // the cell of diagonal d + 1 in column c0 reads the left strip's state after diagonal d
+					if (bnd_in && d >= rf_left && d <= rl_left && d + 1 >= s_lo && d + 1 <= s_hi) {
+						for (;;) {
+							inw = __hip_atomic_load(&bnd_in[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if (inw >> 31 & 1ULL) break;
+							if (stopped()) { gone = true; break; }
+							__builtin_amdgcn_s_sleep(1);
+						}
 					}
 				}
-			}
-			if (__ballot(gone) != 0ULL) { gone = true; break; }
-			unsigned long long outw = 0;
-			for (int r = r_lo; r <= r_hi; ++r) {
-				const int i = r - b * 64;
-				int st0, en0, lst0, len0;
-				bs_range(r, qlen, tlen, w, st0, en0);
-				const int st = st0 & ~15, en = ((en0 + 16) & ~15) - 1, span = ((en0 - st0) & ~15) + 16;
-				int last_st = -1, last_en = -1;
-				if (r > 0) { bs_range(r - 1, qlen, tlen, w, lst0, len0); last_st = lst0 & ~15, last_en = ((len0 + 16) & ~15) - 1; }
-				qb = wave_shr1(qb, __builtin_amdgcn_readlane(qwin, i));
-				// the column that joins on this diagonal starts from the first-row values (ksw2_extd2_sse.c:184-190)
-				if (en >= r && t == r) { U = first_row(r); Y = INI1; Y2 = INI2; }
-				// x, v, x2 (and H) of the column on the left as the previous diagonal left them; column st takes the edge values (:176-183)
-				uint32_t lw = (uint32_t)wave_shr1((int)PK, __builtin_amdgcn_readlane((int)(uint32_t)inw, i));
-				const int Hl = wave_shr1(H, __builtin_amdgcn_readlane((int)(uint32_t)(inw >> 32), i));
-				if (t == st) {
-					if (st == 0) lw = ((uint32_t)INI1 & 0xffu) | ((uint32_t)first_row(r) & 0xffu) << 8 | ((uint32_t)INI2 & 0xffu) << 16;
-					else if (!(st - 1 >= last_st && st - 1 <= last_en)) lw = PK_INI;
-				}
-				// the score byte: refreshed over [st0, st0 + span) only (the profile loop runs in blocks of sixteen from st0, :196-221)
-				if (t >= st0 && t < st0 + span && t < T) {
-					int sc = tb == qb ? sc_mch : sc_mis;
-					sc = ((tb | qb) & 4) ? sc_N : sc;
-					S = bs_sx8(sc);
-				}
-				int Un = U, Vn = bs_byte(PK, 8);
-				if (t >= st && t <= en) {
+				if (__ballot(gone) != 0ULL) { gone = true; break; }
+#ifdef PGA_BS_PROF
+				const long long pf1 = clock64(); pf_poll += pf1 - pf0;
+#endif
+				for (int r = s_lo; r <= s_hi; ++r) {
+					const int i = r - b * 64;
+					const int st0 = __builtin_amdgcn_readlane(v_st0, i), en0 = __builtin_amdgcn_readlane(v_en0, i), fr = __builtin_amdgcn_readlane(v_fr, i);
+					const int st = st0 & ~15, en = ((en0 + 16) & ~15) - 1, span = ((en0 - st0) & ~15) + 16;
+					qb = wave_shr1(qb, __builtin_amdgcn_readlane(qwin, i));
+					// the column that joins on this diagonal starts from the first-row values (ksw2_extd2_sse.c:184-190)
+					const bool join = t == r && en >= r;
+					U = join ? fr : U; Y = join ? INI1 : Y; Y2 = join ? INI2 : Y2;
+					// x, v, x2 (and H) of the column on the left as the previous diagonal left them; column st takes the edge values (:176-183)
+					uint32_t lw = (uint32_t)wave_shr1((int)PK, __builtin_amdgcn_readlane((int)(uint32_t)inw, i));
+					const int Hl = wave_shr1(H, __builtin_amdgcn_readlane((int)(uint32_t)(inw >> 32), i));
+					{
+						const bool keep = st > 0 && st - 1 >= last_st && st - 1 <= last_en;       // (uniform) the column on the left of st was computed on the last diagonal
+						const uint32_t edge = st == 0 ? (((uint32_t)INI1 & 0xffu) | ((uint32_t)fr & 0xffu) << 8 | ((uint32_t)INI2 & 0xffu) << 16) : PK_INI;
+						lw = (t == st && !keep) ? edge : lw;
+					}
+					// the score byte: refreshed over [st0, st0 + span) only (the profile loop runs in blocks of sixteen from st0, :196-221)
+					{
+						int sc = tb == qb ? sc_mch : sc_mis;
+						sc = ((tb | qb) & 4) ? sc_N : sc;
+						S = (t >= st0 && t < st0 + span && t < T) ? bs_sx8(sc) : S;
+					}
+					const bool in_rng = t >= st && t <= en;
 					const int xt1 = bs_byte(lw, 0), vt1 = bs_byte(lw, 8), x2t1 = bs_byte(lw, 16);
 					int z = S;
 					int a = bs_sx8(xt1 + vt1), bb = bs_sx8(Y + U), a2 = bs_sx8(x2t1 + vt1), b2 = bs_sx8(Y2 + U), d;
-					if (!right) {
+					if (!RIGHT) {
 						d = a > z ? 1 : 0; z = a > z ? a : z;
 						d = bb > z ? 2 : d; z = bb > z ? bb : z;
 						d = a2 > z ? 3 : d; z = a2 > z ? a2 : z;
@@ -281,46 +234,60 @@ void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_
 						d = z > b2 ? d : 4; z = z > b2 ? z : b2;
 					}
 					z = sc_mch < z ? sc_mch : z;
-					Un = bs_sx8(z - vt1); Vn = bs_sx8(z - U);
+					const int un = bs_sx8(z - vt1), vn = bs_sx8(z - U);
 					int tmp = bs_sx8(z - q); a = bs_sx8(a - tmp); bb = bs_sx8(bb - tmp);
 					tmp = bs_sx8(z - q2); a2 = bs_sx8(a2 - tmp); b2 = bs_sx8(b2 - tmp);
 					int xn, yn, x2n, y2n;
-					if (!right) {
-						xn = bs_sx8((a > 0 ? a : 0) - qe);    d |= a > 0 ? 0x08 : 0;
-						yn = bs_sx8((bb > 0 ? bb : 0) - qe);  d |= bb > 0 ? 0x10 : 0;
+					if (!RIGHT) {
+						xn = bs_sx8((a > 0 ? a : 0) - qe);     d |= a > 0 ? 0x08 : 0;
+						yn = bs_sx8((bb > 0 ? bb : 0) - qe);   d |= bb > 0 ? 0x10 : 0;
 						x2n = bs_sx8((a2 > 0 ? a2 : 0) - qe2); d |= a2 > 0 ? 0x20 : 0;
 						y2n = bs_sx8((b2 > 0 ? b2 : 0) - qe2); d |= b2 > 0 ? 0x40 : 0;
 					} else {
-						xn = bs_sx8((0 > a ? 0 : a) - qe);    d |= !(0 > a) ? 0x08 : 0;
-						yn = bs_sx8((0 > bb ? 0 : bb) - qe);  d |= !(0 > bb) ? 0x10 : 0;
+						xn = bs_sx8((0 > a ? 0 : a) - qe);     d |= !(0 > a) ? 0x08 : 0;
+						yn = bs_sx8((0 > bb ? 0 : bb) - qe);   d |= !(0 > bb) ? 0x10 : 0;
 						x2n = bs_sx8((0 > a2 ? 0 : a2) - qe2); d |= !(0 > a2) ? 0x20 : 0;
 						y2n = bs_sx8((0 > b2 ? 0 : b2) - qe2); d |= !(0 > b2) ? 0x40 : 0;
 					}
-					U = Un; Y = yn; Y2 = y2n;
-					PK = ((uint32_t)xn & 0xffu) | ((uint32_t)Vn & 0xffu) << 8 | ((uint32_t)x2n & 0xffu) << 16;
-					pmat[(size_t)r * n_col + (size_t)(t - st)] = (uint8_t)d;
+					// a column outside [st, en] keeps its rows; Un / Vn: what u[t], v[t] hold behind this diagonal
+					const int Un = in_rng ? un : U, Vn = in_rng ? vn : bs_byte(PK, 8);
+					const uint32_t pkn = ((uint32_t)xn & 0xffu) | ((uint32_t)vn & 0xffu) << 8 | ((uint32_t)x2n & 0xffu) << 16;
+					U = Un; Y = in_rng ? yn : Y; Y2 = in_rng ? y2n : Y2; PK = in_rng ? pkn : PK;
+					if (in_rng) prow[t - st] = (uint8_t)d;
+					// H[t] += v[t] over [st0, en0); H[en0] = H[en0 - 1] (as the previous diagonal left it) + u[en0] (ksw2_extd2_sse.c:325-340); the maximum
+					// with the reference's tie order (H[en0] first, then four lanes by (t - st0) & 3 over [st0, en1), then the tail) as one key per column
+					{
+						const int en1 = st0 + ((en0 - st0) & ~3);
+						const bool act = t >= st0 && t <= en0, is_en = t == en0;
+						const int h_en = Hl + Un, h_in = H + Vn;
+						int h = (is_en && en0 > 0) ? h_en : h_in;
+						h = (is_en && r == 0) ? Vn - qe_h : h;
+						H = act ? h : H;
+						const uint32_t field = is_en ? 8u : 7u - (t < en1 ? (uint32_t)((t - st0) & 3) : 4u);
+						const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;
+						const uint32_t key = ((uint32_t)(hc + 32768) << 16) | field << 12 | (uint32_t)(63 - lane);
+						s_key[i * 65 + lane] = act ? key : 0u;
+						// H[en0] and H[st0] of the diagonal for the end-of-sequence scores: collected a diagonal per lane, stored once per block
+						const int le = en0 - c0, ls = st0 - c0;
+						if ((unsigned)le < 64u) { const int hv = __builtin_amdgcn_readlane(H, le & 63); if (lane == i) hen_acc = hv, hen_set = true; }
+						if ((unsigned)ls < 64u && r - st0 == qlen - 1) { const int hv = __builtin_amdgcn_readlane(H, ls & 63); if (lane == i) hst_acc = hv, hst_set = true; }
+					}
+					{
+						const uint32_t w63 = (uint32_t)__builtin_amdgcn_readlane((int)PK, 63);
+						const unsigned long long wv = 0x80000000ULL | (w63 & 0x00ffffffu) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(H, 63) << 32;
+						outw = lane == i ? wv : outw;
+					}
+					prow += n_col;
+					last_st = st, last_en = en;
 				}
-				// H[t] += v[t] over [st0, en0); H[en0] = H[en0 - 1] (as the previous diagonal left it) + u[en0] (ksw2_extd2_sse.c:325-340); the maximum
-				// with the reference's tie order (H[en0] first, then four lanes by (t - st0) & 3 over [st0, en1), then the tail) as one key per column
-				uint32_t key = 0;
-				if (t >= st0 && t <= en0) {
-					const int en1 = st0 + (en0 - st0) / 4 * 4;
-					int h; uint32_t field;
-					if (t == en0) { h = r == 0 ? Vn - qe_h : en0 > 0 ? Hl + Un : H + Vn; field = 8u; __hip_atomic_store(&hen_arr[r], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-					else { h = H + Vn; field = 7u - (t < en1 ? (uint32_t)((t - st0) & 3) : 4u); }
-					H = h;
-					if (t == st0 && r - st0 == qlen - 1) __hip_atomic_store(&hst_arr[r], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					const int hc = h < -32768 ? -32768 : h > 32767 ? 32767 : h;
-					key = ((uint32_t)(hc + 32768) << 16) | field << 12 | (uint32_t)(63 - lane);
-				}
-				s_key[i * 65 + lane] = key;
-				if (bnd_out) {
-					const uint32_t w63 = (uint32_t)__builtin_amdgcn_readlane((int)PK, 63);
-					const unsigned long long wv = 0x80000000ULL | (w63 & 0x00ffffffu) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(H, 63) << 32;
-					if (lane == i) outw = wv;
-				}
+				if (bnd_out && outw) { __hip_atomic_store(&bnd_out[b * 64 + lane], outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); outw = 0; }
+#ifdef PGA_BS_PROF
+				pf_comp += clock64() - pf1; pf_n += s_hi - s_lo + 1;
+#endif
 			}
-			if (bnd_out && outw) __hip_atomic_store(&bnd_out[b * 64 + lane], outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (gone) break;
+			if (hen_set) __hip_atomic_store(&hen_arr[b * 64 + lane], hen_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (hst_set) __hip_atomic_store(&hst_arr[b * 64 + lane], hst_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			{
 				const int r = b * 64 + lane;
@@ -335,25 +302,59 @@ void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__threadfence();
-			uint32_t c = 0;
-			if (lane == 0) c = __hip_atomic_fetch_add(&done[b], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-			c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-			if (c >= need[b]) try_eval();
+			if (lane == 0) (void)__hip_atomic_fetch_add(&done[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
+#ifdef PGA_BS_PROF
+		if (lane == 0 && jl == 0 && (k % 6) == 2) printf("[bstrips prof] strip %u: %lld diagonals; cycles per diagonal: poll %lld compute %lld everything %lld\n", k, pf_n, pf_poll / (pf_n ? pf_n : 1), pf_comp / (pf_n ? pf_n : 1), (clock64() - pf_t0) / (pf_n ? pf_n : 1));
+#endif
 		if (gone) break;
 	}
 
-	// ---- the last wave of the pool to leave walks the path back and reports ----
-	__threadfence();
-	uint32_t last = 0;
-	if (lane == 0) last = atomicAdd(&ctl->done_waves, 1u);
-	last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
-	if (last + 1 != n_pool) return;
-	__threadfence();
-	const int ez_max = ctl->ez_init ? ctl->ez_max : 0, ez_max_t = ctl->ez_init ? ctl->ez_max_t : -1, ez_max_q = ctl->ez_init ? ctl->ez_max_q : -1;
-	const int ez_mqe = ctl->ez_init ? ctl->ez_mqe : KSW_NEG_INF, ez_mqe_t = ctl->ez_init ? ctl->ez_mqe_t : -1, ez_mte = ctl->ez_init ? ctl->ez_mte : KSW_NEG_INF, ez_mte_q = ctl->ez_init ? ctl->ez_mte_q : -1;
-	const int ez_score = ctl->ez_init ? ctl->ez_score : KSW_NEG_INF, ez_zdropped = ctl->ez_init ? ctl->ez_zdropped : 0, r_done = ctl->ez_init ? ctl->r_end : 0;
-	const int sat = (int)ctl->sat;
+		return;
+	}
+	// ---- the evaluator: the reference's per-diagonal decisions (ksw2_extd2_sse.c:326-366, ksw2.h:167-184), block by block as the strips complete
+	// them; a z-drop (or a clamped key, or a range that ran empty) raises the stop flag; then the walk back ----
+	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF, ez_zdropped = 0, r_done = 0;
+	int sat = 0;
+	{
+		bool halt = false;
+		for (int b = 0; b < nblk_eff && !halt; ++b) {
+			// (a guard, not a path: if a block's strips never report -- they cannot, by the ordering argument above -- the problem is handed back
+			// to the workgroup kernel after ~20 M polls instead of hanging the launch)
+			{ long long polls = 0; while (__hip_atomic_load(&done[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need[b]) { if (++polls > 20000000LL) { sat = 1; break; } __builtin_amdgcn_s_sleep(8); } }
+			if (sat) { halt = true; break; }
+			__threadfence();
+			const int r0 = b * 64, r = r0 + lane;
+			unsigned long long bestk = 0; int hen = KSW_NEG_INF, hst = KSW_NEG_INF;
+			if (r < n_eff) {
+				bestk = __hip_atomic_load(&best_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				hen = __hip_atomic_load(&hen_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				hst = __hip_atomic_load(&hst_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			const uint32_t h16 = (uint32_t)(bestk >> 24) & 0xffffu;
+			const int mH_l = (int)h16 - 32768, mt_l = (4095 - (int)((bestk >> 8) & 4095)) * BS_W + (63 - (int)(bestk & 255));
+			const int sat_l = r < n_eff && (h16 == 0 || h16 == 65535u) ? 1 : 0;
+			const int lim = n_eff - r0 < 64 ? n_eff - r0 : 64;
+			for (int ii = 0; ii < lim; ++ii) {
+				const int rr = r0 + ii;
+				const int mH = __builtin_amdgcn_readlane(mH_l, ii), mt = __builtin_amdgcn_readlane(mt_l, ii);
+				const int he = __builtin_amdgcn_readlane(hen, ii), hs = __builtin_amdgcn_readlane(hst, ii);
+				sat |= __builtin_amdgcn_readlane(sat_l, ii);
+				int st0, en0; bs_range(rr, qlen, tlen, w, st0, en0);
+				r_done = rr + 1;
+				if (en0 == tlen - 1) { if (he > ez_mte) ez_mte = he, ez_mte_q = rr - en0; if (rr == n_diag - 1) ez_score = he; }
+				if (rr - st0 == qlen - 1 && hs > ez_mqe) ez_mqe = hs, ez_mqe_t = st0;
+				const bool upd = mH > ez_max;
+				const int tl = mt - ez_max_t, ql = (rr - mt) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+				const bool stop = !upd && tl >= 0 && ql >= 0 && zdrop >= 0 && ez_max - mH > zdrop + l * e2;
+				if (upd) ez_max = mH, ez_max_t = mt, ez_max_q = rr - mt;
+				if (stop) { ez_zdropped = 1, ez_score = KSW_NEG_INF; halt = true; break; }
+			}
+			if (!halt && r0 + lim >= n_eff && n_eff < n_diag) { ez_zdropped = 1; r_done = n_eff + 1; halt = true; }      // the range ran empty (ksw2_extd2_sse.c:172)
+			if (sat) halt = true;
+		}
+		if (lane == 0) __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // strips that are still out there leave
+	}
 	int ez_reach_end = 0;
 	int n_cigar = 0, bi = -1, bj = -1;
 	if (sat) {}
@@ -431,6 +432,19 @@ void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_
 	}
 }
 
+__global__ __launch_bounds__(64)
+void k_bstrips(const DpJob *__restrict__ jobs, const uint32_t *__restrict__ blk_job, PkBases bases, DpParams P,
+               uint8_t *__restrict__ slab_all, const uint64_t *__restrict__ slab_off, unsigned long long *__restrict__ bnd_all, const uint64_t *__restrict__ bnd_off,
+               const uint32_t *__restrict__ tab_all, const uint64_t *__restrict__ tab_off,
+               DpRes *__restrict__ res, uint32_t *__restrict__ cigar_pool, unsigned long long *__restrict__ pool_cursor, unsigned long long pool_cap)
+{
+	__shared__ __align__(16) uint8_t s_win[64 * 65 * 4];      // the keys of a block ([diagonal][lane], row stride 65 words); at the end the traceback window
+	const uint32_t jl = blk_job[blockIdx.x];
+	const DpJob J = jobs[jl];
+	if (J.flag & EZ_RIGHT) bstrip_body<true>(J, jl, s_win, bases, P, slab_all, slab_off, bnd_all, bnd_off, tab_all, tab_off, res, cigar_pool, pool_cursor, pool_cap);
+	else bstrip_body<false>(J, jl, s_win, bases, P, slab_all, slab_off, bnd_all, bnd_off, tab_all, tab_off, res, cigar_pool, pool_cursor, pool_cap);
+}
+
 // ---- host side ----
 // 0: the lane kernel keeps every banded problem; 1 (default): launches that hold few of them, and the long ones of any launch; 2: every eligible one
 int bstrips_mode()               // (read on every call: the parity tests switch it inside one process)
@@ -438,15 +452,16 @@ int bstrips_mode()               // (read on every call: the parity tests switch
 	const char *e = getenv("PGA_BSTRIPS");
 	return !e ? 1 : !strcmp(e, "off") || !strcmp(e, "0") ? 0 : !strcmp(e, "force") ? 2 : 1;
 }
-int bstrips_max_problems() { static const int v = getenv("PGA_BSTRIPS_MAX") ? atoi(getenv("PGA_BSTRIPS_MAX")) : 48; return v; }
+int bstrips_max_problems() { static const int v = getenv("PGA_BSTRIPS_MAX") ? atoi(getenv("PGA_BSTRIPS_MAX")) : 8; return v; }
 int bstrips_long_diagonals() { static const int v = getenv("PGA_BSTRIPS_LONG") ? atoi(getenv("PGA_BSTRIPS_LONG")) : 6000; return v; }
 bool bstrips_eligible(const DpJob &j, const DpParams &P)
 {
 	if (j.flag & (PGA_JOB_LL | EZ_APPROX_MAX)) return false;
-	if (j.qlen < 64 || j.tlen < 64 || j.qlen > 32000 || j.tlen > 32000) return false;
+	if (j.qlen < 1 || j.tlen < 1 || j.qlen > 32000 || j.tlen > 32000) return false;
 	if (!(P.sc_mch >= 0 && P.sc_mch < 127)) return false;
-	const int w = j.w < 0 ? (j.tlen > j.qlen ? j.tlen : j.qlen) : j.w;
-	return w >= 64;                                            // (narrow bands: a strip or two -- the one-wave lane kernel's case)
+	// (a narrow ring -- an extension towards a block end a few bases away: 20 columns, 10 k diagonals -- is ONE strip: no hand-over at all, and a
+	// diagonal of one column per lane costs a quarter of the one-wave lane kernel's)
+	return j.qlen + j.tlen >= 128;
 }
 size_t bstrips_slab_bytes(const DpJob &j)
 {
@@ -483,7 +498,7 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab)
 	}
 	for (int b = 0; b < L.nblk; ++b) alive_max = std::max(alive_max, (int)need[b]);
 	// strips run a block of 64 diagonals apart: about twice the strips of one diagonal are alive at a time
-	const uint32_t pool = (uint32_t)std::max(1, std::min(L.n_strips, std::min(2 * alive_max + 2, 56)));
+	const uint32_t pool = 1u + (uint32_t)std::max(1, std::min(L.n_strips, std::min(2 * alive_max + 2, 56)));      // + the evaluator
 	tab[at] = pool, tab[at + 1] = (uint32_t)n_eff;
 	return pool;
 }
