@@ -188,7 +188,7 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 							inw = __hip_atomic_load(&bnd_in[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							if (inw >> 31 & 1ULL) break;
 							if (stopped()) { gone = true; break; }
-							__builtin_amdgcn_s_sleep(1);
+							__builtin_amdgcn_s_sleep(4);
 						}
 					}
 				}
@@ -497,8 +497,10 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab)
 		for (int b = r_in >> 6; b <= (r_out - 1) >> 6; ++b) ++need[b];
 	}
 	for (int b = 0; b < L.nblk; ++b) alive_max = std::max(alive_max, (int)need[b]);
-	// strips run a block of 64 diagonals apart: about twice the strips of one diagonal are alive at a time
-	const uint32_t pool = 1u + (uint32_t)std::max(1, std::min(L.n_strips, std::min(2 * alive_max + 2, 56)));      // + the evaluator
+	// strips run sixteen diagonals apart: little more than the strips alive in one block of 64 diagonals are busy at a time (a wave that waits for
+	// its turn still holds a slot and polls: PGA_BSTRIPS_POOL_EXTRA more than that, default 4)
+	static const int extra = getenv("PGA_BSTRIPS_POOL_EXTRA") ? atoi(getenv("PGA_BSTRIPS_POOL_EXTRA")) : 4;
+	const uint32_t pool = 1u + (uint32_t)std::max(1, std::min(L.n_strips, std::min(alive_max + extra, 56)));      // + the evaluator
 	tab[at] = pool, tab[at + 1] = (uint32_t)n_eff;
 	return pool;
 }
