@@ -38,6 +38,7 @@ for q in set(r[2] for r in rows):
     qbusy[q] = tot + hi - lo
 out = {"trace": sys.argv[1].split("/")[-1], "note": "whole trace (warm-up step and timed step of bench.py under rocprofv3 --kernel-trace), runtime blit kernels included",
        "kernels": len(rows), "wall_s": wall * 1e-9, "sum_of_kernel_time_s": ksum * 1e-9, "average_kernels_in_flight": ksum / wall,
+       "average_kernels_in_flight_while_any_runs": ksum / max(1, wall - hist.get(0, 0)),
        "share_of_wall_time_by_kernels_in_flight": {str(k): round(v / wall, 4) for k, v in sorted(hist.items())},
        "share_of_wall_time_by_queues_with_a_kernel_in_flight": {str(k): round(v / wall, 4) for k, v in sorted(qhist.items())},
        "busy_share_per_queue": {str(q): round(v / wall, 4) for q, v in sorted(qbusy.items(), key=lambda kv: -kv[1])}}
