@@ -80,7 +80,7 @@ def pmc_issue():
     d = json.load(open(files[-1])).get("kernels", {})
     return {"source": os.path.relpath(files[-1], ROOT),
             "kernels": {k.replace("pga::", ""): {"valu_issue_frac": v.get("valu_issue_frac_of_wave_cycles"), "lds_issue_frac": v.get("lds_issue_frac_of_wave_cycles")}
-                        for k, v in d.items() if any(t in k for t in ("k_extd2", "k_gapfill", "k_ll_i16", "k_approx_strips"))}}
+                        for k, v in d.items() if any(t in k for t in ("k_extd2", "k_gapfill", "k_ll_i16", "k_approx_strips", "k_wstrips", "k_bstrips"))}}
 
 
 def _cpu_worker(args):
@@ -577,6 +577,17 @@ def main():
         else "pga_batch_derive (device-to-device) + pga_batch_align"
     # whole path: algorithmic HBM bytes per step by SURVEY 8d's formula with the measured counts
     alg_step = 1.5 * st["n_bases"] + 64.0 * st["n_minimizers"] + 52.0 * st["n_anchors"] + 0.5 * st["n_dp_bases"]
+    valu_frac = None
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue*kernels.json")))
+        if f and kname.startswith("k_"):
+            cand = [(v.get("SQ_WAVE_CYCLES", 0.0), v.get("valu_issue_frac_of_wave_cycles")) for k, v in json.load(open(f[-1])).get("kernels", {}).items()
+                    if k.replace("pga::", "").split("<")[0] == kname.split("+")[0]]
+            if cand:
+                valu_frac = round(max(cand)[1], 3)       # the instantiation with the most wave cycles
+    except Exception:   # noqa: BLE001
+        valu_frac = None
     out = {
         "metric": "aligned Gbp/s in `pangraph build` (bases handed to the aligner per second, all merges, all self-merge rounds)",
         "value": units * args.steps / dt / 1e9,
@@ -602,7 +613,10 @@ def main():
                      "launches_per_step": klaunch, "busy_ms_per_step": busy.get(kname, 0.0) / args.steps,
                      "any_kernel_busy_ms_per_step": busy.get("any", 0.0) / args.steps,
                      "whole_path": {"alg_bytes_per_step": alg_step, "achieved": alg_step / (ms_step * 1e-3) / 1e9, "frac": alg_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                     "note": "kernel = largest summed HIP-event time (own stream); batches overlap, see busy_ms; traffic: profiles/ PMC passes, same unit as alg_bytes_per_launch"},
+                     "valu_issue_frac": valu_frac,
+                     "note": "kernel = largest summed HIP-event time (own stream); batches overlap, see busy_ms; traffic: profiles/ PMC passes, same unit as alg_bytes_per_launch; "
+                             "an integer DP kernel is bound by VALU issue of its waves, not by HBM or MFMA: valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of its largest "
+                             "instantiation (profiles/ PMC passes)"},
         "n_matches_gathered": last["n_matches"],
         "build_sha256": build_sha,
         "resident_gbp_s": resident["gbp_s"] if resident else (units * args.steps / dt / 1e9 if inp["lib"] is not None else None),
