@@ -390,7 +390,7 @@ int bstrips_long_diagonals();
 bool bstrips_eligible(const DpJob &j, const DpParams &P);
 size_t bstrips_slab_bytes(const DpJob &j);
 size_t bstrips_words(const DpJob &j);
-uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab);
+uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab, size_t *words);
 void launch_bstrips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                     unsigned long long *bnd, const uint64_t *bnd_off, const uint32_t *tab, const uint64_t *tab_off, DpRes *res, uint32_t *pool, unsigned long long *cursor,
                     unsigned long long pool_cap, hipStream_t st);
@@ -716,9 +716,10 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
 				so[i] = s_acc; s_acc += need[ids[i]];
-				bo[i] = b_acc; b_acc += bstrips_words(j);
 				to[i] = tab.size();
-				const uint32_t pool_waves = bstrips_table(j, tab);
+				size_t words = 0;
+				const uint32_t pool_waves = bstrips_table(j, tab, &words);
+				bo[i] = b_acc; b_acc += words;
 				for (uint32_t k2 = 0; k2 < pool_waves; ++k2) bj.push_back((uint32_t)i);
 			}
 			// (blocks of one problem are consecutive: the waves of a pool are dispatched together)

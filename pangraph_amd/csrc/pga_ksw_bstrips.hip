@@ -60,9 +60,10 @@ __host__ __device__ __forceinline__ void bs_range(int r, int qlen, int tlen, int
 __device__ __forceinline__ int bs_sx8(int v) { return __builtin_amdgcn_sbfe(v, 0, 8); }
 __device__ __forceinline__ int bs_byte(uint32_t v, int sh) { return __builtin_amdgcn_sbfe((int)v, sh, 8); }
 
-// the layout of a problem's words (64 bit each) behind bnd_off: control block | boundary words, n_strips rows of Ld | best key per diagonal |
-// H[en0] per diagonal, H[st0] per diagonal (32 bit) | completed strips per block of 64 diagonals (32 bit)
-struct BsLayout { int T, n_strips, n_diag, nblk, n_col; size_t Ld, o_bnd, o_best, o_hen, o_hst, o_done, words; };
+// the layout of a problem's words (64 bit each) behind bnd_off: control block | best key per diagonal | H[en0] per diagonal, H[st0] per diagonal
+// (32 bit) | completed strips per block of 64 diagonals (32 bit) | boundary words: one row per strip over the diagonals of its LIFETIME only (the
+// rows' offsets are in the problem's table: 4 MB instead of 25 for a 10 kb x 10 kb extension -- all of it is zeroed before every launch)
+struct BsLayout { int T, n_strips, n_diag, nblk, n_col; size_t Ld, o_bnd, o_best, o_hen, o_hst, o_done, words; };   // words: without the boundary rows
 __host__ __device__ inline BsLayout bs_layout(int qlen, int tlen, int w)
 {
 	BsLayout L;
@@ -74,17 +75,17 @@ __host__ __device__ inline BsLayout bs_layout(int qlen, int tlen, int w)
 	int n_col = qlen < tlen ? qlen : tlen;
 	L.n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
 	L.Ld = (size_t)(qlen + tlen);
-	L.o_bnd = sizeof(BsCtl) / 8;
-	L.o_best = L.o_bnd + (size_t)L.n_strips * L.Ld;
+	L.o_best = sizeof(BsCtl) / 8;
 	L.o_hen = L.o_best + L.Ld;
 	L.o_hst = L.o_hen + (L.Ld + 1) / 2;
 	L.o_done = L.o_hst + (L.Ld + 1) / 2;
-	L.words = L.o_done + ((size_t)L.nblk + 1) / 2 + 2;
+	L.o_bnd = L.o_done + ((size_t)L.nblk + 1) / 2 + 2;
+	L.words = L.o_bnd;
 	return L;
 }
 
-// tab (32 bit words) of a problem: [0] waves in its pool, [1] first diagonal with an empty range (or n_diag), then first / last diagonal of every
-// strip (first > last: the band never reaches it), then the number of strips alive in every block of 64 diagonals
+// tab (32 bit words) of a problem: [0] waves in its pool, [1] first diagonal with an empty range (or n_diag), then first diagonal / last diagonal /
+// offset of its boundary row for every strip (first > last: the band never reaches it), then the number of strips alive in every block of 64 diagonals
 template <bool RIGHT>
 __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, uint8_t *s_win, PkBases bases, const DpParams &P,
                uint8_t *__restrict__ slab_all, const uint64_t *__restrict__ slab_off, unsigned long long *__restrict__ bnd_all, const uint64_t *__restrict__ bnd_off,
@@ -115,7 +116,7 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 	uint32_t *done = (uint32_t*)(base_w + Lo.o_done);
 	const uint32_t *tab = tab_all + tab_off[jl];
 	const int n_eff = (int)tab[1];                                  // diagonals [0, n_eff) have a range; diagonal n_eff, if it exists, ends the problem (z-dropped)
-	const uint32_t *strip_r = tab + 2, *need = tab + 2 + 2 * (size_t)n_strips;
+	const uint32_t *strip_r = tab + 2, *need = tab + 2 + 3 * (size_t)n_strips;
 	const int nblk_eff = (n_eff + 63) / 64;
 	uint32_t *s_key = (uint32_t*)s_win;
 	const int INI1 = bs_sx8(-q - e), INI2 = bs_sx8(-q2 - e2);
@@ -142,11 +143,12 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 		if (lane == 0) k = atomicAdd(&ctl->next_strip, 1u);
 		k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
 		if ((int)k >= n_strips || stopped()) break;
-		const int r_first = (int)strip_r[2 * k], r_last = (int)strip_r[2 * k + 1];
+		const int r_first = (int)strip_r[3 * k], r_last = (int)strip_r[3 * k + 1];
 		if (r_first > r_last) continue;
-		const int rf_left = k > 0 ? (int)strip_r[2 * k - 2] : 0, rl_left = k > 0 ? (int)strip_r[2 * k - 1] : -1;
-		const unsigned long long *bnd_in = k > 0 ? bnd + (size_t)(k - 1) * Lo.Ld : nullptr;
-		unsigned long long *bnd_out = (int)k + 1 < n_strips ? bnd + (size_t)k * Lo.Ld : nullptr;
+		const int rf_left = k > 0 ? (int)strip_r[3 * k - 3] : 0, rl_left = k > 0 ? (int)strip_r[3 * k - 2] : -1;
+		// rows are indexed by diagonal: the pointers are moved back by the row's first diagonal
+		const unsigned long long *bnd_in = k > 0 && rf_left <= rl_left ? bnd + (size_t)strip_r[3 * k - 1] - rf_left : nullptr;
+		unsigned long long *bnd_out = (int)k + 1 < n_strips ? bnd + (size_t)strip_r[3 * k + 2] - r_first : nullptr;
 		const int c0 = (int)k * BS_W, t = c0 + lane;
 		const int tb = target_at(t);
 		// the lane's column: the rows at index t as the reference's freshly initialised arrays hold them (ksw2_extd2_sse.c:109-118)
@@ -468,9 +470,10 @@ size_t bstrips_slab_bytes(const DpJob &j)
 	const BsLayout L = bs_layout(j.qlen, j.tlen, j.w);
 	return (((size_t)L.n_diag * L.n_col + 15) & ~(size_t)15) + 4 * ((size_t)j.qlen + j.tlen + 8) + 256;
 }
-size_t bstrips_words(const DpJob &j) { return bs_layout(j.qlen, j.tlen, j.w).words; }
-// the problem's table (see k_bstrips) appended to `tab`; returns the number of waves in its pool
-uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab)
+uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab, size_t *words);
+size_t bstrips_words(const DpJob &j) { std::vector<uint32_t> scratch; size_t w = 0; (void)bstrips_table(j, scratch, &w); return w; }
+// the problem's table (see k_bstrips) appended to `tab`; returns the number of waves in its pool, *words = 64-bit words of the problem's region
+uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab, size_t *words)
 {
 	const BsLayout L = bs_layout(j.qlen, j.tlen, j.w);
 	const int w = j.w < 0 ? (j.tlen > j.qlen ? j.tlen : j.qlen) : j.w;
@@ -482,8 +485,9 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab)
 		st[(size_t)r] = st0 & ~15; en[(size_t)r] = ((en0 + 16) & ~15) - 1;
 	}
 	const size_t at = tab.size();
-	tab.resize(at + 2 + 2 * (size_t)L.n_strips + (size_t)L.nblk, 0u);
-	uint32_t *first = &tab[at + 2], *need = &tab[at + 2 + 2 * (size_t)L.n_strips];
+	tab.resize(at + 2 + 3 * (size_t)L.n_strips + (size_t)L.nblk, 0u);
+	uint32_t *first = &tab[at + 2], *need = &tab[at + 2 + 3 * (size_t)L.n_strips];
+	size_t row_words = 0;
 	int alive_max = 0;
 	// en and st do not decrease along the diagonals: a strip's diagonals are one interval
 	int r_in = 0, r_out = 0;
@@ -492,8 +496,9 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab)
 		while (r_in < n_eff && en[(size_t)r_in] < c0) ++r_in;
 		if (r_out < r_in) r_out = r_in;
 		while (r_out < n_eff && st[(size_t)r_out] <= c1) ++r_out;      // r_out: the first diagonal whose st has passed the strip
-		if (r_in >= n_eff || r_out <= r_in) { first[2 * k] = 1, first[2 * k + 1] = 0; continue; }
-		first[2 * k] = (uint32_t)r_in, first[2 * k + 1] = (uint32_t)(r_out - 1);
+		if (r_in >= n_eff || r_out <= r_in) { first[3 * k] = 1, first[3 * k + 1] = 0, first[3 * k + 2] = (uint32_t)row_words; continue; }
+		first[3 * k] = (uint32_t)r_in, first[3 * k + 1] = (uint32_t)(r_out - 1), first[3 * k + 2] = (uint32_t)row_words;
+		row_words += (size_t)(r_out - r_in) + 1;
 		for (int b = r_in >> 6; b <= (r_out - 1) >> 6; ++b) ++need[b];
 	}
 	for (int b = 0; b < L.nblk; ++b) alive_max = std::max(alive_max, (int)need[b]);
@@ -502,6 +507,7 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab)
 	static const int extra = getenv("PGA_BSTRIPS_POOL_EXTRA") ? atoi(getenv("PGA_BSTRIPS_POOL_EXTRA")) : 4;
 	const uint32_t pool = 1u + (uint32_t)std::max(1, std::min(L.n_strips, std::min(alive_max + extra, 56)));      // + the evaluator
 	tab[at] = pool, tab[at + 1] = (uint32_t)n_eff;
+	if (words) *words = L.words + row_words + 2;
 	return pool;
 }
 
