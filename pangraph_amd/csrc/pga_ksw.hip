@@ -556,9 +556,10 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	}
 	// class 12 (banded wave strips, pga_ksw_bstrips.hip): a launch that holds only a few banded exact problems is bound by the latency of ONE
 	// of them on one CU -- those go over several CUs each; a launch that holds more keeps them on the lane kernels, but for its few longest (an
-	// extension that runs its band out: 20 k diagonals).  "Few" is 8 (PGA_BSTRIPS_MAX): with six batches in flight, 20 or 48 problems per launch
-	// on strips (50 waves each, a zeroed 25 MB of boundary words each) make a step 4 and 9 % SLOWER, 8 leave it where it is; alone on the device
-	// a second self-merge round falls from 6.3 to 3.5 ms and the 20 k-diagonal extension from 48 to 17.5 ms
+	// extension that runs its band out: 20 k diagonals).  "Few" is 32 (PGA_BSTRIPS_MAX).  Alone on the device a second self-merge round falls
+	// from 6.3 to 3.5 ms and the 20 k-diagonal extension from 48 to 17.5 ms; with six batches in flight a step measures the same for 8 ... 64
+	// problems per launch on strips (2.39-2.46 s against 2.42-2.49 s without; when every strip row spanned all diagonals -- 25 MB zeroed per
+	// problem and launch -- 20 / 48 per launch cost 4 / 9 %)
 	if (allow_band && bstrips_mode() > 0) {
 		std::vector<uint32_t> elig;
 		for (int c : {10, 11}) for (uint32_t id : cls[c]) if (bstrips_eligible(jobs[id], P)) elig.push_back(id);

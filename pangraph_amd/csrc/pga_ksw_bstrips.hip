@@ -136,7 +136,44 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 	uint32_t role = 0;
 	if (lane == 0) role = atomicAdd(&ctl->roles, 1u);
 	role = (uint32_t)__builtin_amdgcn_readfirstlane((int)role);
-	if (role != 0) {
+	// the evaluator's state, and the reference's per-diagonal decisions for one completed block of 64 diagonals (true: the problem ends there)
+	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF, ez_zdropped = 0, r_done = 0;
+	int sat = 0;
+	auto eval_block = [&](int b) -> bool {
+		bool halt = false;
+		const int r0 = b * 64, r = r0 + lane;
+		unsigned long long bestk = 0; int hen = KSW_NEG_INF, hst = KSW_NEG_INF;
+		if (r < n_eff) {
+			bestk = __hip_atomic_load(&best_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			hen = __hip_atomic_load(&hen_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			hst = __hip_atomic_load(&hst_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const uint32_t h16 = (uint32_t)(bestk >> 24) & 0xffffu;
+		const int mH_l = (int)h16 - 32768, mt_l = (4095 - (int)((bestk >> 8) & 4095)) * BS_W + (63 - (int)(bestk & 255));
+		const int sat_l = r < n_eff && (h16 == 0 || h16 == 65535u) ? 1 : 0;
+		const int lim = n_eff - r0 < 64 ? n_eff - r0 : 64;
+		for (int ii = 0; ii < lim; ++ii) {
+			const int rr = r0 + ii;
+			const int mH = __builtin_amdgcn_readlane(mH_l, ii), mt = __builtin_amdgcn_readlane(mt_l, ii);
+			const int he = __builtin_amdgcn_readlane(hen, ii), hs = __builtin_amdgcn_readlane(hst, ii);
+			sat |= __builtin_amdgcn_readlane(sat_l, ii);
+			int st0, en0; bs_range(rr, qlen, tlen, w, st0, en0);
+			r_done = rr + 1;
+			if (en0 == tlen - 1) { if (he > ez_mte) ez_mte = he, ez_mte_q = rr - en0; if (rr == n_diag - 1) ez_score = he; }
+			if (rr - st0 == qlen - 1 && hs > ez_mqe) ez_mqe = hs, ez_mqe_t = st0;
+			const bool upd = mH > ez_max;
+			const int tl = mt - ez_max_t, ql = (rr - mt) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+			const bool stop = !upd && tl >= 0 && ql >= 0 && zdrop >= 0 && ez_max - mH > zdrop + l * e2;
+			if (upd) ez_max = mH, ez_max_t = mt, ez_max_q = rr - mt;
+			if (stop) { ez_zdropped = 1, ez_score = KSW_NEG_INF; halt = true; break; }
+		}
+		if (!halt && r0 + lim >= n_eff && n_eff < n_diag) { ez_zdropped = 1; r_done = n_eff + 1; halt = true; }      // the range ran empty (ksw2_extd2_sse.c:172)
+		if (sat) halt = true;
+		return halt;
+	};
+	// a problem of ONE strip (a ring of at most 64 columns: the extensions towards a block end) is one wave: it evaluates its own blocks
+	const bool solo = n_strips == 1;
+	if (role != 0 || solo) {
 	// ---- strips, in ascending order from the problem's counter ----
 	for (;;) {
 		uint32_t k = 0;
@@ -305,6 +342,7 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__threadfence();
 			if (lane == 0) (void)__hip_atomic_fetch_add(&done[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			if (solo) { __threadfence(); if (eval_block(b)) { gone = true; break; } }
 		}
 #ifdef PGA_BS_PROF
 		if (lane == 0 && jl == 0 && (k % 6) == 2) printf("[bstrips prof] strip %u: %lld diagonals; cycles per diagonal: poll %lld compute %lld everything %lld\n", k, pf_n, pf_poll / (pf_n ? pf_n : 1), pf_comp / (pf_n ? pf_n : 1), (clock64() - pf_t0) / (pf_n ? pf_n : 1));
@@ -312,13 +350,11 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 		if (gone) break;
 	}
 
-		return;
+		if (!solo) return;
 	}
 	// ---- the evaluator: the reference's per-diagonal decisions (ksw2_extd2_sse.c:326-366, ksw2.h:167-184), block by block as the strips complete
 	// them; a z-drop (or a clamped key, or a range that ran empty) raises the stop flag; then the walk back ----
-	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF, ez_zdropped = 0, r_done = 0;
-	int sat = 0;
-	{
+	if (!solo) {
 		bool halt = false;
 		for (int b = 0; b < nblk_eff && !halt; ++b) {
 			// (a guard, not a path: if a block's strips never report -- they cannot, by the ordering argument above -- the problem is handed back
@@ -326,34 +362,7 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 			{ long long polls = 0; while (__hip_atomic_load(&done[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need[b]) { if (++polls > 20000000LL) { sat = 1; break; } __builtin_amdgcn_s_sleep(8); } }
 			if (sat) { halt = true; break; }
 			__threadfence();
-			const int r0 = b * 64, r = r0 + lane;
-			unsigned long long bestk = 0; int hen = KSW_NEG_INF, hst = KSW_NEG_INF;
-			if (r < n_eff) {
-				bestk = __hip_atomic_load(&best_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				hen = __hip_atomic_load(&hen_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				hst = __hip_atomic_load(&hst_arr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			const uint32_t h16 = (uint32_t)(bestk >> 24) & 0xffffu;
-			const int mH_l = (int)h16 - 32768, mt_l = (4095 - (int)((bestk >> 8) & 4095)) * BS_W + (63 - (int)(bestk & 255));
-			const int sat_l = r < n_eff && (h16 == 0 || h16 == 65535u) ? 1 : 0;
-			const int lim = n_eff - r0 < 64 ? n_eff - r0 : 64;
-			for (int ii = 0; ii < lim; ++ii) {
-				const int rr = r0 + ii;
-				const int mH = __builtin_amdgcn_readlane(mH_l, ii), mt = __builtin_amdgcn_readlane(mt_l, ii);
-				const int he = __builtin_amdgcn_readlane(hen, ii), hs = __builtin_amdgcn_readlane(hst, ii);
-				sat |= __builtin_amdgcn_readlane(sat_l, ii);
-				int st0, en0; bs_range(rr, qlen, tlen, w, st0, en0);
-				r_done = rr + 1;
-				if (en0 == tlen - 1) { if (he > ez_mte) ez_mte = he, ez_mte_q = rr - en0; if (rr == n_diag - 1) ez_score = he; }
-				if (rr - st0 == qlen - 1 && hs > ez_mqe) ez_mqe = hs, ez_mqe_t = st0;
-				const bool upd = mH > ez_max;
-				const int tl = mt - ez_max_t, ql = (rr - mt) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-				const bool stop = !upd && tl >= 0 && ql >= 0 && zdrop >= 0 && ez_max - mH > zdrop + l * e2;
-				if (upd) ez_max = mH, ez_max_t = mt, ez_max_q = rr - mt;
-				if (stop) { ez_zdropped = 1, ez_score = KSW_NEG_INF; halt = true; break; }
-			}
-			if (!halt && r0 + lim >= n_eff && n_eff < n_diag) { ez_zdropped = 1; r_done = n_eff + 1; halt = true; }      // the range ran empty (ksw2_extd2_sse.c:172)
-			if (sat) halt = true;
+			halt = eval_block(b);
 		}
 		if (lane == 0) __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // strips that are still out there leave
 	}
@@ -454,7 +463,7 @@ int bstrips_mode()               // (read on every call: the parity tests switch
 	const char *e = getenv("PGA_BSTRIPS");
 	return !e ? 1 : !strcmp(e, "off") || !strcmp(e, "0") ? 0 : !strcmp(e, "force") ? 2 : 1;
 }
-int bstrips_max_problems() { static const int v = getenv("PGA_BSTRIPS_MAX") ? atoi(getenv("PGA_BSTRIPS_MAX")) : 8; return v; }
+int bstrips_max_problems() { static const int v = getenv("PGA_BSTRIPS_MAX") ? atoi(getenv("PGA_BSTRIPS_MAX")) : 32; return v; }
 int bstrips_long_diagonals() { static const int v = getenv("PGA_BSTRIPS_LONG") ? atoi(getenv("PGA_BSTRIPS_LONG")) : 6000; return v; }
 bool bstrips_eligible(const DpJob &j, const DpParams &P)
 {
@@ -505,7 +514,7 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab, size_t *words
 	// strips run sixteen diagonals apart: little more than the strips alive in one block of 64 diagonals are busy at a time (a wave that waits for
 	// its turn still holds a slot and polls: PGA_BSTRIPS_POOL_EXTRA more than that, default 4)
 	static const int extra = getenv("PGA_BSTRIPS_POOL_EXTRA") ? atoi(getenv("PGA_BSTRIPS_POOL_EXTRA")) : 4;
-	const uint32_t pool = 1u + (uint32_t)std::max(1, std::min(L.n_strips, std::min(alive_max + extra, 56)));      // + the evaluator
+	const uint32_t pool = L.n_strips == 1 ? 1u : 1u + (uint32_t)std::max(1, std::min(L.n_strips, std::min(alive_max + extra, 56)));      // + the evaluator; a single strip evaluates itself
 	tab[at] = pool, tab[at + 1] = (uint32_t)n_eff;
 	if (words) *words = L.words + row_words + 2;
 	return pool;
