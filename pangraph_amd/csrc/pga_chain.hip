@@ -883,16 +883,29 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	// set needs nothing.  The candidates of the batch after next and the marks of the next batch are requested while this one is looked at
 	// (two dependent loads, ~2 us, per batch otherwise); marks are only ever set, so a mark read early can only err towards "look again".
 	auto load_z = [&](int64_t kb_, int32_t &f_, int32_t &i_) { const int64_t km = kb_ - 1 - lane; f_ = 0; i_ = -1; if (kb_ > 0 && km >= 0) { const u128 e = z[km]; f_ = (int32_t)e.x; i_ = (int32_t)e.y; } };
-	int32_t zf1, zi1, zf2, zi2, tm1 = 1;
-	load_z(n_z, zf1, zi1);
-	load_z(n_z - 64, zf2, zi2);
-	if (zi1 >= 0) tm1 = t[zi1];
-	for (int64_t kb = n_z; kb > 0; kb -= 64) {
+	// FOUR batches per trip: their candidates and then their marks are four independent loads per lane, so a trip costs about two memory round
+	// trips for 256 candidates instead of one and a half for 64 (a whole-genome query holds 300 k candidates, nearly all of them marked)
+	int32_t zfA[4], ziA[4], tmA[4], zfB[4], ziB[4];
+#pragma unroll
+	for (int s4 = 0; s4 < 4; ++s4) load_z(n_z - 64 * s4, zfA[s4], ziA[s4]);
+#pragma unroll
+	for (int s4 = 0; s4 < 4; ++s4) load_z(n_z - 256 - 64 * s4, zfB[s4], ziB[s4]);
+#pragma unroll
+	for (int s4 = 0; s4 < 4; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }
+	for (int64_t kb4 = n_z; kb4 > 0; kb4 -= 256) {
+		int32_t zfC[4], ziC[4], tmC[4];
+#pragma unroll
+		for (int s4 = 0; s4 < 4; ++s4) { zfC[s4] = zfA[s4]; ziC[s4] = ziA[s4]; tmC[s4] = tmA[s4]; zfA[s4] = zfB[s4]; ziA[s4] = ziB[s4]; }
+#pragma unroll
+		for (int s4 = 0; s4 < 4; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }      // (early: re-read below whenever it says "unmarked")
+#pragma unroll
+		for (int s4 = 0; s4 < 4; ++s4) load_z(kb4 - 512 - 64 * s4, zfB[s4], ziB[s4]);
+#pragma unroll
+	for (int s4 = 0; s4 < 4; ++s4) {
+		const int64_t kb = kb4 - 64 * s4;
+		if (kb <= 0) break;
 		// a batch of 64 candidates, highest rank in lane 0
-		const int32_t zf = zf1, zi = zi1, tm = tm1;
-		zf1 = zf2; zi1 = zi2; tm1 = 1;
-		if (zi1 >= 0) tm1 = t[zi1];                                  // (early: re-read below whenever it says "unmarked")
-		load_z(kb - 128, zf2, zi2);
+		const int32_t zf = zfC[s4], zi = ziC[s4], tm = tmC[s4];
 		unsigned long long todo = __ballot(zi >= 0 && tm == 0);
 		if (__ballot(zi >= 0 && tm != 0 && tm == zf)) ev |= 2;
 		while (todo) {
@@ -959,6 +972,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		}
 	}
+	}
 	if (lane == 0) n_u_out[q] = n_u, n_v_out[q] = (int32_t)n_v;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	const unsigned long long c2 = wall_clock64();
@@ -976,12 +990,8 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 		for (int32_t i = 0; i < n_u; ++i) { const int32_t j = (int32_t)w[i].y; u2[i] = u[j]; w[i].x = (uint64_t)kk; kk += (int32_t)u[j]; }
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	// copy every chain, reversed to ascending anchor order, to its slot (all lanes)
-	for (int32_t c = 0; c < n_u; ++c) {
-		const int64_t src0 = (int64_t)(w[c].y >> 32), dst0 = (int64_t)w[c].x; const int32_t ni = (int32_t)u2[c];
-		for (int32_t m = lane; m < ni; m += 64) out[dst0 + m] = A[v[src0 + (ni - m - 1)]];
-	}
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// (the chains themselves are copied to their slots by k_bt_copy, a thread per anchor: one wave going through a query's chains one after the
+	// other paid two dependent loads per chain -- 3 ms for the 1 500 chains of a whole-genome query)
 	for (int32_t c = lane; c < n_u; c += 64) u[c] = u2[c];
 	if (ev_out && lane == 0) ev_out[q] = ev;
 	if (prof && lane == 0) {
@@ -989,6 +999,27 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 		atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2);
 		atomicMax(&prof[3], c1 - c0); atomicMax(&prof[4], c2 - c1); atomicMax(&prof[5], c3 - c2);
 	}
+}
+
+// Every kept anchor to its place in the compacted list: slot p of query q belongs to the chain c with w[c].x <= p < w[c].x + count (the chains'
+// offsets in their final order, left there by k_bt_walk) and takes the chain's anchors in ascending order (the walk collected them backwards).
+__global__ void k_bt_copy(int n_seq, const uint64_t *__restrict__ q_aoff, uint64_t n_a, const u128 *__restrict__ a, const int32_t *__restrict__ v_all, const uint64_t *__restrict__ u_all,
+                          const u128 *__restrict__ w_all, const int32_t *__restrict__ n_u_all, const int32_t *__restrict__ n_v_all, u128 *__restrict__ out_all)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_a) return;
+	int lo = 0, hi = n_seq;
+	while (lo < hi) { const int m = (lo + hi) >> 1; if (q_aoff[m + 1] <= i) lo = m + 1; else hi = m; }
+	const int q = lo;
+	const uint64_t b = q_aoff[q];
+	const int64_t p = (int64_t)(i - b);
+	if (p >= (int64_t)n_v_all[q]) return;
+	const u128 *w = w_all + b;
+	int cl = 0, ch = n_u_all[q];                                // the last chain whose offset is <= p
+	while (ch - cl > 1) { const int m = (cl + ch) >> 1; if ((int64_t)w[m].x <= p) cl = m; else ch = m; }
+	const int64_t src0 = (int64_t)(w[cl].y >> 32), dst0 = (int64_t)w[cl].x;
+	const int32_t ni = (int32_t)u_all[b + cl];
+	out_all[b + p] = a[b + (uint64_t)v_all[b + src0 + (ni - (p - dst0) - 1)]];
 }
 
 // ---- a hint for the replay of the candidate sort (lchain.c:52: radix_sort_128x(z, z + n_z)) ------------------------------------------------
@@ -1218,6 +1249,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 		EventTimer et3(st);
 		hipLaunchKernelGGL(k_bt_walk, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, n_z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
 		                   verbose ? prof.p : (unsigned long long*)nullptr, ev.p);
+		if (n_a) hipLaunchKernelGGL(k_bt_copy, dim3((unsigned)((n_a + 255) / 256)), dim3(256), 0, st, n_seq, q_aoff.p, (uint64_t)n_a, a.p, v.p, u.p, w.p, n_u.p, n_v.p, out.p);
 		const double ms_walk = et3.stop(K_BACKTRACK);
 		if (verbose) {
 			std::vector<uint32_t> he = ev.download(st), hq = q_tie_f.n ? q_tie_f.download(st) : std::vector<uint32_t>();
