@@ -96,8 +96,8 @@ void *dev_alloc(size_t bytes)
 		}
 		// nothing in this arena: the idle blocks of arenas that are not leased at the moment are free for all (their owners synchronised
 		// their streams before giving the arena back); the block changes its home to this arena
-		if (arena != 0) for (auto &kv : g_pools) {
-			if (kv.first.first != dev || kv.first.second == 0 || kv.first.second == arena) continue;
+		if (arena != 0 && arena != PGA_ARENA_QUIESCENT) for (auto &kv : g_pools) {
+			if (kv.first.first != dev || kv.first.second == 0 || kv.first.second == arena || kv.first.second == PGA_ARENA_QUIESCENT) continue;
 			auto ls = g_arena_leased.find(kv.first.second);
 			if (ls == g_arena_leased.end() || ls->second) continue;
 			Pool &O = kv.second;
@@ -112,6 +112,7 @@ void *dev_alloc(size_t bytes)
 	void *p = nullptr;
 	hipError_t e;
 	{ NsScope sc(g_n_malloc, g_ns_malloc); e = hipMalloc(&p, r); }
+	{ static const bool verbose = getenv("PGA_VERBOSE") != nullptr; if (verbose && r >= ((size_t)128 << 20)) fprintf(stderr, "[pga] allocator: hipMalloc of %.0f MB for arena %d (idle in the cache %.1f GB, handed out %.1f GB)\n", r / 1048576.0, arena, g_idle_total / 1073741824.0, g_live_total / 1073741824.0); }
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
 		dev_trim();                                   // give the idle blocks back and retry once
