@@ -30,11 +30,6 @@ void dev_set_arena(int arena);
 int dev_get_arena();   // calling thread: recycle device blocks only within this arena (one per concurrent sub-batch)
 int dev_lease_arena();                // a globally unique arena id until dev_release_arena(): one worker (one stream) at a time
 void dev_release_arena(int arena);    // call after the worker's stream has been synchronised
-// The QUIESCENT arena: one pool per device shared by every thread, for large scratch whose whole life lies between two synchronisations of the
-// stream that uses it -- allocate, launch, hipStreamSynchronize, free.  A block that comes back is idle on the device, so whoever asks next may
-// have it on any stream.  (Blocks of an ordinary arena are only reused inside it: six batches that start together each hold their own arena,
-// and a 3 GB staging buffer freed by one was a fresh hipMalloc -- 40 ms -- for the next.)
-#define PGA_ARENA_QUIESCENT 0x7fff0001
 struct ArenaScope {                   // the calling thread allocates in `arena` while the scope lives
 	int prev; explicit ArenaScope(int arena) : prev(dev_get_arena()) { dev_set_arena(arena); } ~ArenaScope() { dev_set_arena(prev); }
 	ArenaScope(const ArenaScope&) = delete; ArenaScope &operator=(const ArenaScope&) = delete;

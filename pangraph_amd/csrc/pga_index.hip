@@ -121,18 +121,18 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 		int gbits = 0; while ((1LL << gbits) < S.n_grp) ++gbits;
 		const int hash_bits = std::min(64, 2 * k);
 		if (hash_bits + gbits <= 64 && !getenv("PGA_INDEX_TWO_SORTS")) {
-			// (the scratch of this function -- 44 bytes per minimizer -- lives between here and the synchronisation in front of the return: quiescent arena)
-			DBuf<uint64_t> ck, ck2, vy; DBuf<uint32_t> orig, orig2, flag, gid; DBuf<uint8_t> tmp, tmpb;
-			{ ArenaScope quiet(PGA_ARENA_QUIESCENT); ck.alloc(n); ck2.alloc(n); vy.alloc(n); orig.alloc(n); orig2.alloc(n); flag.alloc(n); gid.alloc(n); }
+			DBuf<uint64_t> ck(n), ck2(n), vy(n);
+			DBuf<uint32_t> orig(n), orig2(n);
 			hipLaunchKernelGGL(k_split_ck, dim3(nb), dim3(256), 0, st, M.mz.p, n, S.d_grp_of_seq.p, hash_bits, ck.p, vy.p, orig.p);
 			size_t tmp_bytes = 0;
 			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, hash_bits + gbits, st));
-			{ ArenaScope quiet(PGA_ARENA_QUIESCENT); tmp.alloc(tmp_bytes ? tmp_bytes : 1); }
+			DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
 			PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, hash_bits + gbits, st));
+			DBuf<uint32_t> flag(n), gid(n);
 			hipLaunchKernelGGL(k_head_flags_ck, dim3(nb), dim3(256), 0, st, ck2.p, n, flag.p);
 			size_t tmp2 = 0;
 			PGA_HIP(rocprim::inclusive_scan(nullptr, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
-			{ ArenaScope quiet(PGA_ARENA_QUIESCENT); tmpb.alloc(tmp2 ? tmp2 : 1); }
+			DBuf<uint8_t> tmpb(tmp2 ? tmp2 : 1);
 			PGA_HIP(rocprim::inclusive_scan(tmpb.p, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
 			uint32_t n_keys = 0;
 			PGA_HIP(hipMemcpyAsync(&n_keys, gid.p + (n - 1), 4, hipMemcpyDeviceToHost, st));

@@ -3,7 +3,7 @@
 // A batch allocates a few dozen device arrays per stage and the DP stage a scratch slab of tens of GB; hipMalloc and
 // hipFree cost from 0.1 ms to tens of ms each and hipFree synchronises the device, so freed blocks are kept in
 // per-device, size-rounded free lists and handed out again (a level of `pangraph build` repeats the same sizes call
-// after call).  The cache is bounded: idle blocks may fill what the live blocks leave of 85 % of the device memory (and at most PGA_CACHE_GB,
+// after call).  The cache is bounded: idle blocks may fill what the live blocks leave of 90 % of the device memory (and at most PGA_CACHE_GB,
 // default 200); beyond that the largest idle blocks (of any pool) are released.  hipFree synchronises the device, so a cache that is too
 // small costs far more than the memory it saves.
 #include "pga_common.h"
@@ -46,7 +46,7 @@ size_t cache_limit()                               // (called with g_mu held)
 	// PGA_MEM_SHARE: the part of the device this process may fill (several processes on one device, e.g. the single-device debugging mode of
 	// bench.py: each keeps a cache of its own, and the runtime aborts a queue when nothing is left for its own needs)
 	static const double share = [] { const char *e = getenv("PGA_MEM_SHARE"); const double v = e ? atof(e) : 1.0; return v > 0.0 && v <= 1.0 ? v : 1.0; }();
-	const size_t room = (size_t)((double)(dev_total / 100 * 85) * share);
+	const size_t room = (size_t)((double)(dev_total / 100 * 90) * share);
 	const size_t lim = room > g_live_total ? room - g_live_total : 0;
 	return lim < cap ? lim : cap;
 }
@@ -96,8 +96,8 @@ void *dev_alloc(size_t bytes)
 		}
 		// nothing in this arena: the idle blocks of arenas that are not leased at the moment are free for all (their owners synchronised
 		// their streams before giving the arena back); the block changes its home to this arena
-		if (arena != 0 && arena != PGA_ARENA_QUIESCENT) for (auto &kv : g_pools) {
-			if (kv.first.first != dev || kv.first.second == 0 || kv.first.second == arena || kv.first.second == PGA_ARENA_QUIESCENT) continue;
+		if (arena != 0) for (auto &kv : g_pools) {
+			if (kv.first.first != dev || kv.first.second == 0 || kv.first.second == arena) continue;
 			auto ls = g_arena_leased.find(kv.first.second);
 			if (ls == g_arena_leased.end() || ls->second) continue;
 			Pool &O = kv.second;

@@ -674,8 +674,7 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 		DBuf<int> d_ovf(1); d_ovf.zero(st);
 		uint32_t cap = SK_TILE / 4;                           // expected density is 2/(w+1) per base
 		for (;;) {
-			DBuf<u128> stage;                                   // (4 bytes per base: from the quiescent arena -- its last use is behind the synchronisations below)
-			{ ArenaScope quiet(PGA_ARENA_QUIESCENT); stage.alloc(nt * (size_t)cap); }
+			DBuf<u128> stage(nt * (size_t)cap);
 			EventTimer et(st);
 			// eight consecutive positions per thread where w is one of the presets' (asm5/asm10: 19, asm20: 10) and a key fits 64 bits
 			static const bool no8 = getenv("PGA_SKETCH_STRIDED") != nullptr;
