@@ -4,7 +4,7 @@
 // hipFree cost from 0.1 ms to tens of ms each and hipFree synchronises the device, so freed blocks are kept in
 // per-device, size-rounded free lists and handed out again (a level of `pangraph build` repeats the same sizes call
 // after call).  The cache is bounded: idle blocks may fill what the live blocks leave of 90 % of the device memory (and at most PGA_CACHE_GB,
-// default 200); beyond that the largest idle blocks (of any pool) are released.  hipFree synchronises the device, so a cache that is too
+// default 200); beyond that the blocks that have been idle longest (of any pool) are released.  hipFree synchronises the device, so a cache that is too
 // small costs far more than the memory it saves.
 #include "pga_common.h"
 #include <map>
@@ -25,6 +25,14 @@ std::map<std::pair<int, int>, Pool> g_pools;       // (device, arena)
 std::map<void*, Live> g_live;                      // block -> size and home pool
 size_t g_idle_total = 0;
 thread_local int t_arena = 0;
+// idle blocks by age: when the cache is over its limit the blocks that have lain idle longest go first (the hoard of sizes that never came back),
+// not the largest (the DP slabs: sixteen GB and a second apiece to buy back)
+struct IdleRef { std::pair<int, int> pool; size_t size; void *p; };
+std::map<unsigned long long, IdleRef> g_idle_by_age;
+std::map<void*, unsigned long long> g_idle_seq;
+unsigned long long g_seq = 0;
+void idle_note(const std::pair<int, int> &pool, size_t size, void *p) { const unsigned long long q = ++g_seq; g_idle_seq[p] = q; g_idle_by_age[q] = IdleRef{pool, size, p}; }
+void idle_forget(void *p) { auto it = g_idle_seq.find(p); if (it != g_idle_seq.end()) { g_idle_by_age.erase(it->second); g_idle_seq.erase(it); } }
 
 size_t round_size(size_t b)
 {
@@ -91,7 +99,7 @@ void *dev_alloc(size_t bytes)
 		auto it = P.idle.lower_bound(r);
 		if (it != P.idle.end() && (it->first <= r + r / 4 || (r >= ((size_t)16 << 20) && it->first <= 2 * r))) {   // large blocks: up to twice the need beats a hipMalloc (and the hipFree it provokes)
 			void *p = it->second; const size_t sz = it->first;
-			P.idle.erase(it); P.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz;
+			P.idle.erase(it); P.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz; idle_forget(p);
 			return p;
 		}
 		// nothing in this arena: the idle blocks of arenas that are not leased at the moment are free for all (their owners synchronised
@@ -104,7 +112,7 @@ void *dev_alloc(size_t bytes)
 			auto jt = O.idle.lower_bound(r);
 			if (jt != O.idle.end() && (jt->first <= r + r / 4 || (r >= ((size_t)16 << 20) && jt->first <= 2 * r))) {
 				void *p = jt->second; const size_t sz = jt->first;
-				O.idle.erase(jt); O.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz;
+				O.idle.erase(jt); O.idle_bytes -= sz; g_idle_total -= sz; g_live[p] = Live{sz, dev, arena}; g_live_total += sz; idle_forget(p);
 				return p;
 			}
 		}
@@ -138,13 +146,20 @@ void dev_free(void *p)
 			g_live.erase(it); g_live_total -= lv.size;
 			Pool &P = g_pools[{lv.dev, lv.arena}];
 			P.idle.emplace(lv.size, p); P.idle_bytes += lv.size; g_idle_total += lv.size;
-			// over the limit: release the largest idle blocks, whichever pool holds them (they are the DP slabs of past calls)
-			while (g_idle_total > cache_limit()) {
-				Pool *best = nullptr;
-				for (auto &kv : g_pools) if (!kv.second.idle.empty() && (!best || std::prev(kv.second.idle.end())->first > std::prev(best->idle.end())->first)) best = &kv.second;
-				if (!best) break;
-				auto big = std::prev(best->idle.end());
-				drop.push_back(big->second); best->idle_bytes -= big->first; g_idle_total -= big->first; best->idle.erase(big);
+			idle_note({lv.dev, lv.arena}, lv.size, p);
+			// over the limit: the blocks that have been idle longest go, whichever pool holds them, until 4 GB below it (hipFree synchronises the
+			// device: not on every free from here on)
+			if (g_idle_total > cache_limit()) {
+				const size_t lim = cache_limit(), target = lim > ((size_t)4 << 30) ? lim - ((size_t)4 << 30) : 0;
+				while (g_idle_total > target && !g_idle_by_age.empty()) {
+					const IdleRef v = g_idle_by_age.begin()->second;
+					Pool &V = g_pools[v.pool];
+					auto rg = V.idle.equal_range(v.size);
+					for (auto jt = rg.first; jt != rg.second; ++jt) if (jt->second == v.p) { V.idle.erase(jt); break; }
+					V.idle_bytes -= v.size; g_idle_total -= v.size;
+					drop.push_back(v.p);
+					idle_forget(v.p);
+				}
 			}
 		}
 	}
@@ -189,7 +204,7 @@ void dev_trim()
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
 		for (auto &kv : g_pools) { for (auto &b : kv.second.idle) drop.push_back(b.second); kv.second.idle.clear(); kv.second.idle_bytes = 0; }
-		g_idle_total = 0;
+		g_idle_total = 0; g_idle_by_age.clear(); g_idle_seq.clear();
 	}
 	for (void *q : drop) (void)hipFree(q);
 }
