@@ -879,6 +879,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	// ---- walks (every lane executes the same control flow) ----
 	const int32_t max_drop = P.bw;
 	int64_t n_v = 0; int32_t n_u = 0;
+	unsigned long long pc_walks = 0, pc_reload = 0, pc_iter = 0, pc_trips = 0, pc_marktk = 0, pc_walktk = 0;      // (verbose: where a query's walk time goes)
 	// Almost every candidate is an inner anchor of a chain that a better candidate has already walked over: a batch whose 64 marks are all
 	// set needs nothing.  The candidates of the batch after next and the marks of the next batch are requested while this one is looked at
 	// (two dependent loads, ~2 us, per batch otherwise); marks are only ever set, so a mark read early can only err towards "look again".
@@ -893,7 +894,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 #pragma unroll
 	for (int s4 = 0; s4 < 4; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }
 	for (int64_t kb4 = n_z; kb4 > 0; kb4 -= 256) {
-		int32_t zfC[4], ziC[4], tmC[4];
+		int32_t zfC[4], ziC[4], tmC[4]; ++pc_trips;
 #pragma unroll
 		for (int s4 = 0; s4 < 4; ++s4) { zfC[s4] = zfA[s4]; ziC[s4] = ziA[s4]; tmC[s4] = tmA[s4]; zfA[s4] = zfB[s4]; ziA[s4] = ziB[s4]; }
 #pragma unroll
@@ -917,7 +918,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 			if (!todo) break;
 			const int src = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
-			const int32_t e0 = rl(zi, src), zx = rl(zf, src);
+			const int32_t e0 = rl(zi, src), zx = rl(zf, src); ++pc_walks; const unsigned long long wk0 = prof ? wall_clock64() : 0;
 			// walk
 			int32_t wb = e0 - 63; if (wb < 0) wb = 0;
 			int32_t wp = -1, wf = 0, wt = 1;
@@ -925,6 +926,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 			int32_t cur = e0, m = 0, kept = 0, max_s = 0;
 			const int64_t n_v0 = n_v;
 			for (;;) {
+				++pc_iter;
 				// Co-linear stretch inside the window, all at once: while the path steps to the anchor just below (p[j] == j-1), that
 				// anchor is unused (t == 0) and scores less (f[j-1] < f[j]), every step is a new maximum of z.x - f -- provided the
 				// last step was one too (kept == m; at the start both sides are 0) -- so nothing can break the walk and `run` steps
@@ -950,6 +952,7 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 				if (nxt < 0) sv = zx;
 				else {
 					if (nxt < wb) {
+						++pc_reload;
 						wb = nxt - 63; if (wb < 0) wb = 0;
 						const int32_t idx = wb + lane;
 						wp = -1, wf = 0, wt = 1;
@@ -964,8 +967,10 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 				cur = nxt;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");              // the path was stored by whichever lanes held it
+			const unsigned long long wk1 = prof ? wall_clock64() : 0;
 			// kept part: the first `kept` path elements (the walk stops before max_i, lchain.c:72); marks stay even if the chain is dropped
 			for (int32_t c = lane; c < kept; c += 64) t[v[n_v0 + c]] = zx;          // (nonzero: min_sc > 0) the claimant's score
+			if (prof) { const unsigned long long wk2 = wall_clock64(); pc_walktk += wk1 - wk0; pc_marktk += wk2 - wk1; }
 			// score of the chain: z.x - f[max_i]; max_i is the path element number `kept` (or -1 past the root)
 			const int32_t sc = max_s;
 			if (kept > 0 && sc >= P.min_sc && kept >= P.min_cnt) { if (lane == 0) u[n_u] = (uint64_t)sc << 32 | (uint64_t)kept, u2[n_u] = (uint64_t)zx; ++n_u; n_v += kept; if (zx == last_emit) ev |= 8; last_emit = zx; }
@@ -998,6 +1003,8 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 		const unsigned long long c3 = wall_clock64();
 		atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2);
 		atomicMax(&prof[3], c1 - c0); atomicMax(&prof[4], c2 - c1); atomicMax(&prof[5], c3 - c2);
+		// of the query with the most anchors: walks, window reloads, walk iterations, candidate trips, ticks inside walks, ticks setting marks
+		if ((unsigned long long)n >= atomicMax(&prof[6], (unsigned long long)n)) { prof[7] = pc_walks; prof[8] = pc_reload; prof[9] = pc_iter; prof[10] = pc_trips; prof[11] = pc_walktk; prof[12] = pc_marktk; }
 	}
 }
 
@@ -1209,7 +1216,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
 	{
 		EventTimer et(st);
-		DBuf<unsigned long long> prof(12); prof.zero(st);
+		DBuf<unsigned long long> prof(16); prof.zero(st);
 		DBuf<int64_t> n_z((size_t)n_seq);
 		DBuf<uint32_t> ev((size_t)n_seq), q_tie_f;
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
@@ -1266,6 +1273,8 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 			std::vector<unsigned long long> pr = prof.download(st);   // wall_clock64 ticks at 100 MHz
 			fprintf(stderr, "[pga]   backtrack: %.3f ms = candidate lists %.3f + walks %.3f; sort replay %.3f (per-query max: walks %.2f, compact %.2f ms)\n", ms, ms_list, ms_walk, ms_sort,
 			        pr[4] * 1e-5, pr[5] * 1e-5);
+			fprintf(stderr, "[pga]   backtrack, the query with the most anchors (%llu): %llu walks, %llu window reloads, %llu walk iterations, %llu candidate trips; inside walks %.2f ms, setting marks %.2f ms\n",
+			        pr[6], pr[7], pr[8], pr[9], pr[10], pr[11] * 1e-5, pr[12] * 1e-5);
 		}
 		if (tm) { tm->kern[K_BACKTRACK].ms += ms; tm->kern[K_BACKTRACK].launches += 1; tm->kern[K_BACKTRACK].alg_bytes += 40.0 * (double)n_a; } // f,p read + anchors read + compacted anchors written
 	}
