@@ -94,7 +94,8 @@ int pga_set_device(int dev);
 int pga_warm_streams(int32_t n);
 /* the library's device-memory cache (diagnostics): out[0..5] = hipMalloc calls behind the cache, ns spent in them, hipFree calls, ns, bytes handed
  * out at the moment, bytes idle in the cache.  A host that sees hipFree calls grow from batch to batch has filled the device: the cache gives
- * its largest idle blocks back (PGA_CACHE_GB, 90 % of the device) and hipFree synchronises the device each time. */
+ * the blocks that have been idle longest back, down to 4 GB below its limit (PGA_CACHE_GB, 90 % of the device), and hipFree synchronises the
+ * device each time. */
 void pga_mem_stats(int64_t out[6]);
 
 /* Stage taps for parity tests (same semantics as the reference functions named in each comment). */

@@ -456,6 +456,8 @@ struct Driver {
 		P.k = k; P.bw = opt.bw; P.bw_long = std::max((int)(opt.bw_long * 1.5 + 1.), (int)(opt.bw * 1.5 + 1.)); P.max_gap = opt.max_gap; P.min_cnt = opt.min_cnt; P.min_chain_score = opt.min_chain_score;
 		P.min_ksw_len = opt.min_ksw_len; P.a = opt.a; P.q = opt.q; P.e = opt.e; P.no_end_flt = (opt.flag & MM_F_NO_END_FLT) ? 1 : 0; P.probe_m_max = lean_probes ? probe_m_max : -1;
 		P.max_sw_mat = opt.max_sw_mat;
+		const int g_max_env = getenv("PGA_PLAN_G_MAX") ? atoi(getenv("PGA_PLAN_G_MAX")) : 4096;
+		P.g_max = std::min(4096, std::max(0, g_max_env));      // PLAN_G_MAX of pga_plan.hip
 		return P;
 	}
 	// what plan() leaves in a RegTask, from the planner's records (same order of requests: left extension, segments, right extension)
@@ -894,6 +896,8 @@ static void plan_list(const SeqSet &S, Driver &D, std::vector<std::pair<QueryCtx
 			std::vector<u128> tmp((size_t)q.n_a);
 			PGA_HIP(hipMemcpy(tmp.data(), D.d_anchors + q.a_off, tmp.size() * sizeof(u128), hipMemcpyDeviceToHost));
 			q.a = tmp.data();
+			// (with the plans on the device nobody has computed this region's extent on the host: the kernel filled it before it gave up)
+			{ Reg &r = T.r; const PlanOut &O = out[i]; r.rev = (uint32_t)O.rev, r.rid = O.rid, r.rs = O.r_rs, r.re = O.r_re, r.qs = O.r_qs, r.qe = O.r_qe, r.mlen = O.r_mlen, r.blen = O.r_blen; }
 			D.plan(q, T);
 			q.a = nullptr;
 			PGA_HIP(hipMemcpy(D.d_anchors + q.a_off + (uint64_t)T.r.as, tmp.data() + T.r.as, (size_t)T.r.cnt * sizeof(u128), hipMemcpyHostToDevice));

@@ -1170,6 +1170,8 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 		seg_q.alloc((size_t)n_seq); seg_q.zero(st);
 		EventTimer et(st);
 		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
+		// (A/B mode without the fast kernel: EVERY segment runs the tree re-enactment, so every query counts as "has such a segment" for k_need_exact)
+		if (!use_fast && n_seq > 0) PGA_HIP(hipMemsetD32Async((hipDeviceptr_t)seg_q.p, 1, (size_t)n_seq, st));
 		DBuf<unsigned long long> cprof(16); cprof.zero(st);
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 		const bool prof_on = verbose && getenv("PGA_CHAIN_PROF");
@@ -1327,6 +1329,9 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 // On the BASELINE build: no event of kind (2) at all, ~37 queries per step (of 230 000) with (3).
 void chain_all(const SeqSet &S, SeedResult &SR, const mm_mapopt_t &opt, int k, ChainResult &O, hipStream_t st, Timers *tm, bool exact_order)
 {
+	// what only this stage reads of the seeding stage's result goes back to the arena when it returns (36 B per anchor that used to stay live through
+	// the alignment stage of every batch in flight); the alignment stage reads h_q_aoff / h_rep_len only.  Freed blocks are reused in stream order.
+	struct Release { SeedResult &R; ~Release() { R.raw_x.release(); R.raw_y.release(); R.srt_x.release(); R.srt_y.release(); R.dupc.release(); R.q_tie.release(); R.a.release(); } } release_on_return{SR};
 	const int n_seq = S.n_seq;
 	const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 	if (exact_order || exact_sorts_forced()) {

@@ -29,6 +29,7 @@ struct PlanItem {               // kind 0: a RUN of consecutive segments the ide
 
 struct PlanParams {
 	int32_t k, bw, bw_long, max_gap, min_cnt, min_chain_score, min_ksw_len, a, q, e, no_end_flt, probe_m_max;
+	int32_t g_max, pad;         // long gaps of a region the kernel plans itself (<= PLAN_G_MAX of pga_plan.hip; PGA_PLAN_G_MAX lowers it: tests of the host route)
 	int64_t max_sw_mat;
 };
 

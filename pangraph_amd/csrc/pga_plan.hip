@@ -116,7 +116,7 @@ void k_plan_regions(const PlanIn *__restrict__ in, uint32_t n_regions, u128 *__r
 		n_g += __popcll(m);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	if (n_g > PLAN_G_MAX) { O.status = 2; if (lane == 0) out[rid_x] = O; return; }
+	if (n_g > P.g_max) { O.status = 2; if (lane == 0) out[rid_x] = O; return; }
 	// ---- ignore_indel_bursts(A, as1, cnt1, 10, 40, max_gap >> 1, 10) (align.c:392-431) and join_crowded_gaps(A, as1, cnt1, 30, max_gap >> 1)
 	// (align.c:433-469): both read indels only, so they are evaluated on the unflagged anchors and the flags are set afterwards ----
 	int n_f = 0;

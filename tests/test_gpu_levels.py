@@ -69,6 +69,24 @@ def test_c3_small_every_wave(gpu_lib, exp):
         assert [dict(n=len(r), sha256=digest(r)) for r in got] == e["groups"], label
 
 
+@pytest.mark.parametrize("kw", [dict(sensitivity=5), dict(sensitivity=20), dict(sensitivity=10, kmer_length=15), dict(sensitivity=20, kmer_length=16),
+                                dict(sensitivity=5, kmer_length=17)], ids=lambda k: "asm%d%s" % (k["sensitivity"], "-k%d" % k["kmer_length"] if "kmer_length" in k else ""))
+def test_c3_small_every_wave_other_presets_live_vs_reference(gpu_lib, ref_lib, exp, kw):
+    """the multi-level build of test_c3_small_every_wave under the other two presets and under -k (options.c:115-130; align_with_minimap2_lib.rs:42-57:
+    sensitivity picks asm5 / asm10 / asm20, kmer_length overrides k; an even k takes the serial sketch kernel): every wave live against the compiled
+    reference"""
+    p = exp["c3_small"]["params"]
+    pop = Population(p["seed"], p["n"], p["length"], Rates(**p["rates"]))
+    n = 0
+    for label, groups, names in pop.build_waves():
+        got = product_align_groups(groups, names, **kw)
+        want = ref_align_groups(groups, names, **kw)
+        for g, (a, b) in enumerate(zip(got, want)):
+            assert a == b, (label, g, len(a), len(b))
+            n += len(a)
+    assert n > 50
+
+
 def test_c3_full_size_every_wave_vs_reference(gpu_lib, ref_lib):
     """config C3: 10 genomes x 5 Mbp, the whole build, every wave against the reference run here"""
     pop = Population(2, 10, 5_000_000)
