@@ -73,6 +73,7 @@ typedef struct {
 #define PGO_EZ_EXTZ_ONLY  0x40
 #define PGO_EZ_REV_CIGAR  0x80
 #define PGO_NEG_INF (-0x40000000)
+void pgo_lb_counters(long long out[3], int reset);   /* observer of the product's length-bound stop (pgo_ksw.c) */
 void pgo_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, pgo_extz_t *ez);
 int pgo_ll_i16(int qlen, const uint8_t *query, int m, const int8_t *mat, int tlen, const uint8_t *target,

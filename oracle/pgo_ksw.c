@@ -80,9 +80,19 @@ static int apply_zdrop(pgo_extz_t *ez, int32_t H, int r, int t, int zdrop, int8_
 	return 0;
 }
 
+/* An OBSERVER, not part of the restatement: the product's kernels end an extension towards a block end early when alignment length alone proves
+ * that the record is final (pangraph_amd/csrc/pga_dp.h, "length-bound stop": tlen <= 32, qlen >= w + 2 tlen, w >= 64).  The same rule is
+ * evaluated here beside the reference's full sweep; when it says "final" the record is remembered and compared with the record the sweep ends
+ * with.  pgo_lb_counters(): [0] problems in which the rule closed, [1] problems in which the full sweep still changed the record afterwards
+ * (must stay 0: tests/test_oracle_cpu.py), [2] diagonals the sweeps ran after the rule had closed. */
+static long long pgo_lb_cnt[3];
+void pgo_lb_counters(long long out[3], int reset) { for (int i = 0; i < 3; ++i) { out[i] = __atomic_load_n(&pgo_lb_cnt[i], __ATOMIC_RELAXED); if (reset) __atomic_store_n(&pgo_lb_cnt[i], 0, __ATOMIC_RELAXED); } }
+static int lb_gap(int q, int e, int q2, int e2, int L) { int a = q + e * L, b = q2 + e2 * L; return a < b ? a : b; }
+
 void pgo_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, pgo_extz_t *ez)
 {
+	int lb_on = 0, lb_tail = 0, lb_hit = 0; pgo_extz_t lb_ez;
 	int r, t, qe, qe_h = q + e /* ksw2_extd2_sse.c:73: taken BEFORE the (q,e)<->(q2,e2) swap and used for H at r==0 */, n_col, tlen16, qlen16, last_st, last_en, max_sc, min_sc, long_thres, long_diff;
 	int with_cigar = !(flag & PGO_EZ_SCORE_ONLY), approx_max = !!(flag & PGO_EZ_APPROX_MAX);
 	int32_t *H = 0, H0 = 0, last_H0_t = 0;
@@ -108,6 +118,10 @@ void pgo_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 	long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	if (!approx_max && tlen <= 32 && w >= 64 && qlen >= w + 2 * tlen && sc_mch >= 0 && sc_mis <= sc_mch && sc_N <= sc_mch && q >= 0 && e >= 0 && q2 >= 0 && e2 >= 0) {
+		lb_on = 1;
+		lb_tail = tlen > 16 ? sc_mch * tlen - lb_gap(q, e, q2, e2, w + 32 - 2 * tlen) + (sc_mch + q + e) * (2 * tlen - 32) : INT32_MIN;
+	}
 
 	u = (int8_t*)malloc((size_t)tlen16 * 7);
 	v = u + tlen16, x = v + tlen16, y = x + tlen16, x2 = y + tlen16, y2 = x2 + tlen16, s = y2 + tlen16;
@@ -223,6 +237,11 @@ void pgo_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 			if (r - st0 == qlen - 1 && H[st0] > ez->mqe) ez->mqe = H[st0], ez->mqe_t = st0;
 			if (apply_zdrop(ez, max_H, r, max_t, zdrop, e2)) break;
 			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez->score = H[tlen - 1];
+			if (lb_hit) __atomic_fetch_add(&pgo_lb_cnt[2], 1, __ATOMIC_RELAXED);
+			if (lb_on && !lb_hit && (r & 7) == 7 && r >= 2 * tlen && r <= w + 30) {     /* the observer (see above) */
+				int mm = (int32_t)ez->max < ez->mte ? (int32_t)ez->max : ez->mte;
+				if (sc_mch * tlen - lb_gap(q, e, q2, e2, r + 3 - 2 * tlen) <= mm && lb_tail <= mm) lb_hit = 1, lb_ez = *ez;
+			}
 		} else { /* ksw2_extd2_sse.c:367-384: follow one cell per diagonal */
 			if (r > 0) {
 				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
@@ -237,6 +256,11 @@ void pgo_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 		last_st = st, last_en = en;
 	}
 	free(u); free(sf); free(qr); free(H);
+	if (lb_hit) {
+		__atomic_fetch_add(&pgo_lb_cnt[0], 1, __ATOMIC_RELAXED);
+		if (!(ez->zdropped && ez->max == lb_ez.max && ez->max_t == lb_ez.max_t && ez->max_q == lb_ez.max_q && ez->mte == lb_ez.mte && ez->mte_q == lb_ez.mte_q &&
+		      ez->mqe == lb_ez.mqe && ez->mqe_t == lb_ez.mqe_t && ez->score == lb_ez.score)) __atomic_fetch_add(&pgo_lb_cnt[1], 1, __ATOMIC_RELAXED);
+	}
 	if (with_cigar) { /* ksw2_extd2_sse.c:389-399 */
 		int rev_cigar = !!(flag & PGO_EZ_REV_CIGAR);
 		if (!ez->zdropped && !(flag & PGO_EZ_EXTZ_ONLY))

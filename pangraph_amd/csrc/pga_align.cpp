@@ -1319,7 +1319,7 @@ void align_batch(const SeqSet &S, const mm_mapopt_t &opt, int k, const std::vect
 	// The queries are dealt into a few SETS that run their rounds concurrently (one host thread, one stream and one
 	// device-memory arena each): while the GPU works on one set's problems the host classifies, collects and advances
 	// another's, and the short dependent rounds at the end of one set hide behind the bulk of the next.
-	const DpParams P{opt.q, opt.e, opt.q2, opt.e2, D.mat[0], D.mat[1], D.mat[24]};
+	const DpParams P{opt.q, opt.e, opt.q2, opt.e2, D.mat[0], D.mat[1], D.mat[24], dp_lb_mode()};
 	// deal the queries by anchor count (largest first, round robin): balanced sets
 	// (two sets pay from a few hundred queries on; below that the few long problems of a set only get in each other's way)
 	int n_sets = getenv("PGA_ALIGN_SETS") ? atoi(getenv("PGA_ALIGN_SETS")) : (n_seq >= 256 && part_concurrency() < 2 ? 2 : 1);

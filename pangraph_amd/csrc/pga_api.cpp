@@ -757,7 +757,7 @@ extern "C" int pga_stage_extd2(int32_t n_jobs, const uint8_t *const *q, const in
 		DBuf<uint32_t> d_pk; d_pk.upload(pk, 0); DBuf<uint16_t> d_nm; d_nm.upload(nm, 0);
 		const PkBases d{d_pk.p, d_nm.p};
 		a = a < 0 ? -a : a; b = b > 0 ? -b : b; sc_ambi = sc_ambi > 0 ? -sc_ambi : sc_ambi;
-		DpParams P{gapo, gape, gapo2, gape2, a, b, sc_ambi};
+		DpParams P{gapo, gape, gapo2, gape2, a, b, sc_ambi, dp_lb_mode()};
 		std::vector<DpJob> run; std::vector<int> idx;
 		for (int i = 0; i < n_jobs; ++i) if (qlen[i] > 0 && tlen[i] > 0) run.push_back(jobs[i]), idx.push_back(i);
 		std::vector<DpRes> res; PinVec<uint32_t> cg;

@@ -23,6 +23,7 @@
 #include <thread>
 #include <array>
 #include <cstdio>
+#include <cstring>
 
 namespace pga {
 
@@ -486,12 +487,17 @@ struct LaneLease {
 	LaneLease(const LaneLease&) = delete; LaneLease &operator=(const LaneLease&) = delete;
 };
 
+int dp_lb_mode() { const char *e = getenv("PGA_LB"); return !e ? 0 : !strcmp(e, "off") || !strcmp(e, "0") ? 1 : !strcmp(e, "check") ? 2 : 0; }
+
 void dp_run(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
 	dp_run_impl(d_bases, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr);
 	// problems the corridor kernel could not prove exact: full matrix, results spliced in (their CIGARs go behind the pool)
 	std::vector<uint32_t> redo;
-	for (size_t i = 0; i < res.size(); ++i) if (res[i].n_cigar == -9) redo.push_back((uint32_t)i);
+	for (size_t i = 0; i < res.size(); ++i) {
+		if (res[i].n_cigar == -11) throw std::runtime_error("pga: the length-bound stop of an extension (pga_dp.h) closed on a record that the full sweep changed: qlen " + std::to_string(jobs[i].qlen) + " tlen " + std::to_string(jobs[i].tlen));
+		if (res[i].n_cigar == -9) redo.push_back((uint32_t)i);
+	}
 	if (redo.empty()) return;
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     corridor / lane kernels: %zu of %zu problems handed back, workgroup kernel\n", redo.size(), jobs.size());
 	std::vector<DpJob> jb(redo.size());
@@ -808,6 +814,15 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->kern[kk].cells += cells; tm->dp_bases += bases;
 		}
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
+		if (const char *dump = getenv("PGA_DP_DUMP")) {           // development: geometry and outcome of every problem of the banded classes, appended as text
+			if (c == 10 || c == 11 || c == 12 || c == 2 || c == 3) {
+				static std::mutex dmu; std::lock_guard<std::mutex> lk(dmu);
+				if (FILE *f = fopen(dump, "a")) {
+					for (size_t i = 0; i < ids.size(); ++i) { const DpJob &j = jobs[ids[i]]; fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d\n", c, j.qlen, j.tlen, j.w, j.flag, j.zdrop, j.end_bonus, r[i].pad, r[i].max, r[i].max_q, r[i].max_t, r[i].zdropped); }
+					fclose(f);
+				}
+			}
+		}
 		if (((c >= 2 && c <= 4) || c == 7 || c == 10 || c == 11 || c == 12) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {

@@ -139,6 +139,7 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 	// the evaluator's state, and the reference's per-diagonal decisions for one completed block of 64 diagonals (true: the problem ends there)
 	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF, ez_zdropped = 0, r_done = 0;
 	int sat = 0;
+	const LbStop LB = lb_stop_of(qlen, tlen, w, flag, q, e, q2, e2, sc_mch, sc_mis, sc_N, P.lb_mode == 2 ? 0 : P.lb_mode);   // the length-bound stop (pga_dp.h; the checked mode is the lane kernel's)
 	auto eval_block = [&](int b) -> bool {
 		bool halt = false;
 		const int r0 = b * 64, r = r0 + lane;
@@ -166,6 +167,7 @@ __device__ __forceinline__ void bstrip_body(const DpJob &J, const uint32_t jl, u
 			const bool stop = !upd && tl >= 0 && ql >= 0 && zdrop >= 0 && ez_max - mH > zdrop + l * e2;
 			if (upd) ez_max = mH, ez_max_t = mt, ez_max_q = rr - mt;
 			if (stop) { ez_zdropped = 1, ez_score = KSW_NEG_INF; halt = true; break; }
+			if (LB.on && (rr & 7) == 7 && lb_final(LB, rr, tlen, q, e, q2, e2, sc_mch, ez_max < ez_mte ? ez_max : ez_mte)) { ez_zdropped = 1; halt = true; break; }
 		}
 		if (!halt && r0 + lim >= n_eff && n_eff < n_diag) { ez_zdropped = 1; r_done = n_eff + 1; halt = true; }      // the range ran empty (ksw2_extd2_sse.c:172)
 		if (sat) halt = true;

@@ -226,6 +226,9 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 		int ez_score = KSW_NEG_INF, ez_zdropped = 0, ez_reach_end = 0;
 		int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
 		const int n_diag = qlen + tlen - 1;
+		// the length-bound stop (pga_dp.h): an extension towards a block end a few bases away is final after ~3 tlen diagonals
+		const LbStop LB = lb_stop_of(qlen, tlen, w, flag, q, e, q2, e2, sc_mch, sc_mis, sc_N, P.lb_mode);
+		int lb_hit = 0, lb_max = 0, lb_max_t = 0, lb_max_q = 0, lb_mte = 0, lb_mte_q = 0;      // (checked mode: the record as it was when the bounds closed)
 		int r_done = 0;
 		uint32_t q_next = tid == 0 && qlen > 0 ? (uint32_t)qq[0] : 0u;       // query[r - t0] of the first diagonal
 		auto col8 = [&](const s2_t (&A)[4], int i) -> int { return __builtin_amdgcn_sbfe(as_i(A[i >> 1]), (i & 1) ? 24 : 8, 8); };   // the int8 of column i
@@ -518,6 +521,10 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 				stop = !upd & (tl >= 0) & (ql >= 0) & (zdrop >= 0) & (ez_max - max_H > zdrop + l * e2);
 				ez_max_t = upd ? max_t : ez_max_t; ez_max_q = upd ? r - max_t : ez_max_q; ez_max = upd ? max_H : ez_max;
 				if (stop) ez_zdropped = 1, ez_score = KSW_NEG_INF;
+				else if (LB.on && (r & 7) == 7 && !lb_hit && lb_final(LB, r, tlen, q, e, q2, e2, sc_mch, ez_max < ez_mte ? ez_max : ez_mte)) {
+					if (P.lb_mode == 2) lb_hit = r + 1, lb_max = ez_max, lb_max_t = ez_max_t, lb_max_q = ez_max_q, lb_mte = ez_mte, lb_mte_q = ez_mte_q;
+					else ez_zdropped = 1, stop = true;
+				}
 			} else {
 				const int h0v = s_h0v[r & 1], h0u = s_h0u[r & 1];
 				if (r > 0) {
@@ -550,6 +557,8 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 #endif
 		// ---- backtrack by wave 0 (ksw2.h:127-159) through a 64x64 LDS window of the direction matrix ----
 		int n_cigar = 0, bi = -1, bj = -1;
+		const bool lb_broken = lb_hit && !sat && !(ez_zdropped && ez_max == lb_max && ez_max_t == lb_max_t && ez_max_q == lb_max_q && ez_mte == lb_mte && ez_mte_q == lb_mte_q &&
+		                                            ez_mqe == KSW_NEG_INF && ez_score == KSW_NEG_INF);
 		if (sat) {}                                                 // (no traceback: the problem is redone)
 		else if (!ez_zdropped && !(flag & EZ_EXTZ_ONLY)) bi = tlen - 1, bj = qlen - 1;
 		else if (!ez_zdropped && (flag & EZ_EXTZ_ONLY) && ez_mqe + end_bonus > ez_max) ez_reach_end = 1, bi = ez_mqe_t, bj = qlen - 1;
@@ -621,7 +630,7 @@ void k_extd2_lanes(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases base
 			if (lane == 0) {
 				DpRes R;
 				R.max = ez_max, R.max_q = ez_max_q, R.max_t = ez_max_t, R.mqe = ez_mqe, R.mqe_t = ez_mqe_t, R.mte = ez_mte, R.mte_q = ez_mte_q;
-				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = sat ? -9 : n_cigar, R.pad = r_done, R.cigar_off = base;
+				R.score = ez_score, R.zdropped = ez_zdropped, R.reach_end = ez_reach_end, R.n_cigar = lb_broken ? -11 : sat ? -9 : n_cigar, R.pad = r_done, R.cigar_off = base;
 				res[jid] = R;
 			}
 		}

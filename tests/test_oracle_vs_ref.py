@@ -76,3 +76,61 @@ def test_e2e_synthetic_population(oracle_lib, ref_lib):
     a = rows_to_lists(ref_lib.align_all(seqs, names))
     b = rows_to_lists(oracle_lib.align_all(seqs, names))
     assert a == b and len(a) >= 6
+
+
+def _lb_problem(rng, trial, w):
+    """an extension towards a block end: 1 ... 32 target bases, a query that runs on; tails built to put as many matches as possible far from the diagonal"""
+    tl = int(rng.integers(1, 33)) if trial % 8 else (1, 15, 16, 17, 31, 32)[trial // 8 % 6]
+    t = random_seq(rng, tl)
+    ql = w + 2 * tl + int(rng.integers(0, 1200))
+    kind = trial % 8
+    head = mutate(rng, t, snp=0.08 * (trial % 3), indel=0.03 * (trial % 2)) if kind != 6 else random_seq(rng, tl)
+    body = random_seq(rng, max(1, ql - len(head)))
+    if kind == 1:
+        for p in range(int(rng.integers(0, 60)), len(body) - tl - 1, max(tl + int(rng.integers(0, 5)), 5)):
+            body[p:p + tl] = t
+    elif kind == 2:
+        t = np.full(tl, ord("ACGT"[trial % 4]), dtype=np.uint8); head = t.copy(); body[: int(len(body) * rng.random())] = t[0]
+    elif kind == 3 and tl > 6:
+        t = t.copy(); t[tl // 3: tl // 3 + 2] = ord("N"); body[100:130] = ord("N")
+    elif kind == 4:
+        reps = np.tile(t, 1 + len(body) // max(1, tl))[: len(body)]; body[:] = reps
+    elif kind == 5:                                                   # copies of the target's LAST bases: what the last column meets again and again
+        k = max(1, tl // 2)
+        for p in range(0, len(body) - k, k + 1):
+            body[p:p + k] = t[-k:]
+    elif kind == 7:                                                   # dinucleotide repeats in both
+        t = np.tile(np.frombuffer(b"AC", np.uint8), tl)[:tl].copy(); head = t.copy(); body[:] = np.tile(np.frombuffer(b"AC", np.uint8), len(body))[: len(body)]
+    q = np.concatenate([head, body])[: max(ql, 1)]
+    return sb.nt4(q.tobytes().decode()), sb.nt4(t.tobytes().decode())
+
+
+def test_length_bound_stop_rule_against_the_full_sweep(oracle_lib, ref_lib):
+    """pangraph_amd/csrc/pga_dp.h (length-bound stop): the product ends an extension whose target window is the <= 32 bases before a block end once
+    alignment length alone bounds every cell the reference would still visit below ez.max / ez.mte.  The restatement evaluates the same rule beside
+    its full sweep (pgo_ksw.c, the observer) and counts the problems whose record changed after the rule had closed: none may, over windows built
+    against the bound (copies of the target all along the query, homopolymers, tandem and dinucleotide repeats, N runs), three presets, bands 64 ...
+    1501, both gap alignments.  A sample of the same problems is held against the compiled reference (ksw_extd2_sse) so that the observer sits on
+    the reference's own sweep."""
+    rng = np.random.default_rng(99)
+    cnt = (C.c_longlong * 3)()
+    oracle_lib.dll.pgo_lb_counters(cnt, 1)
+    EXTZ, RIGHT, REV = 0x40, 0x02, 0x80
+    n = 0
+    for pname, (ma, mb, q1, e1, q2, e2) in {"asm10": (1, 9, 16, 2, 41, 1), "asm5": (1, 19, 39, 3, 81, 1), "asm20": (1, 4, 6, 2, 26, 1)}.items():
+        mat = sb.simple_mat(ma, mb, 1)
+        for trial in range(8000):
+            w = (1501, 751, 300, 64, 100, 1501, 200, 1000)[trial % 8]
+            qn, tn = _lb_problem(rng, trial, w)
+            flag = (EXTZ, EXTZ | RIGHT | REV, EXTZ | REV, EXTZ | RIGHT, 0, RIGHT)[trial % 6] | 0x01          # score only: the sweep, not the traceback, is what is checked
+            zd = (200, 400, 100, -1)[trial % 4]
+            o = sb.oracle_extd2(oracle_lib.dll, qn, tn, mat, q1, e1, q2, e2, w, zd, -1, flag)
+            if trial % 16 == 0:
+                r = sb.ref_extd2(ref_lib.dll, qn, tn, mat, q1, e1, q2, e2, w, zd, -1, flag)
+                for k in ("zdropped", "max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score"):
+                    assert o[k] == r[k], (pname, trial, k)
+            n += 1
+    oracle_lib.dll.pgo_lb_counters(cnt, 0)
+    assert cnt[1] == 0, f"the rule closed on {cnt[1]} records that the full sweep still changed"
+    assert cnt[0] > 0.7 * n, (cnt[0], n)          # and it does close (unless the band is too narrow to leave it room: w = 64, 100)
+    assert cnt[2] > 200 * cnt[0]                   # ... long before the sweep ends
