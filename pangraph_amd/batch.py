@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 from .mm2ffi import PafRow, MM_CIGAR_STR
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgalign.so")
+LIB_PATH = os.environ.get("PGA_LIB") or os.path.join(_HERE, "libpgalign.so")      # (PGA_LIB: a development build of the same library, e.g. dev/pipe_prof.sh)
 
 
 class pga_params_t(C.Structure):
@@ -35,9 +35,9 @@ class pga_stats_t(C.Structure):
 
 
 KERNELS = ("k_sketch_tiles", "k_chain_fast", "k_bt_list+k_bt_walk", "k_extd2_fast", "k_extd2_wide<256>", "k_ll_i16", "k_rs_init+k_rs_pass+k_rs_small",
-           "k_gapfill_band", "k_extd2_wide<512>", "k_extd2_wide<1024>", "index build (sorts + CSR kernels)", "seeding kernels + anchor sort", "k_approx_strips", "k_extd2_lanes", "-", "-")
+           "k_gapfill_band", "k_extd2_wide<512>", "k_extd2_wide<1024>", "index build (sorts + CSR kernels)", "seeding kernels + anchor sort", "k_approx_strips", "k_extd2_lanes", "k_ext_pipe", "-")
 # what bounds each slot: HBM traffic (scan / sort / hash work) or the integer DP recurrences (VALU + LDS issue; no MFMA)
-KERNEL_BOUND = ("hbm", "hbm", "hbm", "dp", "dp", "dp", "hbm", "dp", "dp", "dp", "hbm", "hbm", "dp", "dp", "-", "-")
+KERNEL_BOUND = ("hbm", "hbm", "hbm", "dp", "dp", "dp", "hbm", "dp", "dp", "dp", "hbm", "hbm", "dp", "dp", "dp", "-")
 
 
 class PgaError(RuntimeError):

@@ -353,7 +353,7 @@ void launch_extd2_wide(unsigned n_blocks, int n_threads, int r_cap, int seq_cap,
 //   11     like 10 with ONE wave per problem: rings of up to 512 columns (end extensions next to a block end, narrow banded fills)
 //   7      like 4, but exact-maximum problems (14 instead of 10 B of LDS per column: launched apart so that the approximate
 //          first passes of class 4 keep room for their sequences in LDS)
-#define DP_NCLASS 13
+#define DP_NCLASS 14
 #define WIDE_LDS_MAX (152 * 1024)
 static inline int wide_ring(const DpJob &j)
 {
@@ -395,6 +395,13 @@ uint32_t bstrips_table(const DpJob &j, std::vector<uint32_t> &tab, size_t *words
 void launch_bstrips(unsigned n_blocks, const DpJob *jobs, const uint32_t *blk_job, PkBases bases, const DpParams &P, uint8_t *slab, const uint64_t *slab_off,
                     unsigned long long *bnd, const uint64_t *bnd_off, const uint32_t *tab, const uint64_t *tab_off, DpRes *res, uint32_t *pool, unsigned long long *cursor,
                     unsigned long long pool_cap, hipStream_t st);
+bool pipe_eligible(const DpJob &j);
+int pipe_mode();
+size_t pipe_cig_bytes(int q_cap, int t_cap);
+size_t pipe_chunk_bytes();
+int pipe_max_chunks();
+void launch_ext_pipe(unsigned n_blocks, int q_cap, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter, uint8_t *slab, uint32_t n_chunks,
+                     DpRes *res, uint32_t *pool, unsigned long long *cursor, unsigned long long pool_cap, hipStream_t st);
 bool lanes_eligible(const DpJob &j, int nt);
 size_t lanes_cig_bytes(int q_cap, int t_cap);
 size_t lanes_chunk_bytes(int nt);
@@ -434,7 +441,7 @@ template <class F> static void host_parallel(size_t n, F f)
 	for (auto &t : th) t.join();
 }
 
-static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band);
+static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, int band_level);   // 0: no banded kernels, 1: lane kernels + strips, 2: and the workgroup pipeline
 
 // Launch lanes: four priority streams (lane 0, the million-tile classes, at the lower priority) and four grow-only scratch slabs per SET.
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
@@ -491,27 +498,32 @@ int dp_lb_mode() { const char *e = getenv("PGA_LB"); return !e ? 0 : !strcmp(e, 
 
 void dp_run(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)
 {
-	dp_run_impl(d_bases, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr);
-	// problems the corridor kernel could not prove exact: full matrix, results spliced in (their CIGARs go behind the pool)
-	std::vector<uint32_t> redo;
-	for (size_t i = 0; i < res.size(); ++i) {
-		if (res[i].n_cigar == -11) throw std::runtime_error("pga: the length-bound stop of an extension (pga_dp.h) closed on a record that the full sweep changed: qlen " + std::to_string(jobs[i].qlen) + " tlen " + std::to_string(jobs[i].tlen));
-		if (res[i].n_cigar == -9) redo.push_back((uint32_t)i);
+	dp_run_impl(d_bases, jobs, P, res, cigars, st, tm, getenv("PGA_NO_BAND") == nullptr ? 2 : 0);
+	// problems a kernel handed back, results spliced in (their CIGARs go behind the pool): -10 = the workgroup pipeline (pga_ksw_pipe.hip) met a sweep
+	// that outgrows its ring or ran out of chunks -> the other banded kernels; -9 = the corridor kernel could not prove its answer exact, a banded
+	// kernel met a clamped maximum or a dry pool -> the full-matrix / workgroup kernels
+	for (int pass = 1; pass <= 2; ++pass) {
+		std::vector<uint32_t> redo;
+		for (size_t i = 0; i < res.size(); ++i) {
+			if (res[i].n_cigar == -11) throw std::runtime_error("pga: the length-bound stop of an extension (pga_dp.h) closed on a record that the full sweep changed: qlen " + std::to_string(jobs[i].qlen) + " tlen " + std::to_string(jobs[i].tlen));
+			if (res[i].n_cigar == (pass == 1 ? -10 : -9)) redo.push_back((uint32_t)i);
+		}
+		if (redo.empty()) continue;
+		if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     %s: %zu of %zu problems handed back\n", pass == 1 ? "workgroup pipeline -> lane kernels / wave strips" : "corridor / banded kernels -> workgroup kernel", redo.size(), jobs.size());
+		std::vector<DpJob> jb(redo.size());
+		for (size_t k = 0; k < redo.size(); ++k) jb[k] = jobs[redo[k]];
+		std::vector<DpRes> r2; PinVec<uint32_t> c2;
+		dp_run_impl(d_bases, jb, P, r2, c2, st, tm, pass == 1 ? 1 : 0);
+		const size_t base = cigars.size();
+		cigars.resize(base + c2.size());
+		if (c2.size()) memcpy(cigars.data() + base, c2.data(), c2.size() * sizeof(uint32_t));
+		for (size_t k = 0; k < redo.size(); ++k) { res[redo[k]] = r2[k]; res[redo[k]].cigar_off += base; }
 	}
-	if (redo.empty()) return;
-	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]     corridor / lane kernels: %zu of %zu problems handed back, workgroup kernel\n", redo.size(), jobs.size());
-	std::vector<DpJob> jb(redo.size());
-	for (size_t k = 0; k < redo.size(); ++k) jb[k] = jobs[redo[k]];
-	std::vector<DpRes> r2; PinVec<uint32_t> c2;
-	dp_run_impl(d_bases, jb, P, r2, c2, st, tm, false);
-	const size_t base = cigars.size();
-	cigars.resize(base + c2.size());
-	if (c2.size()) memcpy(cigars.data() + base, c2.data(), c2.size() * sizeof(uint32_t));
-	for (size_t k = 0; k < redo.size(); ++k) { res[redo[k]] = r2[k]; res[redo[k]].cigar_off += base; }
 }
 
-static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, bool allow_band)
+static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, int band_level)
 {
+	const bool allow_band = band_level > 0;
 	res.clear(); cigars.clear();
 	const size_t n = jobs.size();
 	if (n == 0) return;
@@ -566,6 +578,23 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// from 6.3 to 3.5 ms and the 20 k-diagonal extension from 48 to 17.5 ms; with six batches in flight a step measures the same for 8 ... 64
 	// problems per launch on strips (2.39-2.46 s against 2.42-2.49 s without; when every strip row spanned all diagonals -- 25 MB zeroed per
 	// problem and launch -- 20 / 48 per launch cost 4 / 9 %)
+	// class 13 (the workgroup pipeline, pga_ksw_pipe.hip): the lane kernel's four-wave class (rings of up to 2 048 columns: the end extensions);
+	// PGA_PIPE=force: the one-wave class too (tests)
+	// A single extension into unrelated sequence takes 4.4 ms there against 6.3 ms on the lane kernel (the waves the band has not reached cost nothing,
+	// and no barrier paces the diagonal), 64 of them 4.8 against 6.7 ms; with more than a problem per CU in the launch the lane kernel's
+	// throughput is the same (512: 9.3 against 8.9 ms, 4 096: 72 against 65 ms): the pipeline takes the launches of at most PGA_PIPE_MAX problems.
+	static const size_t pipe_max = getenv("PGA_PIPE_MAX") ? (size_t)atoi(getenv("PGA_PIPE_MAX")) : 256;
+	if (band_level >= 2 && pipe_mode() > 0 && (pipe_mode() == 2 || cls[10].size() <= pipe_max)) {
+		for (int c : {10, 11}) {
+			if (c == 11 && pipe_mode() < 2) continue;
+			std::vector<uint32_t> rest;
+			for (uint32_t id : cls[c]) {
+				if (pipe_eligible(jobs[id])) { cls[13].push_back(id); cls_of[id] = 13; slab_max[13] = std::max(slab_max[13], need[id]); } else rest.push_back(id);
+			}
+			cls[c].swap(rest);
+		}
+		std::sort(cls[13].begin(), cls[13].end());
+	}
 	if (allow_band && bstrips_mode() > 0) {
 		std::vector<uint32_t> elig;
 		for (int c : {10, 11}) for (uint32_t id : cls[c]) if (bstrips_eligible(jobs[id], P)) elig.push_back(id);
@@ -606,7 +635,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
 	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off; };   // (class 9: block tables, strip boundaries)
@@ -628,7 +657,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// scratch slabs: one grow-only buffer per launch lane (classes of a lane run one after the other and share it); sized
 	// before anything is launched so that no buffer moves under a running kernel
 	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
-	uint32_t lanes_pool_chunks[2] = {0, 0};
+	uint32_t lanes_pool_chunks[2] = {0, 0}, pipe_pool_chunks = 0;
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
 		static const int c8w = getenv("PGA_C8_WAVES") ? atoi(getenv("PGA_C8_WAVES")) : 16;
@@ -639,6 +668,20 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			size_t tot = 0; for (uint32_t id : cls[c]) tot += need[id];
 			waves_of[c] = cls[c].size();
 			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], tot);
+			continue;
+		}
+		if (c == 13) {
+			// one CIGAR buffer per workgroup + three chunks per workgroup (a workgroup keeps its chunks from problem to problem; a sweep that needs
+			// more than the pool has left is handed back)
+			static const int c13 = getenv("PGA_C13_WGS") ? atoi(getenv("PGA_C13_WGS")) : 2;
+			n_waves = std::min<size_t>(cls[c].size(), 256 * (size_t)c13);
+			int q_cap = 16, t_cap = 16;
+			for (uint32_t id : cls[c]) { q_cap = std::max(q_cap, jobs[id].qlen); t_cap = std::max(t_cap, jobs[id].tlen); }
+			const size_t chunk = pipe_chunk_bytes();
+			const size_t pool = (n_waves * 3 + 64) * chunk;
+			pipe_pool_chunks = (uint32_t)(pool / chunk);
+			waves_of[c] = n_waves;
+			lane_need[lane_of_class[c]] = std::max(lane_need[lane_of_class[c]], n_waves * pipe_cig_bytes(q_cap, t_cap) + pool + 256);
 			continue;
 		}
 		if (c == 10 || c == 11) {
@@ -672,7 +715,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
-	static const int launch_order[DP_NCLASS] = {12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
+	static const int launch_order[DP_NCLASS] = {13, 12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
 		if (cls[c].empty()) continue;
@@ -742,7 +785,11 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
 			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
 		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		else if (c == 10 || c == 11) {
+		else if (c == 13) {
+			int q_cap = 16, t_cap = 16;
+			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
+			launch_ext_pipe((unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, pipe_pool_chunks, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else if (c == 10 || c == 11) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
 			launch_extd2_lanes(c == 11 ? 64 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
@@ -775,7 +822,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		PGA_HIP(hipEventSynchronize(X.e1));
 		float msf = 0, ms_off = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1)); (void)hipEventElapsedTime(&ms_off, ready, X.e0);
 		const double ms = msf;
-		busy_note(c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE, X.e0, X.e1);
+		busy_note(c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c == 13 ? K_PIPE : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE, X.e0, X.e1);
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
@@ -810,12 +857,12 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 				part_b[(size_t)s] += bases; part_c[(size_t)s] += cells;
 			});
 			double bases = 0, cells = 0; for (double x : part_b) bases += x; for (double x : part_c) cells += x;
-			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
+			const int kk = c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c == 13 ? K_PIPE : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE;   // (wide: classes 2-5 and 7, by workgroup size)
 			tm->kern[kk].ms += ms; tm->kern[kk].launches += 1; tm->kern[kk].alg_bytes += 0.5 * bases; tm->kern[kk].cells += cells; tm->dp_bases += bases;
 		}
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) res[ids[i]] = r[i]; });
 		if (const char *dump = getenv("PGA_DP_DUMP")) {           // development: geometry and outcome of every problem of the banded classes, appended as text
-			if (c == 10 || c == 11 || c == 12 || c == 2 || c == 3) {
+			if (c == 10 || c == 11 || c == 12 || c == 13 || c == 2 || c == 3) {
 				static std::mutex dmu; std::lock_guard<std::mutex> lk(dmu);
 				if (FILE *f = fopen(dump, "a")) {
 					for (size_t i = 0; i < ids.size(); ++i) { const DpJob &j = jobs[ids[i]]; fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d\n", c, j.qlen, j.tlen, j.w, j.flag, j.zdrop, j.end_bonus, r[i].pad, r[i].max, r[i].max_q, r[i].max_t, r[i].zdropped); }
@@ -823,7 +870,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 				}
 			}
 		}
-		if (((c >= 2 && c <= 4) || c == 7 || c == 10 || c == 11 || c == 12) && verbose) {
+		if (((c >= 2 && c <= 4) || c == 7 || c == 10 || c == 11 || c == 12 || c == 13) && verbose) {
 			double sq = 0, stl = 0, sw = 0, zd = 0, mt = 0, ext = 0, big = 0, dg = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
