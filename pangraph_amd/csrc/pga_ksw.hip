@@ -447,7 +447,49 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
 // the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
 // used on the set's streams); a set returns to the pool with its streams drained.
-struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };   // slabs are grow-only and stay with the set: no allocation in the launch path
+struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };
+
+// SHARED launch streams (round 5).  With a set of four streams per concurrent call, six batches in flight (two query sets each) hold up to 48 lane
+// streams on the 6 + 6 hardware queues of the two priority pools: four streams per queue, dealt by creation order -- and kernels of streams that share a
+// queue run one after the other, so a 2 ms tile launch of one batch sat behind a 48 ms extension launch of another whenever their lanes happened to
+// share a queue.  Now the device has ONE pool of launch streams, as many as there are hardware queues for them (PGA_DP_STREAMS, default 6 low + 6
+// high priority, created together so that each lands on a queue of its own); a launch goes to the stream with the least estimated work outstanding
+// (long classes and short classes therefore spread over the queues instead of colliding by accident), and the estimate is taken off when the host
+// has seen the launch complete.  A call still leases a set of scratch slabs for itself (LaneSet: no stream of its own any more).
+struct DpStreamPool {
+	std::mutex mu; int dev = -1; std::vector<hipStream_t> st; std::vector<double> load; std::vector<int> pending;
+	void init(int d)
+	{
+		dev = d;
+		int n_lo = 6, n_hi = 6;
+		if (const char *e = getenv("PGA_DP_STREAMS")) { if (sscanf(e, "%d,%d", &n_lo, &n_hi) != 2) n_lo = n_hi = 6; }
+		int prio_lo = 0, prio_hi = 0;
+		PGA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+		for (int i = 0; i < n_lo + n_hi; ++i) { hipStream_t s; PGA_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, i < n_lo ? prio_lo : prio_hi)); st.push_back(s); }
+		load.assign(st.size(), 0.0); pending.assign(st.size(), 0);
+	}
+};
+static std::mutex g_dps_mu; static std::vector<DpStreamPool*> g_dps;
+static DpStreamPool &dp_stream_pool(int dev)
+{
+	std::lock_guard<std::mutex> lk(g_dps_mu);
+	for (DpStreamPool *p : g_dps) if (p->dev == dev) return *p;
+	DpStreamPool *p = new DpStreamPool(); p->init(dev); g_dps.push_back(p); return *p;
+}
+static int dp_stream_pick(DpStreamPool &P, double est_ms)
+{
+	std::lock_guard<std::mutex> lk(P.mu);
+	size_t best = 0;
+	for (size_t i = 1; i < P.st.size(); ++i) if (P.load[i] < P.load[best] || (P.load[i] == P.load[best] && P.pending[i] < P.pending[best])) best = i;
+	P.load[best] += est_ms; ++P.pending[best];
+	return (int)best;
+}
+static void dp_stream_done(DpStreamPool &P, int i, double est_ms)
+{
+	std::lock_guard<std::mutex> lk(P.mu);
+	P.load[(size_t)i] -= est_ms; if (--P.pending[(size_t)i] == 0 || P.load[(size_t)i] < 0) P.load[(size_t)i] = P.pending[(size_t)i] ? std::max(0.0, P.load[(size_t)i]) : 0.0;
+}
+static bool dp_shared_streams() { static const bool v = !(getenv("PGA_DP_SHARED") && getenv("PGA_DP_SHARED")[0] == '0'); return v; }   // slabs are grow-only and stay with the set: no allocation in the launch path
 static std::mutex g_lane_mu;
 static std::vector<LaneSet*> g_lane_idle;
 static std::atomic<size_t> g_slab_total(0);                  // bytes held by the slabs of all sets of all devices
@@ -476,14 +518,14 @@ struct LaneLease {
 		// queues (measured: lanes 1-3 all high 3.75-3.83 s per step, lanes {0,1} low / {2,3} high 3.60-3.64, {0,3} low / {1,2} high 3.49-3.61;
 		// every lane at the default priority 4.6 s).  PGA_LANE_PRIO=lhhh etc. for experiments (l low, h high, n default).
 		static const std::string pr = getenv("PGA_LANE_PRIO") && strlen(getenv("PGA_LANE_PRIO")) == 4 ? getenv("PGA_LANE_PRIO") : "lhhl";
-		for (int l = 0; l < 4; ++l) {
+		if (!dp_shared_streams()) for (int l = 0; l < 4; ++l) {
 			if (pr[(size_t)l] == 'n') PGA_HIP(hipStreamCreateWithFlags(&set->stream[l], hipStreamNonBlocking));
 			else PGA_HIP(hipStreamCreateWithPriority(&set->stream[l], hipStreamNonBlocking, pr[(size_t)l] == 'l' ? prio_lo : prio_hi));
 		}
 	}
 	~LaneLease()
 	{
-		for (int l = 0; l < 4; ++l) (void)hipStreamSynchronize(set->stream[l]);
+		for (int l = 0; l < 4; ++l) if (set->stream[l]) (void)hipStreamSynchronize(set->stream[l]);
 		// the slabs stay with the set as long as all sets together hold a reasonable share of the device; beyond that this set gives its
 		// slabs back (to the block cache, which may drop them)
 		static const size_t keep = (size_t)(getenv("PGA_SLAB_KEEP_GB") ? atof(getenv("PGA_SLAB_KEEP_GB")) : 96.0) << 30;
@@ -637,7 +679,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// land on the same queue run back to back)
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
-	struct Launch { int c; int nt = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
+	struct Launch { int c; int nt = 0; hipStream_t cs = nullptr; int si = -1; double est = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
 	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off; };   // (class 9: block tables, strip boundaries)
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
@@ -715,6 +757,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
+	int lane_si[4] = {-1, -1, -1, -1};
 	static const int launch_order[DP_NCLASS] = {13, 12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
@@ -737,7 +780,20 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
 		static const bool on_main = getenv("PGA_DP_ON_MAIN") != nullptr;    // experiment: every class on the call's own stream (one hardware queue per batch)
 		static const bool three = getenv("PGA_DP_THREE_LANES") != nullptr;   // experiment: lane 3's classes (strips, class 3) share lane 1's stream
-		hipStream_t cs = on_main ? st : lane_stream[serial ? 0 : (three && lane_of_class[c] == 3) ? 1 : lane_of_class[c]];
+		hipStream_t cs;
+		if (on_main) cs = st;
+		else if (dp_shared_streams()) {
+			// what the launch is expected to hold its queue for (ms): the long banded classes by their longest problem's nominal diagonals, the others by count
+			static const double base_ms[DP_NCLASS] = {1.5, 2.0, 4.0, 6.0, 10.0, 10.0, 10.0, 10.0, 0.5, 12.0, 5.0, 4.0, 2.0, 3.0};
+			double est = base_ms[c] * std::max(1.0, (double)ids.size() / (c <= 1 || c == 8 ? 20000.0 : c == 10 || c == 11 || c == 13 ? 512.0 : 64.0));
+			// (the classes of one lane share a scratch slab and therefore one stream: the lane's first launch picks it)
+			DpStreamPool &SP = dp_stream_pool(dev_id);
+			int &lsi = lane_si[lane_of_class[c]];
+			if (lsi < 0) lsi = dp_stream_pick(SP, est);
+			else { std::lock_guard<std::mutex> lk(SP.mu); SP.load[(size_t)lsi] += est; ++SP.pending[(size_t)lsi]; }
+			X.si = lsi; X.est = est; cs = SP.st[(size_t)X.si];
+		} else cs = lane_stream[serial ? 0 : (three && lane_of_class[c] == 3) ? 1 : lane_of_class[c]];
+		X.cs = cs;
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
 		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
@@ -826,7 +882,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
-		download_to(r, X.d_r.p, ids.size(), getenv("PGA_DP_ON_MAIN") ? st : lane_stream[getenv("PGA_DP_SERIAL") ? 0 : (getenv("PGA_DP_THREE_LANES") && lane_of_class[c] == 3) ? 1 : lane_of_class[c]]);
+		download_to(r, X.d_r.p, ids.size(), X.cs);
+		if (X.si >= 0) { dp_stream_done(dp_stream_pool(dev_id), X.si, X.est); X.si = -1; }
 		if (tm) {
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below.
 			// cells: what the kernel's loops evaluated -- the corridor kernel 32 columns on every diagonal, the register tiles the whole
