@@ -83,6 +83,36 @@ def pmc_issue():
                         for k, v in d.items() if any(t in k for t in ("k_extd2", "k_gapfill", "k_ll_i16", "k_approx_strips", "k_wstrips", "k_bstrips"))}}
 
 
+# Cycles ONE wave spends on the cell recurrence per cell it evaluates, measured inside the kernels (dev builds with cycle counters): what the kernel's
+# own arithmetic allows if nothing else cost anything.  k_extd2_lanes: 1 370 cycles of a 5 170-cycle diagonal for the 512 cells of a wave
+# (-DPGA_LANES_PROF); k_ext_pipe: the same packed arithmetic, four columns per lane (dev/pipe_prof.sh: 2 450-cycle diagonal of 256 cells,
+# the cell block a third of its instructions).  The other DP families use the lane kernel's figure.
+DP_CELL_CYCLES = {"k_extd2_lanes": 1370.0 / 512.0, "k_ext_pipe": 820.0 / 256.0}
+N_SIMD, CLOCK_HZ = 1024, 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+
+
+def profile_counts(ms_step: float):
+    """From the committed rocprofv3 summaries of this same workload (profiles/r*_kernel_concurrency.json: kernel trace of warm-up + one step;
+    profiles/r*_pmc_issue*kernels.json: SQ_WAVE_CYCLES of one step, in quad-cycles): kernel dispatches per step and the average number of waves
+    resident per SIMD over a step of ms_step.  NOT measured in this run; None where there is no summary."""
+    import glob
+    out = {"dispatches_per_step": None, "resident_waves_per_simd": None}
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_concurrency.json")))
+    if f:
+        d = json.load(open(f[-1]))
+        out["dispatches_per_step"] = int(d.get("kernels", 0) / float(d.get("steps_in_trace", 2)))
+        out["dispatches_source"] = os.path.relpath(f[-1], ROOT)
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue*kernels.json")))
+    if f and ms_step > 0:
+        d = json.load(open(f[-1]))
+        wc = d.get("all_kernels_SQ_WAVE_CYCLES")
+        if wc is None:
+            wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in d.get("kernels", {}).values())
+        out["resident_waves_per_simd"] = round(4.0 * wc / (ms_step * 1e-3 * CLOCK_HZ * N_SIMD), 3)
+        out["waves_source"] = os.path.relpath(f[-1], ROOT)
+    return out
+
+
 def _cpu_worker(args):
     so, seqs, names = args
     from pangraph_amd.mm2ffi import Mm2Lib
@@ -296,7 +326,9 @@ def main():
 
     # host threads of this rank: the ranks of a node share one CPU quota
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    n_threads = max(2, usable_cpus() // max(1, local_world))
+    # (most of a batch's helper threads wait for the device: with eight ranks on a 16-core grant a rank still gets four -- the grant is a CPU-time quota,
+    # not a thread limit -- and the model in schedule.predict_scaling prices the host's share)
+    n_threads = max(4, usable_cpus() // max(1, local_world))
 
     def add_stats(agg, st):
         if agg["stats"] is None:
@@ -608,6 +640,7 @@ def main():
                    "schedule": f"ready set, {args.slots} batches in flight" if args.schedule == "ready" else "level-synchronous waves",
                    "parallelism": f"{world} rank(s): subtrees per rank, no data-path collective, match-list gathers only"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "hbm_achieved_GBs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(kname, klaunch),
                      "alg_bytes_per_launch": kbytes / klaunch if klaunch else None, "avg_launch_ms": kms / klaunch if klaunch else None,
                      "launches_per_step": klaunch, "busy_ms_per_step": busy.get(kname, 0.0) / args.steps,
@@ -615,12 +648,23 @@ def main():
                      "whole_path": {"alg_bytes_per_step": alg_step, "achieved": alg_step / (ms_step * 1e-3) / 1e9, "frac": alg_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      "valu_issue_frac": valu_frac,
                      "note": "kernel = largest summed HIP-event time (own stream); batches overlap, see busy_ms; traffic: profiles/ PMC passes, same unit as alg_bytes_per_launch; "
-                             "an integer DP kernel is bound by VALU issue of its waves, not by HBM or MFMA: valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of its largest "
-                             "instantiation (profiles/ PMC passes)"},
+                             "an integer DP kernel is bound by VALU issue of its waves, not by HBM or MFMA: bound valu = cells/s over 1024 SIMDs x 2.4 GHz / (cycles one wave spends "
+                             "on the recurrence per cell, measured in the kernel); valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of its largest instantiation; "
+                             "dispatches_per_step, resident_waves_per_simd: profiles/ (rocprofv3 passes of this workload, not this run)"},
         "n_matches_gathered": last["n_matches"],
         "build_sha256": build_sha,
         "resident_gbp_s": resident["gbp_s"] if resident else (units * args.steps / dt / 1e9 if inp["lib"] is not None else None),
     }
+    # an integer DP kernel is bound by the VALU issue of its waves, not by HBM: cells per second against what the device's SIMDs could do at the
+    # kernel's own measured cost of a cell (the HBM figures of the same kernel stay beside it)
+    if batch.KERNEL_BOUND[ki] == "dp" and kms > 0:
+        kcells = st["kern_cells"][ki]
+        cyc = DP_CELL_CYCLES.get(kname.split("+")[0].split("<")[0], DP_CELL_CYCLES["k_extd2_lanes"])
+        peak = N_SIMD * CLOCK_HZ / cyc / 1e9
+        ach = kcells / (kms * 1e-3) / 1e9
+        out["roofline"].update({"bound": "valu", "achieved": ach, "peak": peak, "unit": "Gcell/s", "frac": ach / peak, "cells_per_launch": kcells / klaunch if klaunch else None,
+                                "cycles_per_cell_of_one_wave": cyc})
+    out["roofline"].update(profile_counts(ms_step))
     out.update(parity)
     detail = {
         "bench_line": None,
@@ -646,7 +690,8 @@ def main():
         "workload_generation_s": t_gen,
         "host_cpu": {"cpu_s_per_step": host_cpu_s / args.steps, "mean_busy_cores": host_cpu_s / dt, "usable_cores": usable_cpus(), "threads_per_batch": slot_threads},
         "resident_inputs": resident,
-        "predicted_scaling": (sched.predict_scaling(pop, tasks, (1, 2, 4, 8), units * args.steps / dt / 1e9, args.slots) if world == 1 and args.schedule == "ready" and not args.leaf_only else None),
+        "predicted_scaling": (sched.predict_scaling(pop, tasks, (1, 2, 4, 8), units * args.steps / dt / 1e9, args.slots, host_cpu_s_per_gbp=host_cpu_s / args.steps / (units / 1e9),
+                                                    host_cores=usable_cpus()) if world == 1 and args.schedule == "ready" and not args.leaf_only else None),
         "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run); bytes per launch in the unit of alg_bytes_per_launch",
     }
     if rank == 0:

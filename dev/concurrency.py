@@ -42,5 +42,14 @@ out = {"trace": sys.argv[1].split("/")[-1], "note": "whole trace (warm-up step a
        "share_of_wall_time_by_kernels_in_flight": {str(k): round(v / wall, 4) for k, v in sorted(hist.items())},
        "share_of_wall_time_by_queues_with_a_kernel_in_flight": {str(k): round(v / wall, 4) for k, v in sorted(qhist.items())},
        "busy_share_per_queue": {str(q): round(v / wall, 4) for q, v in sorted(qbusy.items(), key=lambda kv: -kv[1])}}
+# dispatches by family (the trace holds STEPS steps: the warm-up step and the timed one)
+STEPS = 2
+fam = collections.Counter(); fam_ns = collections.Counter()
+for a, b, q, k in rows:
+    f = "runtime copyBuffer" if "copyBuffer" in k else "runtime fillBuffer" if "fillBuffer" in k else "rocPRIM" if "rocprim" in k else "own kernels (k_*)"
+    fam[f] += 1; fam_ns[f] += b - a
+out["steps_in_trace"] = STEPS
+out["dispatches_per_step"] = len(rows) // STEPS
+out["dispatches_per_step_by_family"] = {f: {"dispatches": fam[f] // STEPS, "kernel_time_s": round(fam_ns[f] * 1e-9 / STEPS, 4)} for f in fam}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out)[:3000])

@@ -100,6 +100,7 @@ for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_INS
             tot[row["Kernel_Name"].split("(")[0].replace("void ", "")] += float(row["Counter_Value"])
     for k, v in tot.items(): agg[k][c] = v
 out = {}
+all_wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in agg.values())
 for k, v in agg.items():
     if "k_" not in k: continue
     wc = v.get("SQ_WAVE_CYCLES", 0.0)
@@ -108,7 +109,8 @@ for k, v in agg.items():
     out[k] = v
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:24]:
     print("%-44s VALU issue %.3f  LDS issue %.3f  of wave cycles;  insts VALU %.3g SALU %.3g" % (k[:44], v["valu_issue_frac_of_wave_cycles"] or 0, v["lds_issue_frac_of_wave_cycles"] or 0, v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0)))
-json.dump({"_source": "dev/gpu.sh profile <tag> issue: one step of the BASELINE build per counter pass (six batches in flight)", "kernels": out}, open("gpurun_out/profiles_out/${ROUND}_${TAG}_pmc_issue_kernels.json", "w"), indent=1)
+print("SQ_WAVE_CYCLES of all kernels of the step (quad-cycles): %.4g" % all_wc)
+json.dump({"_source": "dev/gpu.sh profile <tag> issue: one step of the BASELINE build per counter pass (six batches in flight)", "all_kernels_SQ_WAVE_CYCLES": all_wc, "kernels": out}, open("gpurun_out/profiles_out/${ROUND}_${TAG}_pmc_issue_kernels.json", "w"), indent=1)
 PY
     find gpurun_out/pmci_* -name "*.csv" -size +20M -delete ;;
   esac; done ;;

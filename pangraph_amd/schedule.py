@@ -321,11 +321,15 @@ def partition_subtrees(pop, tasks: List[Task], world: int, per_rank: int = 4):
     return owner, per
 
 
-def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu: float, slots: int = 6) -> Dict[str, dict]:
+def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu: float, slots: int = 6, host_cpu_s_per_gbp: float = 0.0,
+                    host_cores: int = 0) -> Dict[str, dict]:
     """What the subtree partition lets N ranks do, from ONE GPU's measurements: a rank cannot finish phase 1 before (a) its share of the bases
-    has gone through at the single-GPU throughput and (b) the longest dependency chain of its subtrees has run (cost_estimate per call, the
-    calls of a chain one after the other); phase 2 is the merges above the cut level by level, each level shortened by the query split only as far
-    as the per-call floor allows.  A MODEL to hold the first real multi-GPU run against -- not a measurement."""
+    has gone through at the single-GPU throughput, (b) the longest dependency chain of its subtrees has run (cost_estimate per call, the
+    calls of a chain one after the other) and (c) the HOST has done its part: the driver of a batch costs host_cpu_s_per_gbp core-seconds per Gbp
+    (measured at N = 1: process CPU time of the timed steps / bases), and the N ranks of a node share its host_cores -- a rank gets host_cores / N of them
+    (16 usable cores on the pool's boxes: two per rank at N = 8, where one rank alone keeps seven busy); phase 2 is the merges above the cut level by
+    level, each level shortened by the query split only as far as the per-call floor allows, every rank paying the host cost of the WHOLE level's
+    index on its share of the cores.  A MODEL to hold the first real multi-GPU run against -- not a measurement."""
     out = {}
     total = float(sum(t.bases for t in tasks))
     for n in worlds:
@@ -340,7 +344,9 @@ def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu
             longest[tid] = cost_estimate(t.bases, len(t.seqs)) + max((longest[d] for d in t.deps if owner[d] == owner[tid]), default=0.0)
             load[owner[tid]] += t.bases
         crit = [max((longest[t.tid] for t in tasks if owner[t.tid] == r), default=0.0) for r in range(max(1, n))]
-        phase1 = max(max(load[r] / 1e9 / gbp_s_one_gpu, crit[r]) for r in range(max(1, n)))
+        cores_per_rank = (host_cores / max(1, n)) if host_cores else 0.0
+        host1 = [(load[r] / 1e9 * host_cpu_s_per_gbp / cores_per_rank) if cores_per_rank else 0.0 for r in range(max(1, n))]
+        phase1 = max(max(load[r] / 1e9 / gbp_s_one_gpu, crit[r], host1[r]) for r in range(max(1, n)))
         # phase 2 as bench.py runs it: the calls above the cut level by level (a level = the calls whose dependencies are done, ONE batch that
         # all ranks work on with the queries split): a level waits for its slowest call's floor, its bases go through n ranks
         top = [t for t in tasks if owner[t.tid] < 0]
@@ -352,10 +358,14 @@ def predict_scaling(pop, tasks: List[Task], worlds: Sequence[int], gbp_s_one_gpu
             if not level:
                 break
             floor = max(cost_estimate(0, 1) + (cost_estimate(tasks[i].bases, len(tasks[i].seqs)) - cost_estimate(0, 1)) / n for i in level)
-            phase2 += max(floor, sum(tasks[i].bases for i in level) * 2.5e-10 / n + cost_estimate(0, 1))
+            lvl_gbp = sum(tasks[i].bases for i in level) / 1e9
+            host2 = (lvl_gbp * host_cpu_s_per_gbp / cores_per_rank) if cores_per_rank else 0.0     # (every rank indexes the whole level)
+            phase2 += max(floor, lvl_gbp * 0.25 / n + cost_estimate(0, 1), host2)
             done.update(level)
             left = [i for i in left if i not in done]
         step = phase1 + phase2
         out[str(n)] = {"per_rank_gbp": [round(x / 1e9, 6) for x in load], "per_rank_critical_path_s": [round(x, 3) for x in crit], "calls_above_the_cut": len(top),
-                       "phase1_s": round(phase1, 3), "phase2_s": round(phase2, 3), "step_s": round(step, 3), "gbp_s": round(total / 1e9 / step, 2) if step > 0 else None}
+                       "phase1_s": round(phase1, 3), "phase2_s": round(phase2, 3), "step_s": round(step, 3), "gbp_s": round(total / 1e9 / step, 2) if step > 0 else None,
+                       "host_cores_per_rank": round(cores_per_rank, 2) if cores_per_rank else None,
+                       "phase1_bound": ("host" if host1 and max(host1) >= phase1 - 1e-12 and max(host1) > 0 else "critical path" if max(crit) >= phase1 - 1e-12 else "device throughput")}
     return out

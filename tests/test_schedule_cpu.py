@@ -127,3 +127,21 @@ def test_more_ranks_than_subtrees_and_the_scaling_model():
         assert abs(sum(m["per_rank_gbp"]) + above - total) < 1e-2 * max(total, 1e-9) + 1e-3
         assert m["step_s"] >= m["phase1_s"] and m["step_s"] >= m["phase2_s"] and len(m["per_rank_gbp"]) == int(n)
     assert model["1"]["calls_above_the_cut"] == 0 and model["8"]["calls_above_the_cut"] > 0
+
+
+def test_scaling_model_prices_the_host():
+    """schedule.predict_scaling with the host term (core-seconds per Gbp measured at N = 1, the node's cores shared by its ranks): a step is never
+    shorter than without it, at N = 1 a host that is not the bottleneck changes nothing, and with few cores per rank the model says so."""
+    big = _pop(60)
+    bt = sched.build_tasks(big)
+    total = sum(t.bases for t in bt) / 1e9
+    free = sched.predict_scaling(big, bt, (1, 2, 4, 8), gbp_s_one_gpu=0.01)
+    # a host that needs a tenth of a core-second per device-second at N = 1: irrelevant there, the bound at N = 8 on two cores per rank
+    cheap = sched.predict_scaling(big, bt, (1, 2, 4, 8), gbp_s_one_gpu=0.01, host_cpu_s_per_gbp=0.1 / 0.01 * 0.1, host_cores=16)
+    dear = sched.predict_scaling(big, bt, (1, 2, 4, 8), gbp_s_one_gpu=0.01, host_cpu_s_per_gbp=7.0 / 0.01, host_cores=16)      # seven cores busy at N = 1
+    for n in ("1", "2", "4", "8"):
+        assert cheap[n]["step_s"] >= free[n]["step_s"] - 1e-9 and dear[n]["step_s"] >= cheap[n]["step_s"] - 1e-9
+        assert dear[n]["host_cores_per_rank"] == 16 / int(n)
+    assert abs(cheap["1"]["step_s"] - free["1"]["step_s"]) < 1e-9
+    assert dear["8"]["phase1_bound"] == "host" and dear["8"]["gbp_s"] < 0.5 * free["8"]["gbp_s"]
+    assert total > 0
