@@ -679,7 +679,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// land on the same queue run back to back)
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
-	struct Launch { int c; int nt = 0; hipStream_t cs = nullptr; int si = -1; double est = 0; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
+	struct Launch { int c; int nt = 0; hipStream_t cs = nullptr; int si = -1; double est = 0; bool zc = false; const DpJob *jobs_p = nullptr; DpRes *res_p = nullptr; PinVec<DpRes> hr; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
 	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off; };   // (class 9: block tables, strip boundaries)
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
@@ -772,8 +772,14 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		X.c = c; X.ids = &ids;
 		PinVec<DpJob> &jb = X.jb; jb.resize(ids.size());       // stays alive until the class has been collected
 		host_parallel(ids.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) jb[i] = jobs[ids[i]]; });
-		X.d_jobs.alloc(ids.size());
-		X.d_r.alloc(ids.size());
+		// a launch of few problems takes its descriptors straight from the pinned list and writes its records straight into pinned memory (the
+		// host's pointers are the device's): no copy in, no copy + synchronisation out -- three runtime dispatches and ~50 us less per class
+		// and round, which is what the rounds of the upper tree are made of.  (A descriptor read costs a trip over the host link: not for the
+		// launches that hold thousands of small tiles.)
+		static const size_t zc_max = getenv("PGA_DP_ZEROCOPY_MAX") ? (size_t)atol(getenv("PGA_DP_ZEROCOPY_MAX")) : 2048;
+		X.zc = ids.size() <= zc_max;
+		if (X.zc) { X.hr.resize(ids.size()); X.jobs_p = jb.data(); X.res_p = X.hr.data(); }
+		else { X.d_jobs.alloc(ids.size()); X.d_r.alloc(ids.size()); X.jobs_p = X.d_jobs.p; X.res_p = X.d_r.p; }
 		X.d_cnt.alloc(c == 9 ? ids.size() : 2);               // (class 12 keeps its counters in the problems' control blocks)               // (class 10: [1] is the cursor of its chunk pool)                // (class 9: one completion counter per problem)
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
@@ -796,7 +802,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		X.cs = cs;
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
-		PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
+		if (!X.zc) PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
 		PGA_HIP(hipMemsetAsync(X.d_cnt.p, 0, sizeof(uint32_t) * X.d_cnt.n, cs));
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
@@ -813,9 +819,9 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			X.d_blk_job.upload(bj, cs); X.d_blk_strip.upload(bs, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs);
 			X.d_bnd.alloc(((size_t)b_acc + 1) * (ws ? 2 : 1)); X.d_bnd.zero(cs);
 			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
-			if (ws) launch_wstrips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			if (ws) launch_wstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 			else
-			launch_approx_strips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_approx_strips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 12) {
 			std::vector<uint32_t> bj, tab; std::vector<uint64_t> so(ids.size()), bo(ids.size()), to(ids.size());
 			uint64_t s_acc = 0, b_acc = 0;
@@ -833,22 +839,22 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			X.d_bnd.alloc(((size_t)b_acc + 1) * 2); X.d_bnd.zero(cs);
 			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
 			X.n_waves = bj.size();
-			launch_bstrips((unsigned)bj.size(), X.d_jobs.p, X.d_blk_job.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_tab.p, X.d_tab_off.p,
-			               X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_bstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_tab.p, X.d_tab_off.p,
+			               X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
 			int t_cap = 16;
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
-			launch_ll_i16((unsigned)X.n_waves, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.d_r.p, cs);
-		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_ll_i16((unsigned)X.n_waves, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.res_p, cs);
+		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 13) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_ext_pipe((unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, pipe_pool_chunks, X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_ext_pipe((unsigned)X.n_waves, q_cap, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, pipe_pool_chunks, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 10 || c == 11) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_extd2_lanes(c == 11 ? 64 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_extd2_lanes(c == 11 ? 64 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
@@ -864,9 +870,9 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			if (getenv("PGA_WIDE_NT")) nt = atoi(getenv("PGA_WIDE_NT"));
 			else if (c == 3) nt = 512;
 			X.nt = nt;
-			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.d_r.p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.d_jobs.p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c],
-		                        X.d_r.p, d_pool.p, d_cursor.p, cig_total);
+			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c],
+		                        X.res_p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipEventRecord(X.e1, cs));
 		(void)hipStreamQuery(cs);                             // push the packets out now: the class should start while the next one is prepared
@@ -882,7 +888,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		(void)hipEventDestroy(X.e0); (void)hipEventDestroy(X.e1);
 		if (verbose) fprintf(stderr, "[pga]     dp class %d: %zu problems, %.3f ms (queued at +%.1f ms), slab %.1f KB x %zu waves\n", c, ids.size(), ms, ms_off, slab_max[c] / 1024.0, X.n_waves);
 		PinVec<DpRes> r;
-		download_to(r, X.d_r.p, ids.size(), X.cs);
+		if (X.zc) r = std::move(X.hr); else download_to(r, X.d_r.p, ids.size(), X.cs);
 		if (X.si >= 0) { dp_stream_done(dp_stream_pool(dev_id), X.si, X.est); X.si = -1; }
 		if (tm) {
 			// algorithmic bytes: 2-bit packed q+t reads; the tile kernel also gets the CIGAR bytes below.

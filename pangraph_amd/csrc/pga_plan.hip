@@ -439,6 +439,9 @@ __global__ void k_gather_anchors(const uint64_t *__restrict__ idx, uint32_t n, c
 	if (i < n) out[i] = a[idx[i]];
 }
 
+// Small lists (the calls of the upper tree: a few hundred regions) are planned through PINNED host memory that the kernels read and write directly
+// (the host's pointers are the device's): the three hand-overs of the sequence below then cost a stream synchronisation each instead of a copy dispatch
+// and a synchronisation -- seven runtime dispatches less per call.  PGA_PLAN_ZEROCOPY_MAX=0: always through device copies.
 void plan_regions(const std::vector<PlanIn> &in_, u128 *d_anchors, PkBases bases, const uint64_t *d_seq_off, const uint32_t *d_seq_len, const PlanParams &P,
                   std::vector<PlanOut> &out, std::vector<PlanItem> &items, hipStream_t st)
 {
@@ -447,12 +450,18 @@ void plan_regions(const std::vector<PlanIn> &in_, u128 *d_anchors, PkBases bases
 	out.resize(n);
 	items.clear();
 	if (!n) return;
-	DBuf<PlanIn> d_in; d_in.upload(in, st);
-	DBuf<PlanOut> d_out(n);
-	hipLaunchKernelGGL(k_plan_regions, dim3((unsigned)n), dim3(64), 0, st, d_in.p, (uint32_t)n, d_anchors, d_seq_len, P, d_out.p);
+	static const size_t zc_max = getenv("PGA_PLAN_ZEROCOPY_MAX") ? (size_t)atol(getenv("PGA_PLAN_ZEROCOPY_MAX")) : 1024;
+	const bool zc = n <= zc_max;
+	PinVec<PlanIn> h_in; PinVec<PlanOut> h_out;
+	DBuf<PlanIn> d_in; DBuf<PlanOut> d_out;
+	PlanIn *p_in; PlanOut *p_out;
+	if (zc) { h_in.resize(n); memcpy(h_in.data(), in.data(), n * sizeof(PlanIn)); h_out.resize(n); p_in = h_in.data(); p_out = h_out.data(); }
+	else { d_in.upload(in, st); d_out.alloc(n); p_in = d_in.p; p_out = d_out.p; }
+	hipLaunchKernelGGL(k_plan_regions, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_anchors, d_seq_len, P, p_out);
 	PGA_HIP(hipGetLastError());
-	PGA_HIP(hipMemcpyAsync(out.data(), d_out.p, n * sizeof(PlanOut), hipMemcpyDeviceToHost, st));
+	if (!zc) PGA_HIP(hipMemcpyAsync(out.data(), d_out.p, n * sizeof(PlanOut), hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipStreamSynchronize(st));
+	if (zc) memcpy(out.data(), h_out.data(), n * sizeof(PlanOut));
 	// segment slices: a segment spans at least min_ksw_len bases on both sequences unless it ends at a LONG_JOIN anchor (a long gap) or at the chain's end
 	uint64_t slots = 0;
 	for (size_t i = 0; i < n; ++i) {
@@ -461,28 +470,33 @@ void plan_regions(const std::vector<PlanIn> &in_, u128 *d_anchors, PkBases bases
 		in[i].item_cap = (o.status == 2 || o.status == 3) ? 0u : (uint32_t)(span / std::max(1, P.min_ksw_len) + o.n_long_gaps + 4);
 		in[i].item_off = slots; slots += in[i].item_cap;
 	}
-	d_in.upload(in, st);
+	if (zc) memcpy(h_in.data(), in.data(), n * sizeof(PlanIn)); else d_in.upload(in, st);
 	DBuf<PlanSeg> d_segs((size_t)slots + 1);
 	PGA_HIP(hipMemsetAsync(d_segs.p, 0, ((size_t)slots + 1) * sizeof(PlanSeg), st));
 	DBuf<uint32_t> d_nseg(n);
-	hipLaunchKernelGGL(k_plan_cut, dim3((unsigned)n), dim3(64), 0, st, d_in.p, (uint32_t)n, d_anchors, d_seq_off, P, d_out.p, d_segs.p, d_nseg.p);
+	hipLaunchKernelGGL(k_plan_cut, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_anchors, d_seq_off, P, p_out, d_segs.p, d_nseg.p);
 	if (slots) hipLaunchKernelGGL(k_plan_probe, dim3((unsigned)std::min<uint64_t>((slots + 3) / 4, 256 * 32)), dim3(256), 0, st, d_segs.p, slots, bases, P.probe_m_max);
-	hipLaunchKernelGGL(k_plan_collapse<false>, dim3((unsigned)n), dim3(64), 0, st, d_in.p, (uint32_t)n, d_segs.p, d_nseg.p, d_out.p, (PlanItem*)nullptr, (const uint64_t*)nullptr);
+	hipLaunchKernelGGL(k_plan_collapse<false>, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_segs.p, d_nseg.p, p_out, (PlanItem*)nullptr, (const uint64_t*)nullptr);
 	PGA_HIP(hipGetLastError());
-	PGA_HIP(hipMemcpyAsync(out.data(), d_out.p, n * sizeof(PlanOut), hipMemcpyDeviceToHost, st));
+	if (!zc) PGA_HIP(hipMemcpyAsync(out.data(), d_out.p, n * sizeof(PlanOut), hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipStreamSynchronize(st));
+	if (zc) memcpy(out.data(), h_out.data(), n * sizeof(PlanOut));
 	for (size_t i = 0; i < n; ++i) if (out[i].status == 1) throw std::runtime_error("pga: plan_regions: a region cut more segments than its span allows");
 	// the items of all regions, one region after the other (the order the caller takes them in)
 	std::vector<uint64_t> ioff(n + 1, 0);
 	for (size_t i = 0; i < n; ++i) ioff[i + 1] = ioff[i] + (out[i].status == 0 ? out[i].n_items : 0);
 	items.resize((size_t)ioff[n]);
 	if (ioff[n]) {
-		DBuf<uint64_t> d_ioff; d_ioff.upload(ioff, st);
-		DBuf<PlanItem> d_items((size_t)ioff[n]);
-		hipLaunchKernelGGL(k_plan_collapse<true>, dim3((unsigned)n), dim3(64), 0, st, d_in.p, (uint32_t)n, d_segs.p, d_nseg.p, d_out.p, d_items.p, d_ioff.p);
+		const bool zci = zc && ioff[n] <= 8 * zc_max;
+		PinVec<uint64_t> h_ioff; PinVec<PlanItem> h_items; DBuf<uint64_t> d_ioff; DBuf<PlanItem> d_items;
+		const uint64_t *p_ioff; PlanItem *p_items;
+		if (zci) { h_ioff.resize(n + 1); memcpy(h_ioff.data(), ioff.data(), (n + 1) * sizeof(uint64_t)); h_items.resize((size_t)ioff[n]); p_ioff = h_ioff.data(); p_items = h_items.data(); }
+		else { d_ioff.upload(ioff, st); d_items.alloc((size_t)ioff[n]); p_ioff = d_ioff.p; p_items = d_items.p; }
+		hipLaunchKernelGGL(k_plan_collapse<true>, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_segs.p, d_nseg.p, p_out, p_items, p_ioff);
 		PGA_HIP(hipGetLastError());
-		PGA_HIP(hipMemcpyAsync(items.data(), d_items.p, (size_t)ioff[n] * sizeof(PlanItem), hipMemcpyDeviceToHost, st));
+		if (!zci) PGA_HIP(hipMemcpyAsync(items.data(), d_items.p, (size_t)ioff[n] * sizeof(PlanItem), hipMemcpyDeviceToHost, st));
 		PGA_HIP(hipStreamSynchronize(st));
+		if (zci) memcpy(items.data(), h_items.data(), (size_t)ioff[n] * sizeof(PlanItem));
 	}
 }
 
@@ -490,6 +504,15 @@ void gather_anchors(const std::vector<uint64_t> &idx, const u128 *d_anchors, std
 {
 	out.resize(idx.size());
 	if (idx.empty()) return;
+	if (idx.size() <= 4096) {                                     // (small: through pinned memory the kernel reads and writes directly)
+		PinVec<uint64_t> h_idx; h_idx.resize(idx.size()); memcpy(h_idx.data(), idx.data(), idx.size() * sizeof(uint64_t));
+		PinVec<u128> h_o; h_o.resize(idx.size());
+		hipLaunchKernelGGL(k_gather_anchors, dim3((unsigned)((idx.size() + 255) / 256)), dim3(256), 0, st, h_idx.data(), (uint32_t)idx.size(), d_anchors, h_o.data());
+		PGA_HIP(hipGetLastError());
+		PGA_HIP(hipStreamSynchronize(st));
+		memcpy(out.data(), h_o.data(), idx.size() * sizeof(u128));
+		return;
+	}
 	DBuf<uint64_t> d_idx; d_idx.upload(idx, st);
 	DBuf<u128> d_o(idx.size());
 	hipLaunchKernelGGL(k_gather_anchors, dim3((unsigned)((idx.size() + 255) / 256)), dim3(256), 0, st, d_idx.p, (uint32_t)idx.size(), d_anchors, d_o.p);

@@ -65,6 +65,12 @@ void post_identity(PkBases d_bases, const PinVec<PostProbe> &probes, int m_max, 
 	const size_t n = probes.size();
 	out.resize(n);
 	if (!n) return;
+	if (n <= 4096) {                                              // (few probes: the kernel takes them from, and answers into, the caller's pinned lists)
+		hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, st, probes.data(), (uint32_t)n, d_bases, m_max, out.data());
+		PGA_HIP(hipGetLastError());
+		PGA_HIP(hipStreamSynchronize(st));
+		return;
+	}
 	DBuf<PostProbe> d; d.alloc(n);
 	DBuf<int32_t> r; r.alloc(n);
 	PGA_HIP(hipMemcpyAsync(d.p, probes.data(), n * sizeof(PostProbe), hipMemcpyHostToDevice, st));
@@ -117,9 +123,18 @@ void post_zdrop_walk(PkBases d_bases, const std::vector<PostWalk> &reqs, const s
 	const size_t n = reqs.size();
 	out.resize(n);
 	if (!n) return;
-	DBuf<PostWalk> d; d.upload(reqs, st);
 	DBuf<uint32_t> c; c.alloc(cig.size() ? cig.size() : 1);
 	if (!cig.empty()) PGA_HIP(hipMemcpyAsync(c.p, cig.data(), cig.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	if (n <= 4096) {                                              // (requests and answers through pinned memory; the operation lists are read many times: a device copy)
+		PinVec<PostWalk> hd; hd.resize(n); memcpy(hd.data(), reqs.data(), n * sizeof(PostWalk));
+		PinVec<PostWalkRes> hr; hr.resize(n);
+		hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, hd.data(), (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, hr.data());
+		PGA_HIP(hipGetLastError());
+		PGA_HIP(hipStreamSynchronize(st));
+		memcpy(out.data(), hr.data(), n * sizeof(PostWalkRes));
+		return;
+	}
+	DBuf<PostWalk> d; d.upload(reqs, st);
 	DBuf<PostWalkRes> r; r.alloc(n);
 	hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
 	PGA_HIP(hipGetLastError());
@@ -340,11 +355,21 @@ void post_cigar_finish(PkBases d_bases, const std::vector<PostFin> &reqs, PinVec
 	const size_t n = reqs.size();
 	out.resize(n);
 	if (!n) return;
-	DBuf<PostFin> d; d.upload(reqs, st);
 	DBuf<uint32_t> c; c.alloc(cig.size() ? cig.size() : 1);
 	if (cig.size()) PGA_HIP(hipMemcpyAsync(c.p, cig.data(), cig.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-	DBuf<PostFinRes> r; r.alloc(n);
 	const unsigned grid = (unsigned)std::min<size_t>(n, 256 * 32);
+	if (n <= 4096) {                                              // (requests and records through pinned memory)
+		PinVec<PostFin> hd; hd.resize(n); memcpy(hd.data(), reqs.data(), n * sizeof(PostFin));
+		PinVec<PostFinRes> hr; hr.resize(n);
+		hipLaunchKernelGGL(k_cigar_finish, dim3(grid), dim3(64), 0, st, hd.data(), (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, hr.data());
+		PGA_HIP(hipGetLastError());
+		if (cig.size()) PGA_HIP(hipMemcpyAsync(cig.data(), c.p, cig.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		PGA_HIP(hipStreamSynchronize(st));
+		memcpy(out.data(), hr.data(), n * sizeof(PostFinRes));
+		return;
+	}
+	DBuf<PostFin> d; d.upload(reqs, st);
+	DBuf<PostFinRes> r; r.alloc(n);
 	hipLaunchKernelGGL(k_cigar_finish, dim3(grid), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostFinRes), hipMemcpyDeviceToHost, st));
