@@ -626,7 +626,10 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// and no barrier paces the diagonal), 64 of them 4.8 against 6.7 ms; with more than a problem per CU in the launch the lane kernel's
 	// throughput is the same (512: 9.3 against 8.9 ms, 4 096: 72 against 65 ms): the pipeline takes the launches of at most PGA_PIPE_MAX problems.
 	static const size_t pipe_max = getenv("PGA_PIPE_MAX") ? (size_t)atoi(getenv("PGA_PIPE_MAX")) : 256;
-	if (band_level >= 2 && pipe_mode() > 0 && (pipe_mode() == 2 || cls[10].size() <= pipe_max)) {
+	// (a launch that holds so few banded problems that the wave strips take them all keeps them there: a problem spread over two dozen CUs runs
+	// its diagonal in 0.76 us, a pipeline on one CU in 1.35)
+	const bool strips_take_all = bstrips_mode() == 1 && cls[10].size() + cls[11].size() <= (size_t)std::max(1, bstrips_max_problems());
+	if (band_level >= 2 && pipe_mode() > 0 && (pipe_mode() == 2 || (cls[10].size() <= pipe_max && !strips_take_all))) {
 		for (int c : {10, 11}) {
 			if (c == 11 && pipe_mode() < 2) continue;
 			std::vector<uint32_t> rest;
