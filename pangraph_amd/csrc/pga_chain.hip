@@ -1172,9 +1172,9 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 		const bool use_fast = !getenv("PGA_CHAIN_EXACT_ONLY");
 		// (A/B mode without the fast kernel: EVERY segment runs the tree re-enactment, so every query counts as "has such a segment" for k_need_exact)
 		if (!use_fast && n_seq > 0) PGA_HIP(hipMemsetD32Async((hipDeviceptr_t)seg_q.p, 1, (size_t)n_seq, st));
-		DBuf<unsigned long long> cprof(16); cprof.zero(st);
 		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 		const bool prof_on = verbose && getenv("PGA_CHAIN_PROF");
+		DBuf<unsigned long long> cprof(16); if (prof_on) cprof.zero(st);
 		if (use_fast && prof_on) hipLaunchKernelGGL((k_chain_fast<2048, true>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, cprof.p);
 		else if (use_fast) hipLaunchKernelGGL((k_chain_fast<2048, false>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
 		const double ms_fast = verbose ? et.stop() : 0.0;
@@ -1218,10 +1218,10 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	DBuf<int32_t> n_u((size_t)n_seq), n_v((size_t)n_seq);
 	{
 		EventTimer et(st);
-		DBuf<unsigned long long> prof(16); prof.zero(st);
+		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
+		DBuf<unsigned long long> prof(16); if (verbose) prof.zero(st);
 		DBuf<int64_t> n_z((size_t)n_seq);
 		DBuf<uint32_t> ev((size_t)n_seq), q_tie_f;
-		const bool verbose = getenv("PGA_VERBOSE") != nullptr;
 		hipLaunchKernelGGL(k_bt_list, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, f.p, t.p, z.p, P, n_z.p, n_u.p, n_v.p);
 		double ms_list = 0, ms_sort = 0;
 		ms_list = et.stop(K_BACKTRACK);

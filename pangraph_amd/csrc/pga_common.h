@@ -44,7 +44,8 @@ template <class T> struct DBuf {
 	DBuf(DBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
 	DBuf &operator=(DBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
 	~DBuf() { release(); }
-	void release() { if (p) dev_free(p); p = nullptr; n = cap = 0; }
+	void release() { if (p && cap) dev_free(p); p = nullptr; n = cap = 0; }
+	void view(T *ptr, size_t n_) { release(); p = ptr; n = n_; cap = 0; }     // a window into somebody else's block (cap == 0: never freed from here)
 	void alloc(size_t n_) { // contents undefined
 		if (n_ > cap) { release(); p = (T*)dev_alloc(n_ * sizeof(T)); cap = n_; }
 		n = n_;
@@ -128,6 +129,8 @@ struct SeqSet {
 	std::vector<int64_t> grp_off;       // n_grp+1 offsets into the sequence arrays
 	std::vector<uint32_t> grp_of_seq;   // n_seq
 	DBuf<uint32_t> d_grp_of_seq, d_grp_base;   // per sequence: its group, and the first sequence of that group
+	DBuf<uint8_t> d_tables;                     // d_off, d_len, d_grp_of_seq and d_grp_base are windows into this block: ONE host-to-device copy per batch
+	PinVec<uint8_t> h_tables;                   // ... from this pinned image (kept: the copy is asynchronous)
 };
 
 // ---- minimizers of a SeqSet (sorted by sequence, then by position == mm_sketch output order) ----

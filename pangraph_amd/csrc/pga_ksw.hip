@@ -674,7 +674,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	}
 	res.resize(n);
 	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
-	DBuf<unsigned long long> d_cursor(1); d_cursor.zero(st);
+	// the CIGAR pool's cursor and every class's queue counters in one block, zeroed once (a memset dispatch per class before)
+	DBuf<unsigned long long> d_cursor(1 + DP_NCLASS); d_cursor.zero(st);
 	PGA_HIP(hipStreamSynchronize(st));                      // the only use of the caller's stream: everything below is ordered inside the lane streams
 	// The classes are independent persistent launches: each gets its own stream, so the handful of huge problems
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
@@ -682,7 +683,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// land on the same queue run back to back)
 	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
-	struct Launch { int c; int nt = 0; hipStream_t cs = nullptr; int si = -1; double est = 0; bool zc = false; const DpJob *jobs_p = nullptr; DpRes *res_p = nullptr; PinVec<DpRes> hr; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
+	struct Launch { int c; int nt = 0; uint32_t *cnt_p = nullptr; hipStream_t cs = nullptr; int si = -1; double est = 0; bool zc = false; const DpJob *jobs_p = nullptr; DpRes *res_p = nullptr; PinVec<DpRes> hr; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
 	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off; };   // (class 9: block tables, strip boundaries)
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
@@ -783,7 +784,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		X.zc = ids.size() <= zc_max;
 		if (X.zc) { X.hr.resize(ids.size()); X.jobs_p = jb.data(); X.res_p = X.hr.data(); }
 		else { X.d_jobs.alloc(ids.size()); X.d_r.alloc(ids.size()); X.jobs_p = X.d_jobs.p; X.res_p = X.d_r.p; }
-		X.d_cnt.alloc(c == 9 ? ids.size() : 2);               // (class 12 keeps its counters in the problems' control blocks)               // (class 10: [1] is the cursor of its chunk pool)                // (class 9: one completion counter per problem)
+		if (c == 9) { X.d_cnt.alloc(ids.size()); X.cnt_p = X.d_cnt.p; } else X.cnt_p = reinterpret_cast<uint32_t*>(d_cursor.p + 1 + c);               // (class 12 keeps its counters in the problems' control blocks)               // (class 10: [1] is the cursor of its chunk pool)                // (class 9: one completion counter per problem)
 		X.n_waves = waves_of[c];
 		uint8_t *slab_p = lane_slab[lane_of_class[c]].p;
 		static const bool serial = getenv("PGA_DP_SERIAL") != nullptr;       // diagnosis: every class alone on the GPU, one after the other
@@ -806,7 +807,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		// the problem list and the queue counter travel in the class's own lane stream: a copy queued in another stream can sit
 		// behind a long kernel that happens to share its hardware queue (streams outnumber the queues), and the host would wait for it
 		if (!X.zc) PGA_HIP(hipMemcpyAsync(X.d_jobs.p, jb.data(), jb.size() * sizeof(DpJob), hipMemcpyHostToDevice, cs));
-		PGA_HIP(hipMemsetAsync(X.d_cnt.p, 0, sizeof(uint32_t) * X.d_cnt.n, cs));
+		if (c == 9) PGA_HIP(hipMemsetAsync(X.d_cnt.p, 0, sizeof(uint32_t) * X.d_cnt.n, cs));
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
 		if (c == 9) {
@@ -822,9 +823,9 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			X.d_blk_job.upload(bj, cs); X.d_blk_strip.upload(bs, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs);
 			X.d_bnd.alloc(((size_t)b_acc + 1) * (ws ? 2 : 1)); X.d_bnd.zero(cs);
 			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
-			if (ws) launch_wstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+			if (ws) launch_wstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.cnt_p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 			else
-			launch_approx_strips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.d_cnt.p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_approx_strips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.cnt_p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 12) {
 			std::vector<uint32_t> bj, tab; std::vector<uint64_t> so(ids.size()), bo(ids.size()), to(ids.size());
 			uint64_t s_acc = 0, b_acc = 0;
@@ -844,20 +845,20 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			X.n_waves = bj.size();
 			launch_bstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_tab.p, X.d_tab_off.p,
 			               X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
 			int t_cap = 16;
 			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
-			launch_ll_i16((unsigned)X.n_waves, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, (unsigned long long*)slab_p, slab_max[c] / 8, X.res_p, cs);
-		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_ll_i16((unsigned)X.n_waves, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, (unsigned long long*)slab_p, slab_max[c] / 8, X.res_p, cs);
+		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 13) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_ext_pipe((unsigned)X.n_waves, q_cap, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, pipe_pool_chunks, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_ext_pipe((unsigned)X.n_waves, q_cap, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, pipe_pool_chunks, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 10 || c == 11) {
 			int q_cap = 16, t_cap = 16;
 			for (uint32_t id : ids) q_cap = std::max(q_cap, jobs[id].qlen), t_cap = std::max(t_cap, jobs[id].tlen);
-			launch_extd2_lanes(c == 11 ? 64 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, lanes_pool_chunks[c - 10], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+			launch_extd2_lanes(c == 11 ? 64 : 256, (unsigned)X.n_waves, q_cap, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, lanes_pool_chunks[c - 10], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c <= 4 || c == 7) {
 			int r_cap = 0, seq_cap = 0; bool exact = false;
 			for (uint32_t id : ids) { r_cap = std::max(r_cap, wide_ring(jobs[id])); seq_cap = std::max(seq_cap, wide_seqcap(jobs[id])); exact |= !(jobs[id].flag & EZ_APPROX_MAX); }
@@ -873,8 +874,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			if (getenv("PGA_WIDE_NT")) nt = atoi(getenv("PGA_WIDE_NT"));
 			else if (c == 3) nt = 512;
 			X.nt = nt;
-			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
-		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.d_cnt.p, slab_p, slab_max[c],
+			launch_extd2_wide((unsigned)X.n_waves, nt, r_cap, seq_cap, exact, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
+		} else hipLaunchKernelGGL(k_extd2, dim3((unsigned)X.n_waves), dim3(64), 0, cs, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, slab_max[c],
 		                        X.res_p, d_pool.p, d_cursor.p, cig_total);
 		PGA_HIP(hipGetLastError());
 		PGA_HIP(hipEventRecord(X.e1, cs));

@@ -310,10 +310,14 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	hipLaunchKernelGGL(k_mz_keep, dim3(nb), dim3(256), 0, st, M.mz.p, n, M.seq_off.p, grp_of_mz.p, I.occ_off.p, I.occ.p, P, d_own, keep.p);
 	DBuf<uint64_t> pos64(n + 1);
 	{
-		// exclusive scan over n+1 items (the extra item yields the total)
-		DBuf<uint32_t> keep1(n + 1); keep1.zero(st);
-		PGA_HIP(hipMemcpyAsync(keep1.p, keep.p, n * 4, hipMemcpyDeviceToDevice, st));
-		excl_scan(keep1.p, pos64.p, n + 1, st);
+		// exclusive scan over n+1 items (the extra item, read as zero, yields the total)
+		struct In { const uint32_t *v; uint64_t n; };
+		const In in{keep.p, n};
+		auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), [in] __device__ (uint64_t i) { return i < in.n ? (uint64_t)in.v[i] : (uint64_t)0; });
+		size_t tb = 0;
+		PGA_HIP(rocprim::exclusive_scan(nullptr, tb, it, pos64.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), st));
+		DBuf<uint8_t> tmp(tb ? tb : 1);
+		PGA_HIP(rocprim::exclusive_scan(tmp.p, tb, it, pos64.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), st));
 	}
 	uint64_t n_kept = 0;
 	PGA_HIP(hipMemcpyAsync(&n_kept, pos64.p + n, 8, hipMemcpyDeviceToHost, st));

@@ -212,8 +212,25 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	}
 	PGA_HIP(hipMemsetAsync(S.d_pk2.p + padded / 16, 0, 8 * sizeof(uint32_t), st));
 	PGA_HIP(hipMemsetAsync(S.d_nmask.p + padded / 16, 0xff, 8 * sizeof(uint16_t), st));
-	S.d_off.upload(S.off, st);
-	S.d_len.upload(S.len, st);
+	// the per-sequence tables in one block and one copy (offsets, lengths, group of a sequence, first sequence of its group)
+	S.n_grp = n_grp;
+	S.grp_off.assign(grp_off, grp_off + n_grp + 1);
+	S.grp_of_seq.assign((size_t)n, 0);
+	{
+		std::vector<uint32_t> base((size_t)n, 0);
+		for (int g = 0; g < n_grp; ++g) for (int64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) S.grp_of_seq[i] = (uint32_t)g, base[i] = (uint32_t)grp_off[g];
+		const size_t o_off = 0, o_len = ((size_t)n + 1) * 8, o_gos = o_len + (((size_t)n * 4 + 15) & ~(size_t)15), o_base = o_gos + (((size_t)n * 4 + 15) & ~(size_t)15);
+		const size_t bytes = o_base + (((size_t)n * 4 + 15) & ~(size_t)15) + 16;
+		PinVec<uint8_t> &h = S.h_tables; h.resize(bytes);
+		memcpy(h.data() + o_off, S.off.data(), ((size_t)n + 1) * 8);
+		if (n) { memcpy(h.data() + o_len, S.len.data(), (size_t)n * 4); memcpy(h.data() + o_gos, S.grp_of_seq.data(), (size_t)n * 4); memcpy(h.data() + o_base, base.data(), (size_t)n * 4); }
+		S.d_tables.alloc(bytes);
+		PGA_HIP(hipMemcpyAsync(S.d_tables.p, h.data(), bytes, hipMemcpyHostToDevice, st));
+		S.d_off.view(reinterpret_cast<uint64_t*>(S.d_tables.p + o_off), (size_t)n + 1);
+		S.d_len.view(reinterpret_cast<uint32_t*>(S.d_tables.p + o_len), (size_t)n);
+		S.d_grp_of_seq.view(reinterpret_cast<uint32_t*>(S.d_tables.p + o_gos), (size_t)n);
+		S.d_grp_base.view(reinterpret_cast<uint32_t*>(S.d_tables.p + o_base), (size_t)n);
+	}
 	if (from) {
 		bool any = false; for (int i = 0; i < n; ++i) any |= !seq[i];
 		if (any && S.total) {
@@ -226,13 +243,6 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			PGA_HIP(hipStreamSynchronize(st));
 		}
 	}
-	S.n_grp = n_grp;
-	S.grp_off.assign(grp_off, grp_off + n_grp + 1);
-	S.grp_of_seq.assign((size_t)n, 0);
-	std::vector<uint32_t> base((size_t)n, 0);
-	for (int g = 0; g < n_grp; ++g) for (int64_t i = grp_off[g]; i < grp_off[g + 1]; ++i) S.grp_of_seq[i] = (uint32_t)g, base[i] = (uint32_t)grp_off[g];
-	S.d_grp_of_seq.upload(S.grp_of_seq, st);
-	S.d_grp_base.upload(base, st);
 }
 
 // ------------------------------------------------------------------------------------------------
