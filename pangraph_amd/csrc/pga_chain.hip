@@ -1224,7 +1224,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 		DBuf<uint32_t> ev((size_t)n_seq), q_tie_f;
 		hipLaunchKernelGGL(k_bt_list, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, f.p, t.p, z.p, P, n_z.p, n_u.p, n_v.p);
 		double ms_list = 0, ms_sort = 0;
-		ms_list = et.stop(K_BACKTRACK);
+		et.mark();                                                            // (the three intervals of the backtrack are read behind the walk: nothing here waits for the device)
 		EventTimer et2(st);
 		static const bool z_hint = getenv("PGA_NO_Z_HINT") == nullptr;
 		if (!z_hint && !spec) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, nullptr, st, tm);
@@ -1251,15 +1251,16 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 			}
 			hipLaunchKernelGGL(k_z_take_sorted, dim3(nba), dim3(256), 0, st, z.p, sx.p, sy.p, q_aoff.p, n_z.p, n_seq, spec ? (const uint32_t*)nullptr : q_tie.p, n_a);
 			const RsHint hint{sx.p, sy.p, dupc.p};
-			if (!spec) replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint);
-			PGA_HIP(hipStreamSynchronize(st));                               // (the hint's buffers go out of scope)
+			if (!spec) { replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint); PGA_HIP(hipStreamSynchronize(st)); }
+			// (the buffers of this scope go back to the call's arena: whoever takes them next is queued behind these kernels on the same stream)
 		}
-		ms_sort = et2.stop();
+		et2.mark();
 		EventTimer et3(st);
 		hipLaunchKernelGGL(k_bt_walk, dim3((unsigned)n_seq), dim3(64), 0, st, n_seq, q_aoff.p, a.p, f.p, pp.p, t.p, v.p, z.p, n_z.p, u.p, w.p, u2.p, out.p, P, n_u.p, n_v.p,
 		                   verbose ? prof.p : (unsigned long long*)nullptr, ev.p);
 		if (n_a) hipLaunchKernelGGL(k_bt_copy, dim3((unsigned)((n_a + 255) / 256)), dim3(256), 0, st, n_seq, q_aoff.p, (uint64_t)n_a, a.p, v.p, u.p, w.p, n_u.p, n_v.p, out.p);
 		const double ms_walk = et3.stop(K_BACKTRACK);
+		ms_list = et.finish(K_BACKTRACK); ms_sort = et2.finish();
 		if (verbose) {
 			std::vector<uint32_t> he = ev.download(st), hq = q_tie_f.n ? q_tie_f.download(st) : std::vector<uint32_t>();
 			size_t c[4] = {0, 0, 0, 0}, ft = 0; for (size_t i = 0; i < he.size(); ++i) { c[0] += he[i] & 1; c[1] += (he[i] >> 1) & 1; c[2] += (he[i] >> 2) & 1; c[3] += he[i] != 0; ft += i < hq.size() && hq[i]; }
@@ -1282,11 +1283,11 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	}
 	PGA_HIP(hipGetLastError());
 	mark("backtrack");
-	O.n_u = n_u.download(st); O.n_v = n_v.download(st);
+	std::vector<uint64_t> h_off;
+	{ Downloads dl(st); dl.add(O.n_u, n_u.p, n_u.n); dl.add(O.n_v, n_v.p, n_v.n); dl.add(h_off, q_aoff.p, q_aoff.n); dl.wait(); }
 	// the chains of a query are the first n_u entries of its slice of u: only those travel (a leaf part holds ~5 k chains in an array of
 	// 57 M slots), and land at the same positions of the host array
 	{
-		std::vector<uint64_t> h_off = q_aoff.download(st);
 		std::vector<uint64_t> coff((size_t)n_seq + 1, 0);
 		for (int q = 0; q < n_seq; ++q) coff[(size_t)q + 1] = coff[(size_t)q] + (uint64_t)O.n_u[(size_t)q];
 		const uint64_t total = coff[(size_t)n_seq];

@@ -88,6 +88,24 @@ template <class T> static inline void download_to(PinVec<T> &h, const T *d, size
 	if (n) { PGA_HIP(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(hipStreamSynchronize(s)); }
 }
 
+// several device arrays to the host behind ONE synchronisation (each DBuf::download() pays a copy and a synchronisation of its own)
+struct Downloads {
+	hipStream_t st;
+	struct Item { void *dst; void *pin; size_t bytes; };
+	std::vector<Item> items;
+	explicit Downloads(hipStream_t s) : st(s) {}
+	template <class T> void add(std::vector<T> &dst, const T *src, size_t n)
+	{
+		dst.resize(n);
+		if (!n) return;
+		Item it{dst.data(), pin_alloc(n * sizeof(T)), n * sizeof(T)};
+		PGA_HIP(hipMemcpyAsync(it.pin, src, it.bytes, hipMemcpyDeviceToHost, st));
+		items.push_back(it);
+	}
+	void wait() { if (!items.empty()) PGA_HIP(hipStreamSynchronize(st)); for (Item &it : items) { memcpy(it.dst, it.pin, it.bytes); pin_free(it.pin); } items.clear(); }
+	~Downloads() { for (Item &it : items) pin_free(it.pin); }
+};
+
 // ---- the sequence set of one batch, resident in HBM ----
 
 // The resident sequence store (pga_sketch.hip: k_encode_pk): 2 bits per base, sixteen bases per 32-bit word, plus one "not ACGT" bit per
@@ -167,10 +185,14 @@ void busy_note(int kern, hipEvent_t a, hipEvent_t b);
 hipStream_t stream_lease();
 void stream_release(hipStream_t s);
 // times everything enqueued on `st` between construction and stop()
+// (mark() closes the interval without waiting; finish() reads it -- behind a synchronisation the caller needs anyway it costs nothing, where stop()
+// makes the host wait for the kernels it has just queued before it may queue the next ones)
 struct EventTimer {
-	hipEvent_t a, b; hipStream_t st;
+	hipEvent_t a, b; hipStream_t st; bool marked = false;
 	explicit EventTimer(hipStream_t s) : st(s) { PGA_HIP(hipEventCreate(&a)); PGA_HIP(hipEventCreate(&b)); PGA_HIP(hipEventRecord(a, st)); }
-	double stop(int kern = -1) { float ms = 0; PGA_HIP(hipEventRecord(b, st)); PGA_HIP(hipEventSynchronize(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); if (kern >= 0) busy_note(kern, a, b); return ms; }
+	void mark() { if (!marked) { PGA_HIP(hipEventRecord(b, st)); marked = true; } }
+	double finish(int kern = -1) { float ms = 0; mark(); PGA_HIP(hipEventSynchronize(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); if (kern >= 0) busy_note(kern, a, b); return ms; }
+	double stop(int kern = -1) { mark(); return finish(kern); }
 	~EventTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 };
 

@@ -380,9 +380,8 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	PGA_HIP(hipMemcpyAsync(&n_a, a_off.p + n_kept, 8, hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipStreamSynchronize(st));
 	O.n_a = n_a;
-	O.h_rep_len = rep_len.download(st);
 	hipLaunchKernelGGL(k_query_anchor_off, dim3(nbq), dim3(256), 0, st, a_off.p, seq_off2.p, n_seq, n_kept, n_a, O.q_aoff.p);
-	O.h_q_aoff = O.q_aoff.download(st);
+	{ Downloads dl(st); dl.add(O.h_rep_len, rep_len.p, rep_len.n); dl.add(O.h_q_aoff, O.q_aoff.p, O.q_aoff.n); dl.wait(); }
 	O.a.alloc(n_a ? n_a : 1);
 	if (n_a == 0) return;
 

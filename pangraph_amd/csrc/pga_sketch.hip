@@ -694,8 +694,9 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 			else hipLaunchKernelGGL((k_sketch_tiles<63>), dim3((unsigned)nt), dim3(SK_THREADS), 0, st,
 			                   S.d_pk2.p, S.d_nmask.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
 			PGA_HIP(hipGetLastError());
-			const double k_ms = et.stop(K_SKETCH);
+			et.mark();
 			int ovf = d_ovf.download(st)[0];
+			const double k_ms = et.finish(K_SKETCH);
 			if (ovf) { cap *= 4; d_ovf.zero(st); continue; }  // pathological repeats: retry with bigger slabs
 			exclusive_scan_u64(d_cnt.p, d_toff.p, nt + 1, st);
 			uint64_t total = 0;
