@@ -104,6 +104,7 @@ __global__ void k_groups_ck(const uint64_t *__restrict__ ck, int hash_bits, cons
 	const uint32_t o = orig[i];
 	grp_of_mz[o] = g;
 	occ[i] = vy[o];
+	if (i == n - 1) occ_off[g + 1] = (uint32_t)n;                          // the end of the last key's list (was a 4-byte copy from the host and a wait)
 }
 
 // Sort minimizers by (group, x) keeping y ascending inside a key.  ONE stable sort over the composite key group << 2k | hash when it fits
@@ -142,11 +143,8 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 			I.occ_off.alloc((size_t)n_keys + 1);
 			I.key_grp.alloc(n_keys);
 			hipLaunchKernelGGL(k_groups_ck, dim3(nb), dim3(256), 0, st, ck2.p, hash_bits, flag.p, gid.p, orig2.p, vy.p, n, I.key.p, I.occ_off.p, I.key_grp.p, grp_of_mz.p, I.occ.p);
-			uint32_t n32 = (uint32_t)n;
-			PGA_HIP(hipMemcpyAsync(I.occ_off.p + n_keys, &n32, 4, hipMemcpyHostToDevice, st));
 			PGA_HIP(hipGetLastError());
-			PGA_HIP(hipStreamSynchronize(st));
-			return;
+			return;                                                              // (no wait: the scratch of this scope goes back to the call's arena, reused in stream order)
 		}
 	}
 	DBuf<uint64_t> kx(n), kx2(n), vy(n);

@@ -695,13 +695,13 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 			                   S.d_pk2.p, S.d_nmask.p, S.d_off.p, S.d_len.p, d_tiles.p, w, k, stage.p, cap, d_cnt.p, d_ovf.p);
 			PGA_HIP(hipGetLastError());
 			et.mark();
-			int ovf = d_ovf.download(st)[0];
-			const double k_ms = et.finish(K_SKETCH);
-			if (ovf) { cap *= 4; d_ovf.zero(st); continue; }  // pathological repeats: retry with bigger slabs
+			// (the overflow flag and the total travel together behind the scan: one wait instead of two; an overflow -- pathological repeats -- wastes a scan)
 			exclusive_scan_u64(d_cnt.p, d_toff.p, nt + 1, st);
-			uint64_t total = 0;
-			PGA_HIP(hipMemcpyAsync(&total, d_toff.p + nt, 8, hipMemcpyDeviceToHost, st));
-			PGA_HIP(hipStreamSynchronize(st));
+			std::vector<int> h_ovf; std::vector<uint64_t> h_tot;
+			{ Downloads dl(st); dl.add(h_ovf, d_ovf.p, 1); dl.add(h_tot, d_toff.p + nt, 1); dl.wait(); }
+			const double k_ms = et.finish(K_SKETCH);
+			if (h_ovf[0]) { cap *= 4; d_ovf.zero(st); d_cnt.zero(st); continue; }  // retry with bigger slabs
+			const uint64_t total = h_tot[0];
 			M.n = total;
 			if (tm) { tm->kern[K_SKETCH].ms += k_ms; tm->kern[K_SKETCH].launches += 1; tm->kern[K_SKETCH].alg_bytes += 0.375 * (double)S.total + 16.0 * (double)total; }   // packed bases in (2 bits + the N bit), minimizers out
 			M.mz.alloc(total ? total : 1);
@@ -713,8 +713,8 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 			d_first.upload(ft, st);
 			hipLaunchKernelGGL(k_seq_off_from_tiles, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_toff.p, d_first.p, n, total, M.seq_off.p);
 			PGA_HIP(hipGetLastError());
-			PGA_HIP(hipStreamSynchronize(st));
-			break;
+			M.h_seq_off = M.seq_off.download(st);                 // (waits for everything above: the staging slabs of this scope are done with)
+			return;
 		}
 	} else {
 		DBuf<uint64_t> d_cnt((size_t)n + 1); d_cnt.zero(st);
