@@ -81,7 +81,7 @@ static int apply_zdrop(pgo_extz_t *ez, int32_t H, int r, int t, int zdrop, int8_
 }
 
 /* An OBSERVER, not part of the restatement: the product's kernels end an extension towards a block end early when alignment length alone proves
- * that the record is final (pangraph_amd/csrc/pga_dp.h, "length-bound stop": tlen <= 32, qlen >= w + 2 tlen, w >= 64).  The same rule is
+ * that the record is final (pangraph_amd/csrc/pga_dp.h, "length-bound stop": tlen <= 64, qlen >= w + 2 tlen, w >= 64).  The same rule is
  * evaluated here beside the reference's full sweep; when it says "final" the record is remembered and compared with the record the sweep ends
  * with.  pgo_lb_counters(): [0] problems in which the rule closed, [1] problems in which the full sweep still changed the record afterwards
  * (must stay 0: tests/test_oracle_cpu.py), [2] diagonals the sweeps ran after the rule had closed. */
@@ -118,7 +118,7 @@ void pgo_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 	long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-	if (!approx_max && tlen <= 32 && w >= 64 && qlen >= w + 2 * tlen && sc_mch >= 0 && sc_mis <= sc_mch && sc_N <= sc_mch && q >= 0 && e >= 0 && q2 >= 0 && e2 >= 0) {
+	if (!approx_max && tlen <= 64 && w >= 64 && qlen >= w + 2 * tlen && sc_mch >= 0 && sc_mis <= sc_mch && sc_N <= sc_mch && q >= 0 && e >= 0 && q2 >= 0 && e2 >= 0) {
 		lb_on = 1;
 		lb_tail = tlen > 16 ? sc_mch * tlen - lb_gap(q, e, q2, e2, w + 32 - 2 * tlen) + (sc_mch + q + e) * (2 * tlen - 32) : INT32_MIN;
 	}

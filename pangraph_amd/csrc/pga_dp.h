@@ -33,7 +33,8 @@ struct DpRes {           // ksw_extz_t (ksw2.h:31-40)
 struct DpParams { int32_t q, e, q2, e2, sc_mch, sc_mis, sc_ambi; int32_t lb_mode; }; // sc_* are matrix entries mat[0], mat[1], mat[24]; lb_mode: 0 = the length-bound stop
                                                                                           // (below) is on, 1 = off, 2 = checked (the sweep goes on and the outcome is compared)
 
-// The LENGTH-BOUND STOP of an extension whose target window is the few bases left before a block end (tlen <= 32) while the query runs on for
+// The LENGTH-BOUND STOP of an extension whose target window is the few bases left before a block end (tlen <= 64; the bounds below close up to
+// tlen ~ 50 with the asm10 scores) while the query runs on for
 // kilobases: the reference sweeps ~w + 2 tlen diagonals until the band has slid past the last target column (ksw2_extd2_sse.c:172: st > en ->
 // zdropped), because the cells it still visits are pure gap cells whose drop grows as fast as the threshold (ksw2.h:178).  None of those
 // cells can change the answer, and that is decidable after ~3 tlen diagonals:
@@ -54,7 +55,7 @@ __host__ __device__ inline int32_t lb_gap(int q, int e, int q2, int e2, int L) {
 __host__ __device__ inline LbStop lb_stop_of(int qlen, int tlen, int w, int flag, int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N, int lb_mode)
 {
 	LbStop S; S.on = 0; S.r_lo = S.r_hi = S.tail = 0;
-	if (lb_mode == 1 || (flag & (0x08 | 0x8000)) || tlen > 32 || tlen < 1 || w < 64 || qlen < w + 2 * tlen) return S;
+	if (lb_mode == 1 || (flag & (0x08 | 0x8000)) || tlen > 64 || tlen < 1 || w < 64 || qlen < w + 2 * tlen) return S;
 	if (sc_mch < 0 || sc_mis > sc_mch || sc_N > sc_mch || q < 0 || e < 0 || q2 < 0 || e2 < 0) return S;
 	S.on = 1; S.r_lo = 2 * tlen; S.r_hi = w + 30;
 	const int qe1 = q + e < q2 + e2 ? q + e : q2 + e2;

@@ -447,7 +447,8 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
 // the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
 // used on the set's streams); a set returns to the pool with its streams drained.
-struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[4] = {}; DBuf<uint8_t> slab[4]; };
+#define DP_NLANE 5
+struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[DP_NLANE] = {}; DBuf<uint8_t> slab[DP_NLANE]; };
 
 // SHARED launch streams (round 5).  With a set of four streams per concurrent call, six batches in flight (two query sets each) hold up to 48 lane
 // streams on the 6 + 6 hardware queues of the two priority pools: four streams per queue, dealt by creation order -- and kernels of streams that share a
@@ -495,7 +496,7 @@ static std::vector<LaneSet*> g_lane_idle;
 static std::atomic<size_t> g_slab_total(0);                  // bytes held by the slabs of all sets of all devices
 struct LaneLease {
 	LaneSet *set = nullptr;
-	LaneLease(int dev, const size_t (&need)[4])
+	LaneLease(int dev, const size_t (&need)[DP_NLANE])
 	{
 		{
 			// best fit: the idle set that has to grow least; among those, the one that wastes least
@@ -503,7 +504,7 @@ struct LaneLease {
 			long best = -1; size_t best_grow = 0, best_waste = 0;
 			for (size_t i = 0; i < g_lane_idle.size(); ++i) if (g_lane_idle[i]->dev == dev) {
 				size_t grow = 0, waste = 0;
-				for (int l = 0; l < 4; ++l) { const size_t c = g_lane_idle[i]->slab[l].cap; if (need[l] > c) grow += need[l] - c; else waste += c - need[l]; }
+				for (int l = 0; l < DP_NLANE; ++l) { const size_t c = g_lane_idle[i]->slab[l].cap; if (need[l] > c) grow += need[l] - c; else waste += c - need[l]; }
 				if (best < 0 || grow < best_grow || (grow == best_grow && waste < best_waste)) best = (long)i, best_grow = grow, best_waste = waste;
 			}
 			if (best >= 0) { set = g_lane_idle[(size_t)best]; g_lane_idle.erase(g_lane_idle.begin() + best); }
@@ -517,19 +518,19 @@ struct LaneLease {
 		// long kernels (lane 2: end extensions, inversion tests; lane 3: strips) in each: with six batches in flight 12 + 12 streams on 6 + 6
 		// queues (measured: lanes 1-3 all high 3.75-3.83 s per step, lanes {0,1} low / {2,3} high 3.60-3.64, {0,3} low / {1,2} high 3.49-3.61;
 		// every lane at the default priority 4.6 s).  PGA_LANE_PRIO=lhhh etc. for experiments (l low, h high, n default).
-		static const std::string pr = getenv("PGA_LANE_PRIO") && strlen(getenv("PGA_LANE_PRIO")) == 4 ? getenv("PGA_LANE_PRIO") : "lhhl";
-		if (!dp_shared_streams()) for (int l = 0; l < 4; ++l) {
+		static const std::string pr = getenv("PGA_LANE_PRIO") && strlen(getenv("PGA_LANE_PRIO")) == DP_NLANE ? getenv("PGA_LANE_PRIO") : "lhhlh";
+		if (!dp_shared_streams()) for (int l = 0; l < DP_NLANE; ++l) {
 			if (pr[(size_t)l] == 'n') PGA_HIP(hipStreamCreateWithFlags(&set->stream[l], hipStreamNonBlocking));
 			else PGA_HIP(hipStreamCreateWithPriority(&set->stream[l], hipStreamNonBlocking, pr[(size_t)l] == 'l' ? prio_lo : prio_hi));
 		}
 	}
 	~LaneLease()
 	{
-		for (int l = 0; l < 4; ++l) if (set->stream[l]) (void)hipStreamSynchronize(set->stream[l]);
+		for (int l = 0; l < DP_NLANE; ++l) if (set->stream[l]) (void)hipStreamSynchronize(set->stream[l]);
 		// the slabs stay with the set as long as all sets together hold a reasonable share of the device; beyond that this set gives its
 		// slabs back (to the block cache, which may drop them)
 		static const size_t keep = (size_t)(getenv("PGA_SLAB_KEEP_GB") ? atof(getenv("PGA_SLAB_KEEP_GB")) : 96.0) << 30;
-		if (g_slab_total.load() > keep) for (int l = 0; l < 4; ++l) { g_slab_total -= set->slab[l].cap; set->slab[l].release(); }
+		if (g_slab_total.load() > keep) for (int l = 0; l < DP_NLANE; ++l) { g_slab_total -= set->slab[l].cap; set->slab[l].release(); }
 		std::lock_guard<std::mutex> lk(g_lane_mu);
 		g_lane_idle.push_back(set);
 	}
@@ -640,6 +641,27 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		}
 		std::sort(cls[13].begin(), cls[13].end());
 	}
+	// stragglers of the one-wave class: an extension towards a block end that the length-bound stop (pga_dp.h) does NOT cover -- the query ends before the
+	// band has slid off the target, or the target window is too long for the bounds to close -- sweeps its ~1 540 diagonals twenty columns wide, and a
+	// launch of hundreds of covered ones (~150 diagonals each) waits for it: those go to the wave strips (one wave, a column per lane: 0.76 us per
+	// diagonal against 2.1), whatever the launch holds
+	std::vector<uint32_t> stragglers;
+	if (allow_band && bstrips_mode() > 0 && dp_lb_mode() != 1) {
+		int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+		if (q2 + e2 < q + e) { std::swap(q, q2); std::swap(e, e2); }
+		const int sc_N = P.sc_ambi == 0 ? -e2 : P.sc_ambi;
+		std::vector<uint32_t> rest;
+		for (uint32_t id : cls[11]) {
+			const DpJob &j = jobs[id];
+			bool slow = false;
+			if (j.tlen <= 64 && !(j.flag & EZ_APPROX_MAX) && (int64_t)j.qlen + j.tlen > 600 && bstrips_eligible(j, P) && stragglers.size() < 64) {
+				const LbStop S = lb_stop_of(j.qlen, j.tlen, j.w < 0 ? std::max(j.qlen, j.tlen) : j.w, j.flag, q, e, q2, e2, P.sc_mch, P.sc_mis, sc_N, 0);
+				slow = !S.on || S.tail > -100;
+			}
+			if (slow) stragglers.push_back(id); else rest.push_back(id);
+		}
+		cls[11].swap(rest);
+	}
 	if (allow_band && bstrips_mode() > 0) {
 		std::vector<uint32_t> elig;
 		for (int c : {10, 11}) for (uint32_t id : cls[c]) if (bstrips_eligible(jobs[id], P)) elig.push_back(id);
@@ -659,6 +681,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			for (; kept < take.size(); ++kept) { bytes += bstrips_slab_bytes(jobs[take[kept]]) + 8 * bstrips_words(jobs[take[kept]]); if (bytes > ((size_t)8 << 30)) break; }
 			take.resize(kept);
 		}
+		take.insert(take.end(), stragglers.begin(), stragglers.end());
 		if (!take.empty()) {
 			std::vector<uint8_t> mark(n, 0);
 			for (uint32_t id : take) mark[id] = 1;
@@ -681,10 +704,11 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
 	// land on the same queue run back to back)
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2, 2};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 2, 1, 0, 3, 2, 1, 2, 4};       // (the workgroup pipeline on a lane of its own: the wave strips of the same round run beside it, not behind it)   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	struct Launch { int c; int nt = 0; uint32_t *cnt_p = nullptr; hipStream_t cs = nullptr; int si = -1; double est = 0; bool zc = false; const DpJob *jobs_p = nullptr; DpRes *res_p = nullptr; PinVec<DpRes> hr; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
-	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off; };   // (class 9: block tables, strip boundaries)
+	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off;
+	                std::vector<uint32_t> h_bj, h_bs, h_tab; std::vector<uint64_t> h_so, h_bo, h_to; };   // (their host images: alive until the launch has been collected, so that nothing waits for the copies)   // (class 9: block tables, strip boundaries)
 	std::vector<Launch> L;
 	L.reserve(DP_NCLASS);
 	// scratch budget per class: a slab is n_waves x the largest problem of the class, and n_waves is halved until it fits.  24 GB keeps
@@ -702,7 +726,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	PGA_HIP(hipEventRecord(ready, st));                     // time base of the per-class start offsets printed under PGA_VERBOSE
 	// scratch slabs: one grow-only buffer per launch lane (classes of a lane run one after the other and share it); sized
 	// before anything is launched so that no buffer moves under a running kernel
-	size_t waves_of[DP_NCLASS] = {0}, lane_need[4] = {0, 0, 0, 0};
+	size_t waves_of[DP_NCLASS] = {0}, lane_need[DP_NLANE] = {0, 0, 0, 0, 0};
 	uint32_t lanes_pool_chunks[2] = {0, 0}, pipe_pool_chunks = 0;
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
@@ -753,7 +777,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	LaneLease lanes(dev_id, lane_need);
 	hipStream_t *lane_stream = lanes.set->stream;
 	DBuf<uint8_t> *lane_slab = lanes.set->slab;
-	for (int l = 0; l < 4; ++l) if (lane_need[l] > lane_slab[l].cap) {      // (the set is idle: its last user drained the streams)
+	for (int l = 0; l < DP_NLANE; ++l) if (lane_need[l] > lane_slab[l].cap) {      // (the set is idle: its last user drained the streams)
 		ArenaScope own(lanes.set->arena);
 		g_slab_total -= lane_slab[l].cap; lane_slab[l].alloc(lane_need[l]); g_slab_total += lane_slab[l].cap;
 	}
@@ -761,7 +785,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
-	int lane_si[4] = {-1, -1, -1, -1};
+	int lane_si[DP_NLANE] = {-1, -1, -1, -1, -1};
 	static const int launch_order[DP_NCLASS] = {13, 12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
@@ -811,7 +835,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		PGA_HIP(hipEventCreate(&X.e0)); PGA_HIP(hipEventCreate(&X.e1));
 		PGA_HIP(hipEventRecord(X.e0, cs));
 		if (c == 9) {
-			std::vector<uint32_t> bj, bs; std::vector<uint64_t> so(ids.size()), bo(ids.size());
+			std::vector<uint32_t> &bj = X.h_bj, &bs = X.h_bs; std::vector<uint64_t> &so = X.h_so, &bo = X.h_bo; so.assign(ids.size(), 0); bo.assign(ids.size(), 0);
 			uint64_t s_acc = 0, b_acc = 0;
 			const bool ws = wstrips_on();                                   // wave strips (pga_ksw_wstrips.hip): 64-bit boundary words
 			for (size_t i = 0; i < ids.size(); ++i) {
@@ -822,12 +846,11 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			}
 			X.d_blk_job.upload(bj, cs); X.d_blk_strip.upload(bs, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs);
 			X.d_bnd.alloc(((size_t)b_acc + 1) * (ws ? 2 : 1)); X.d_bnd.zero(cs);
-			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
 			if (ws) launch_wstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.cnt_p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 			else
 			launch_approx_strips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, X.d_blk_strip.p, d_bases, P, slab_p, X.d_slab_off.p, X.d_bnd.p, X.d_bnd_off.p, X.cnt_p, X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 12) {
-			std::vector<uint32_t> bj, tab; std::vector<uint64_t> so(ids.size()), bo(ids.size()), to(ids.size());
+			std::vector<uint32_t> &bj = X.h_bj, &tab = X.h_tab; std::vector<uint64_t> &so = X.h_so, &bo = X.h_bo, &to = X.h_to; so.assign(ids.size(), 0); bo.assign(ids.size(), 0); to.assign(ids.size(), 0);
 			uint64_t s_acc = 0, b_acc = 0;
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const DpJob &j = jobs[ids[i]];
@@ -841,7 +864,6 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			// (blocks of one problem are consecutive: the waves of a pool are dispatched together)
 			X.d_blk_job.upload(bj, cs); X.d_slab_off.upload(so, cs); X.d_bnd_off.upload(bo, cs); X.d_tab.upload(tab, cs); X.d_tab_off.upload(to, cs);
 			X.d_bnd.alloc(((size_t)b_acc + 1) * 2); X.d_bnd.zero(cs);
-			PGA_HIP(hipStreamSynchronize(cs));                              // the host vectors above go out of scope
 			X.n_waves = bj.size();
 			launch_bstrips((unsigned)bj.size(), X.jobs_p, X.d_blk_job.p, d_bases, P, slab_p, X.d_slab_off.p, (unsigned long long*)X.d_bnd.p, X.d_bnd_off.p, X.d_tab.p, X.d_tab_off.p,
 			               X.res_p, d_pool.p, d_cursor.p, cig_total, cs);

@@ -79,8 +79,8 @@ def test_e2e_synthetic_population(oracle_lib, ref_lib):
 
 
 def _lb_problem(rng, trial, w):
-    """an extension towards a block end: 1 ... 32 target bases, a query that runs on; tails built to put as many matches as possible far from the diagonal"""
-    tl = int(rng.integers(1, 33)) if trial % 8 else (1, 15, 16, 17, 31, 32)[trial // 8 % 6]
+    """an extension towards a block end: 1 ... 64 target bases, a query that runs on; tails built to put as many matches as possible far from the diagonal"""
+    tl = int(rng.integers(1, 65)) if trial % 8 else (1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64)[trial // 8 % 12]
     t = random_seq(rng, tl)
     ql = w + 2 * tl + int(rng.integers(0, 1200))
     kind = trial % 8
@@ -106,7 +106,7 @@ def _lb_problem(rng, trial, w):
 
 
 def test_length_bound_stop_rule_against_the_full_sweep(oracle_lib, ref_lib):
-    """pangraph_amd/csrc/pga_dp.h (length-bound stop): the product ends an extension whose target window is the <= 32 bases before a block end once
+    """pangraph_amd/csrc/pga_dp.h (length-bound stop): the product ends an extension whose target window is the <= 64 bases before a block end once
     alignment length alone bounds every cell the reference would still visit below ez.max / ez.mte.  The restatement evaluates the same rule beside
     its full sweep (pgo_ksw.c, the observer) and counts the problems whose record changed after the rule had closed: none may, over windows built
     against the bound (copies of the target all along the query, homopolymers, tandem and dinucleotide repeats, N runs), three presets, bands 64 ...
@@ -132,5 +132,5 @@ def test_length_bound_stop_rule_against_the_full_sweep(oracle_lib, ref_lib):
             n += 1
     oracle_lib.dll.pgo_lb_counters(cnt, 0)
     assert cnt[1] == 0, f"the rule closed on {cnt[1]} records that the full sweep still changed"
-    assert cnt[0] > 0.7 * n, (cnt[0], n)          # and it does close (unless the band is too narrow to leave it room: w = 64, 100)
+    assert cnt[0] > 0.5 * n, (cnt[0], n)          # and it does close (unless the band is too narrow to leave it room: w = 64, 100)
     assert cnt[2] > 200 * cnt[0]                   # ... long before the sweep ends
