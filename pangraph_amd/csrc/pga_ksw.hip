@@ -786,7 +786,13 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
 	int lane_si[DP_NLANE] = {-1, -1, -1, -1, -1};
-	static const int launch_order[DP_NCLASS] = {13, 12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
+	static const int launch_order_bulk[DP_NCLASS] = {13, 12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
+	// a round of the upper tree (a few hundred tiles, one or two banded fills): what it waits for are its longest single problems -- a thin tile of
+	// 10 k diagonals, an approximate fill on the lane kernel -- and every launch costs the host ~60 us: those go out first (a first-round call: the
+	// tile class ended 0.6-0.8 ms behind the others only because it was launched last)
+	static const int launch_order_small[DP_NCLASS] = {13, 10, 0, 1, 12, 9, 11, 7, 6, 5, 4, 3, 2, 8};
+	static const bool small_first = getenv("PGA_DP_SMALL_ORDER") != nullptr;     // (measured: the build is 5 % SLOWER with it -- off)
+	const int *launch_order = small_first && cls[0].size() + cls[1].size() <= 4096 ? launch_order_small : launch_order_bulk;
 	for (int oi = 0; oi < DP_NCLASS; ++oi) {
 		const int c = launch_order[oi];
 		if (cls[c].empty()) continue;
