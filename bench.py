@@ -688,7 +688,7 @@ def main():
         "waves_rank0": [{"wave": w, "Mbp": b / 1e6, "hand_over_s": round(c, 4), "align_s": round(a, 4), "matches": int(m)} for w, b, c, a, m in last["per_wave"]],
         "batches_rank0": [{"t0": round(a, 4), "t1": round(b, 4), "calls": n, "Mbp": round(bs / 1e6, 1), "matches": m} for a, b, n, bs, m in sorted(last.get("batches", []))],
         "workload_generation_s": t_gen,
-        "host_cpu": {"cpu_s_per_step": host_cpu_s / args.steps, "mean_busy_cores": host_cpu_s / dt, "usable_cores": usable_cpus(), "threads_per_batch": slot_threads},
+        "host_cpu": {"cpu_s_per_step": host_cpu_s / args.steps, "system_s_per_step": (cpu1.system - cpu0.system) / args.steps, "mean_busy_cores": host_cpu_s / dt, "usable_cores": usable_cpus(), "threads_per_batch": slot_threads},
         "resident_inputs": resident,
         "predicted_scaling": (sched.predict_scaling(pop, tasks, (1, 2, 4, 8), units * args.steps / dt / 1e9, args.slots, host_cpu_s_per_gbp=host_cpu_s / args.steps / (units / 1e9),
                                                     host_cores=usable_cpus()) if world == 1 and args.schedule == "ready" and not args.leaf_only else None),

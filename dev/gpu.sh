@@ -20,7 +20,7 @@ try:
     r = d.get("roofline", {})
     try:
         dd = json.load(open(sys.argv[1].replace(".json", "_detail.json"))); hc = dd["host_cpu"]; ms = sorted(dd.get("ms_of_each_timed_step_rank0", []))
-        print("   host cpu: %.1f cores busy on average of %d | steps ms: min %.0f median %.0f max %.0f (n=%d)" % (hc["mean_busy_cores"], hc["usable_cores"], ms[0], ms[len(ms) // 2], ms[-1], len(ms)))
+        print("   host cpu: %.1f cores busy on average of %d (system %.1f s of %.1f s per step) | steps ms: min %.0f median %.0f max %.0f (n=%d)" % (hc["mean_busy_cores"], hc["usable_cores"], hc.get("system_s_per_step", -1), hc["cpu_s_per_step"], ms[0], ms[len(ms) // 2], ms[-1], len(ms)))
     except Exception: pass
     print(sys.argv[1], "value", round(d["value"], 3), "ms", round(d["ms_per_step"]), "resident", d.get("resident_gbp_s"), "parity", d.get("parity_checked_calls"),
           "| kernel", r.get("kernel"), "frac", r.get("frac"), "busy", r.get("busy_ms_per_step"), "any", r.get("any_kernel_busy_ms_per_step"), "| cpu", (d.get("cpu_baseline") or {}).get("value"), "| line bytes", len(json.dumps(d)))

@@ -166,6 +166,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	const int64_t one_grp[2] = {0, n};
 	if (!grp_off) grp_off = one_grp, n_grp = 1;
 	upload_seqs(ix->S, n, seq, len, name, n_grp, grp_off, ix->st, from, from_probe);
+	const double t_up = now_s();
 	const std::vector<std::string> &nm = ix->S.name;                  // (the names live in the sequence set: no second copy)
 	ix->seq_hdr.resize((size_t)n);
 	for (int i = 0; i < n; ++i) {
@@ -190,6 +191,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	ix->hdr.n_seq = (uint32_t)n; ix->hdr.seq = ix->seq_hdr.data();
 	PGA_HIP(hipStreamSynchronize(ix->st));
 	ix->tm.upload = now_s() - t0;
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   hand-over: sequences %.2f ms, names and ranks %.2f ms\n", (t_up - t0) * 1e3, (now_s() - t_up) * 1e3);
 	if (do_index) idx_sketch_index(*ix);
 	return ix.release();
 }

@@ -18,6 +18,7 @@
 // The fast path needs an odd k (no k-mer equals its reverse complement, so every base is a window slot)
 // and w+k <= 64; any other (w,k) runs the serial kernel at the bottom (one lane per sequence), exact for
 // all inputs, slow, and never hit by pangraph's presets except through -K with an even k.
+#include <chrono>
 #include "pga_common.h"
 #include "pga_wave.h"
 #include <sched.h>
@@ -61,6 +62,7 @@ int usable_cpus()
 	return c;
 }
 
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static thread_local int t_thread_budget = 0;
 void set_thread_budget(int n) { t_thread_budget = n; }
 int thread_budget() { return t_thread_budget > 0 ? t_thread_budget : usable_cpus(); }
@@ -143,21 +145,23 @@ __global__ void k_repack(uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmas
 
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st, const SeqFrom *from, const uint8_t *const *from_probe)
 {
+	const double tu0 = now_s(); double tu_g = 0, tu_w = 0;
 	S.n_seq = n;
 	S.off.assign((size_t)n + 1, 0); S.len.assign(len, len + n); S.name.resize(n);
 	for (int i = 0; i < n; ++i) { S.off[i + 1] = S.off[i] + len[i]; S.name[i] = name && name[i] ? name[i] : ""; }
 	S.total = S.off[n];
 	S.probe.assign((size_t)n * 64, 4);
-	for (int i = 0; i < n; ++i) {
-		const uint32_t L = len[i]; const uint32_t step = L > 64 ? L / 64 : 1;
-		int k = 0;
-		if (!seq[i]) { if (!from || !from[i].store.pk2) throw std::runtime_error("pga: sequence without bases"); if (from_probe && from_probe[i]) memcpy(&S.probe[(size_t)i * 64], from_probe[i], 64); continue; }
-		for (uint32_t p = 0; p < L && k < 64; p += step, ++k) S.probe[(size_t)i * 64 + k] = nt4_host((uint8_t)seq[i][p]);
+	// (the probes of a host sequence are read by the thread that gathers it, below: 64 strided reads per sequence touch half of its cache lines, and
+	// did so on one thread before anything was on its way to the device -- 7.7 of the 10.7 ms of an 84 Mbp hand-over)
+	for (int i = 0; i < n; ++i) if (!seq[i]) {
+		if (!from || !from[i].store.pk2) throw std::runtime_error("pga: sequence without bases");
+		if (from_probe && from_probe[i]) memcpy(&S.probe[(size_t)i * 64], from_probe[i], 64);
 	}
+	const double tu1 = now_s();
 	// sequences are padded to a 16-byte multiple (and 64 more) so that wide loads never straddle the allocation
 	const uint64_t padded = (S.total + 15) / 16 * 16;
 	S.d_pk2.alloc((size_t)(padded / 16) + 8); S.d_nmask.alloc((size_t)(padded / 16) + 8);
-	const uint64_t chunk = (uint64_t)64 << 20;
+	const uint64_t chunk = (uint64_t)16 << 20;      // (two staging buffers: a chunk is gathered while the one before it crosses PCIe)
 	const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
 	if (n_chunks) {
 		struct Stage { uint8_t *pin = nullptr; uint8_t *dev = nullptr; hipEvent_t sent; bool used = false; };
@@ -187,12 +191,17 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 				for (uint64_t p = lo; p < hi;) {
 					while (S.off[(size_t)i + 1] <= p) ++i;
 					const uint64_t stop = std::min<uint64_t>(hi, S.off[(size_t)i + 1]);
-					if (seq[i]) memcpy(x.pin + (p - b), seq[i] + (p - S.off[(size_t)i]), (size_t)(stop - p));
-					else memset(x.pin + (p - b), 'N', (size_t)(stop - p));       // resident elsewhere: filled in by k_repack
+					if (seq[i]) {
+						const uint64_t s0 = p - S.off[(size_t)i], s1 = stop - S.off[(size_t)i];         // this slice of sequence i, and the probes that lie in it
+						memcpy(x.pin + (p - b), seq[i] + s0, (size_t)(s1 - s0));
+						const uint32_t L = len[i], step = L > 64 ? L / 64 : 1;
+						for (uint64_t k = (s0 + step - 1) / step; k < 64 && k * step < s1; ++k) S.probe[(size_t)i * 64 + k] = nt4_host((uint8_t)seq[i][k * step]);
+					} else memset(x.pin + (p - b), 'N', (size_t)(stop - p));       // resident elsewhere: filled in by k_repack
 					p = stop;
 				}
 			};
 			const uint64_t per = ((e - b) + nt - 1) / nt;
+			const double tg0 = now_s();
 			if (nt == 1 || e - b < (1u << 20)) gather(b, e);
 			else {
 				std::vector<std::thread> th;
@@ -200,6 +209,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 				gather(b, std::min(e, b + per));
 				for (auto &t : th) t.join();
 			}
+			tu_g += now_s() - tg0;
 			const uint64_t nb = (e - b + 15) / 16 * 16;
 			if (nb > e - b) memset(x.pin + (e - b), 'N', (size_t)(nb - (e - b)));
 			PGA_HIP(hipMemcpyAsync(x.dev, x.pin, (size_t)nb, hipMemcpyHostToDevice, st));
@@ -207,9 +217,12 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			hipLaunchKernelGGL(k_encode_pk, dim3((unsigned)((nb / 16 + 255) / 256)), dim3(256), 0, st, (const uint4*)x.dev, S.d_pk2.p + b / 16, S.d_nmask.p + b / 16, nb / 16);
 		}
 		PGA_HIP(hipGetLastError());
+		const double tw0 = now_s();
 		PGA_HIP(hipStreamSynchronize(st));
+		tu_w = now_s() - tw0;
 		if (staged) for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
 	}
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   upload: %.1f Mbp, %d threads: names+probes %.2f ms, gather %.2f ms, last wait %.2f ms, all %.2f ms\n", S.total * 1e-6, (int)std::min<uint64_t>((uint64_t)thread_budget(), 16), (tu1 - tu0) * 1e3, tu_g * 1e3, tu_w * 1e3, (now_s() - tu0) * 1e3);
 	PGA_HIP(hipMemsetAsync(S.d_pk2.p + padded / 16, 0, 8 * sizeof(uint32_t), st));
 	PGA_HIP(hipMemsetAsync(S.d_nmask.p + padded / 16, 0xff, 8 * sizeof(uint16_t), st));
 	// the per-sequence tables in one block and one copy (offsets, lengths, group of a sequence, first sequence of its group)
