@@ -62,6 +62,30 @@ int usable_cpus()
 	return c;
 }
 
+// The gather of a hand-over writes pinned memory that only the DMA engine reads: streaming stores (no read of the destination line, nothing of it left
+// in the caches).  PGA_STREAM_COPY=0: plain memcpy.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+static void stream_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+	static const bool on = !(getenv("PGA_STREAM_COPY") && atoi(getenv("PGA_STREAM_COPY")) == 0);
+	if (!on || n < 1024) { memcpy(dst, src, n); return; }
+	const size_t head = (64 - ((uintptr_t)dst & 63)) & 63;
+	memcpy(dst, src, head); dst += head, src += head, n -= head;
+	for (size_t i = n >> 6; i; --i, src += 64, dst += 64) {
+		_mm_prefetch((const char*)src + 1024, _MM_HINT_NTA);
+		const __m128i a = _mm_loadu_si128((const __m128i*)src), b = _mm_loadu_si128((const __m128i*)(src + 16));
+		const __m128i c = _mm_loadu_si128((const __m128i*)(src + 32)), d = _mm_loadu_si128((const __m128i*)(src + 48));
+		_mm_stream_si128((__m128i*)dst, a); _mm_stream_si128((__m128i*)(dst + 16), b);
+		_mm_stream_si128((__m128i*)(dst + 32), c); _mm_stream_si128((__m128i*)(dst + 48), d);
+	}
+	memcpy(dst, src, n & 63);
+}
+static inline void stream_fence() { _mm_sfence(); }
+#else
+static void stream_copy(uint8_t *dst, const uint8_t *src, size_t n);
+static inline void stream_fence() {}
+#endif
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static thread_local int t_thread_budget = 0;
 void set_thread_budget(int n) { t_thread_budget = n; }
@@ -193,12 +217,13 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 					const uint64_t stop = std::min<uint64_t>(hi, S.off[(size_t)i + 1]);
 					if (seq[i]) {
 						const uint64_t s0 = p - S.off[(size_t)i], s1 = stop - S.off[(size_t)i];         // this slice of sequence i, and the probes that lie in it
-						memcpy(x.pin + (p - b), seq[i] + s0, (size_t)(s1 - s0));
+						stream_copy(x.pin + (p - b), (const uint8_t*)seq[i] + s0, (size_t)(s1 - s0));
 						const uint32_t L = len[i], step = L > 64 ? L / 64 : 1;
 						for (uint64_t k = (s0 + step - 1) / step; k < 64 && k * step < s1; ++k) S.probe[(size_t)i * 64 + k] = nt4_host((uint8_t)seq[i][k * step]);
 					} else memset(x.pin + (p - b), 'N', (size_t)(stop - p));       // resident elsewhere: filled in by k_repack
 					p = stop;
 				}
+				stream_fence();
 			};
 			const uint64_t per = ((e - b) + nt - 1) / nt;
 			const double tg0 = now_s();
