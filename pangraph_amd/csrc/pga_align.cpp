@@ -853,11 +853,12 @@ template <class T> static void scrap_later(std::vector<T> &&v)
 	{ std::lock_guard<std::mutex> lk(J->mu); J->q.push_back(std::move(v)); }
 	J->cv.notify_one();
 }
-template <class F> static void parallel_for(size_t n, int n_threads, F f)
+// (the untyped form is what the other files of the library use: pga_common.h, pool_for)
+void pool_for_raw(size_t n, int n_threads, void (*run)(void*, size_t), void *ctx)
 {
-	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) f(i); return; }
+	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) run(ctx, i); return; }
 	// (items are taken a few at a time once there are thousands: one shared counter)
-	PfJob job; job.n = n; job.chunk = std::max<size_t>(1, n / 256); job.ctx = &f; job.run = [](void *c, size_t i) { (*static_cast<F*>(c))(i); };
+	PfJob job; job.n = n; job.chunk = std::max<size_t>(1, n / 256); job.ctx = ctx; job.run = run;
 	const size_t helpers = std::min<size_t>((size_t)n_threads - 1, n - 1);
 	PfPool &P = pf_pool();
 	{
@@ -874,6 +875,7 @@ template <class F> static void parallel_for(size_t n, int n_threads, F f)
 	}
 	if (job.err) std::rethrow_exception(job.err);
 }
+template <class F> static void parallel_for(size_t n, int n_threads, F f) { pool_for_raw(n, n_threads, [](void *c, size_t i) { (*static_cast<F*>(c))(i); }, &f); }
 
 // ---------------------------------------------------------------- device-side planning of a list of regions (pga_plan.hip)
 static void plan_list(const SeqSet &S, Driver &D, std::vector<std::pair<QueryCtx*, RegTask*>> &list, hipStream_t st, bool verbose)

@@ -207,6 +207,10 @@ void set_part_concurrency(int n);
 int part_concurrency();             // concurrent parts of this call, or batch calls in flight in the process, whichever is larger
 void batch_call_enter(); void batch_call_leave();
 struct SeqFrom { PkBases store; uint64_t pos; };       // where a sequence that is already resident lies (pga_batch_derive)
+// a loop over the library's pool of persistent helper threads (pga_align.cpp): the caller takes part, helpers join as they are free.  Starting std::threads
+// per loop costs a stack mapping and its removal each (and the address-space lock of the whole process while six batches fault pages in).
+void pool_for_raw(size_t n, int n_threads, void (*run)(void*, size_t), void *ctx);
+template <class F> static inline void pool_for(size_t n, int n_threads, F f) { pool_for_raw(n, n_threads, [](void *c, size_t i) { (*static_cast<F*>(c))(i); }, &f); }
 void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, const char *const *name, int n_grp, const int64_t *grp_off, hipStream_t st,
                  const SeqFrom *from = nullptr, const uint8_t *const *from_probe = nullptr);
 void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm = nullptr);

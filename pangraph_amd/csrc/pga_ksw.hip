@@ -435,10 +435,8 @@ template <class F> static void host_parallel(size_t n, F f)
 {
 	const int nt = (int)std::min<size_t>((size_t)thread_budget(), n / 65536 + 1);
 	if (nt <= 1) { f(0, n); return; }
-	std::vector<std::thread> th;
 	const size_t per = (n + nt - 1) / nt;
-	for (int t = 0; t < nt; ++t) { const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per); if (lo < hi) th.emplace_back([=, &f] { f(lo, hi); }); }
-	for (auto &t : th) t.join();
+	pool_for((size_t)nt, nt, [&](size_t t) { const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per); if (lo < hi) f(lo, hi); });
 }
 
 static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, int band_level);   // 0: no banded kernels, 1: lane kernels + strips, 2: and the workgroup pipeline
@@ -600,7 +598,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 				if (!(jobs[i].flag & PGA_JOB_LL)) cg[t] += (unsigned long long)jobs[i].qlen + jobs[i].tlen + 2;   // worst case: one op per base
 			}
 		};
-		{ std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(count, t); count(0); for (auto &x : th) x.join(); }
+		pool_for((size_t)nt, nt, [&](size_t t) { count((int)t); });
 		std::vector<std::array<size_t, DP_NCLASS>> base((size_t)nt);
 		for (int c = 0; c < DP_NCLASS; ++c) {
 			size_t tot = 0;
@@ -613,7 +611,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
 			for (size_t i = lo; i < hi; ++i) cls[cls_of[i]][pos[cls_of[i]]++] = (uint32_t)i;
 		};
-		{ std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(fill, t); fill(0); for (auto &x : th) x.join(); }
+		pool_for((size_t)nt, nt, [&](size_t t) { fill((int)t); });
 	}
 	// class 12 (banded wave strips, pga_ksw_bstrips.hip): a launch that holds only a few banded exact problems is bound by the latency of ONE
 	// of them on one CU -- those go over several CUs each; a launch that holds more keeps them on the lane kernels, but for its few longest (an

@@ -228,12 +228,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			const uint64_t per = ((e - b) + nt - 1) / nt;
 			const double tg0 = now_s();
 			if (nt == 1 || e - b < (1u << 20)) gather(b, e);
-			else {
-				std::vector<std::thread> th;
-				for (int t = 1; t < nt; ++t) { const uint64_t lo = std::min(e, b + (uint64_t)t * per), hi = std::min(e, lo + per); if (lo < hi) th.emplace_back(gather, lo, hi); }
-				gather(b, std::min(e, b + per));
-				for (auto &t : th) t.join();
-			}
+			else pool_for((size_t)nt, nt, [&](size_t t) { const uint64_t lo = std::min(e, b + (uint64_t)t * per), hi = std::min(e, lo + per); if (lo < hi) gather(lo, hi); });
 			tu_g += now_s() - tg0;
 			const uint64_t nb = (e - b + 15) / 16 * 16;
 			if (nb > e - b) memset(x.pin + (e - b), 'N', (size_t)(nb - (e - b)));
