@@ -35,7 +35,7 @@ class pga_stats_t(C.Structure):
 
 
 KERNELS = ("k_sketch_tiles", "k_chain_fast", "k_bt_list+k_bt_walk", "k_extd2_fast", "k_extd2_wide<256>", "k_ll_i16", "k_rs_init+k_rs_pass+k_rs_small",
-           "k_gapfill_band", "k_extd2_wide<512>", "k_extd2_wide<1024>", "index build (sorts + CSR kernels)", "seeding kernels + anchor sort", "k_approx_strips", "k_extd2_lanes", "k_ext_pipe", "-")
+           "k_gapfill_band", "k_extd2_wide<512>", "k_extd2_wide<1024>", "index build (sorts + CSR kernels)", "seeding kernels + anchor sort", "k_wstrips+k_bstrips+k_approx_strips", "k_extd2_lanes", "k_ext_pipe", "-")
 # what bounds each slot: HBM traffic (scan / sort / hash work) or the integer DP recurrences (VALU + LDS issue; no MFMA)
 KERNEL_BOUND = ("hbm", "hbm", "hbm", "dp", "dp", "dp", "hbm", "dp", "dp", "dp", "hbm", "hbm", "dp", "dp", "dp", "-")
 

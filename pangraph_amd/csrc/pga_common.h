@@ -171,7 +171,7 @@ struct Index {
 
 // device kernels timed with HIP events (order is part of pga_stats_t, include/pga_align.h)
 enum { K_SKETCH = 0, K_CHAIN = 1, K_BACKTRACK = 2, K_EXTD2 = 3, K_EXTD2_WIDE = 4 /* <256> */, K_LL = 5, K_SORT = 6, K_BAND = 7, K_WIDE512 = 8, K_WIDE1024 = 9,
-       K_INDEX = 10 /* index build: device sorts + CSR kernels */, K_SEED = 11 /* seeding kernels + anchor sort */, K_STRIPS = 12 /* k_approx_strips */, K_LANES = 13 /* k_extd2_lanes */, K_PIPE = 14 /* k_ext_pipe */, K_COUNT = 16 };
+       K_INDEX = 10 /* index build: device sorts + CSR kernels */, K_SEED = 11 /* seeding kernels + anchor sort */, K_STRIPS = 12 /* k_wstrips, k_bstrips, k_approx_strips */, K_LANES = 13 /* k_extd2_lanes */, K_PIPE = 14 /* k_ext_pipe */, K_COUNT = 16 };
 struct KernelStat { double ms = 0, launches = 0, alg_bytes = 0, cells = 0; };   // cells: DP cells the kernel's loops evaluated
 struct Timers {
 	double upload = 0, sketch = 0, index = 0, seed = 0, chain = 0, align = 0, total = 0, dp_jobs = 0, dp_cells = 0, n_mz = 0, n_anchor = 0, dp_bases = 0, dp_cigar_ops = 0;
