@@ -445,7 +445,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
 // the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
 // used on the set's streams); a set returns to the pool with its streams drained.
-#define DP_NLANE 7
+#define DP_NLANE 9
 struct LaneSet { int dev = 0, arena = 0; hipStream_t stream[DP_NLANE] = {}; DBuf<uint8_t> slab[DP_NLANE]; };
 
 // SHARED launch streams (round 5).  With a set of four streams per concurrent call, six batches in flight (two query sets each) hold up to 48 lane
@@ -516,7 +516,7 @@ struct LaneLease {
 		// long kernels (lane 2: end extensions, inversion tests; lane 3: strips) in each: with six batches in flight 12 + 12 streams on 6 + 6
 		// queues (measured: lanes 1-3 all high 3.75-3.83 s per step, lanes {0,1} low / {2,3} high 3.60-3.64, {0,3} low / {1,2} high 3.49-3.61;
 		// every lane at the default priority 4.6 s).  PGA_LANE_PRIO=lhhh etc. for experiments (l low, h high, n default).
-		static const std::string pr = getenv("PGA_LANE_PRIO") && strlen(getenv("PGA_LANE_PRIO")) == DP_NLANE ? getenv("PGA_LANE_PRIO") : "lhhlhhl";
+		static const std::string pr = getenv("PGA_LANE_PRIO") && strlen(getenv("PGA_LANE_PRIO")) == DP_NLANE ? getenv("PGA_LANE_PRIO") : "lhhlhhlhl";
 		if (!dp_shared_streams()) for (int l = 0; l < DP_NLANE; ++l) {
 			if (pr[(size_t)l] == 'n') PGA_HIP(hipStreamCreateWithFlags(&set->stream[l], hipStreamNonBlocking));
 			else PGA_HIP(hipStreamCreateWithPriority(&set->stream[l], hipStreamNonBlocking, pr[(size_t)l] == 'l' ? prio_lo : prio_hi));
@@ -652,7 +652,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		for (uint32_t id : cls[11]) {
 			const DpJob &j = jobs[id];
 			bool slow = false;
-			if (j.tlen <= 64 && !(j.flag & EZ_APPROX_MAX) && (int64_t)j.qlen + j.tlen > 600 && bstrips_eligible(j, P) && stragglers.size() < 64) {
+			if (!(j.flag & EZ_APPROX_MAX) && (int64_t)j.qlen + j.tlen > 600 && bstrips_eligible(j, P) && stragglers.size() < 64) {      // (a target window of more than 64 bases: never covered)
 				const LbStop S = lb_stop_of(j.qlen, j.tlen, j.w < 0 ? std::max(j.qlen, j.tlen) : j.w, j.flag, q, e, q2, e2, P.sc_mch, P.sc_mis, sc_N, 0);
 				slow = !S.on || S.tail > -100;
 			}
@@ -705,7 +705,9 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// (the classes of a lane share a scratch slab and a stream, i.e. run one behind the other: the classes of long single problems -- the lane kernel's bulk (10),
 	// the wave strips (12), the workgroup pipeline (13), the inversion queries (6) -- each have a lane of their own since round 5: the bulk launch of a leaf
 	// round used to start when the strips' 17 ms extension had finished, not beside it)
-	static const int lane_of_class[DP_NCLASS] = {0, 0, 2, 3, 1, 1, 6, 1, 0, 3, 2, 1, 5, 4};   // tiles | the few largest problems | inversion queries + extensions | large problems
+	// (and the tiles: a near-root call's 1 981 tile problems were launched behind the ONE problem of class 1 and the corridor fills on the same lane, 2.3 ms into
+	// a round whose other classes take 2.2 ms: classes 0, 1 and 8 each on a lane of their own)
+	static const int lane_of_class[DP_NCLASS] = {0, 7, 2, 3, 1, 1, 6, 1, 8, 3, 2, 1, 5, 4};   // tiles | the few largest problems | inversion queries + extensions | large problems
 	int dev_id = 0; PGA_HIP(hipGetDevice(&dev_id));
 	struct Launch { int c; int nt = 0; uint32_t *cnt_p = nullptr; hipStream_t cs = nullptr; int si = -1; double est = 0; bool zc = false; const DpJob *jobs_p = nullptr; DpRes *res_p = nullptr; PinVec<DpRes> hr; std::vector<uint32_t> *ids; PinVec<DpJob> jb; DBuf<DpJob> d_jobs; DBuf<DpRes> d_r; DBuf<uint32_t> d_cnt; size_t n_waves; hipEvent_t e0, e1;
 	                DBuf<uint32_t> d_blk_job, d_blk_strip, d_bnd, d_tab; DBuf<uint64_t> d_slab_off, d_bnd_off, d_tab_off;
@@ -727,7 +729,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	PGA_HIP(hipEventRecord(ready, st));                     // time base of the per-class start offsets printed under PGA_VERBOSE
 	// scratch slabs: one grow-only buffer per launch lane (classes of a lane run one after the other and share it); sized
 	// before anything is launched so that no buffer moves under a running kernel
-	size_t waves_of[DP_NCLASS] = {0}, lane_need[DP_NLANE] = {0, 0, 0, 0, 0, 0, 0};
+	size_t waves_of[DP_NCLASS] = {0}, lane_need[DP_NLANE] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	uint32_t lanes_pool_chunks[2] = {0, 0}, pipe_pool_chunks = 0;
 	for (int c = DP_NCLASS - 1; c >= 0; --c) {
 		if (cls[c].empty()) continue;
@@ -786,7 +788,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// while the host still lays out the million-tile classes
 	// launch order: the classes of few, long problems first -- their workgroups need most of a CU's LDS and would otherwise wait until the
 	// persistent waves of the million-problem classes (16 per CU, all of its LDS) have drained their queue
-	int lane_si[DP_NLANE] = {-1, -1, -1, -1, -1, -1, -1};
+	int lane_si[DP_NLANE] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
 	static const int launch_order_bulk[DP_NCLASS] = {13, 12, 9, 11, 7, 6, 5, 4, 3, 10, 2, 8, 1, 0};
 	// a round of the upper tree (a few hundred tiles, one or two banded fills): what it waits for are its longest single problems -- a thin tile of
 	// 10 k diagonals, an approximate fill on the lane kernel -- and every launch costs the host ~60 us: those go out first (a first-round call: the
