@@ -267,6 +267,8 @@ def main():
                     help="where the long form goes (per-kernel table, batch timeline, stage sums, next rows); the LAST line of stdout stays under 4 KB")
     ap.add_argument("--no-resident-rate", action="store_true", help="skip the one extra step with resident inputs after the timed region (N = 1)")
     ap.add_argument("--no-parity-check", action="store_true", help="do not digest the last timed step's records against tests/golden/builds_expected.json.gz")
+    ap.add_argument("--model-gbp-s", type=float, default=7.9, help="N > 1: single-GPU rate the scaling model is evaluated with (profiles/r05_d_bench_c5.json)")
+    ap.add_argument("--model-host-s-per-gbp", type=float, default=0.85, help="N > 1: host core-seconds per Gbp of the single-GPU run (14.5 s per 17.07 Gbp step)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("PGA_BENCH_SLOTS", 6)), help="batches in flight (ready-set schedule)")
     ap.add_argument("--express", type=int, default=int(os.environ.get("PGA_BENCH_EXPRESS", 0)), help="slots reserved for the calls on the longest remaining path (schedule.run_ready_set: express)")
     ap.add_argument("--cap-gbp", type=float, default=float(os.environ.get("PGA_BENCH_CAP_GBP", 1.2)), help="largest batch of the ready-set schedule")
@@ -438,6 +440,7 @@ def main():
         # phase 1: this rank's subtrees, no communication; one gather.  Phase 2: the merges above the cut -- few, large, one after the other
         # along the tree -- by ALL ranks together: every rank indexes the whole call and maps its share of the queries of every group
         # (pga_batch_align_shard), level by level in an order every rank computes for itself; one more gather.
+        tph0 = time.perf_counter()
         mine_ids = {t.tid for t in tasks if owner[t.tid] == rank}
         if mine_ids:
             sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=mine_ids, on_result=on_result)
@@ -458,7 +461,9 @@ def main():
             return len(rec)
 
         covered = [t.tid for t in tasks if owner[t.tid] != -1]
+        tph1 = time.perf_counter()
         n_gathered = gather_all()
+        tph2 = time.perf_counter()
         top = [t.tid for t in tasks if owner[t.tid] == -1]
         done = {t.tid for t in tasks if owner[t.tid] != -1}
         while top:
@@ -475,8 +480,11 @@ def main():
             done.update(level)
             top = [tid for tid in top if tid not in done]
         covered = [t.tid for t in tasks if owner[t.tid] == -1]
+        tph3 = time.perf_counter()
         n_gathered += gather_all()
         agg["n_matches"] = n_gathered
+        # this rank's phases (the gathers end when the slowest rank arrives: phase 1 of the slowest rank = phase1_s + gather1_s of the fastest)
+        agg["phases"] = {"phase1_s": tph1 - tph0, "gather1_s": tph2 - tph1, "phase2_s": tph3 - tph2, "gather2_s": time.perf_counter() - tph3}
         return agg
 
     def step_waves():
@@ -694,6 +702,15 @@ def main():
                                                     host_cores=usable_cpus()) if world == 1 and args.schedule == "ready" and not args.leaf_only else None),
         "traffic_source": "profiles/ (rocprofv3 --pmc passes of this workload, not this run); bytes per launch in the unit of alg_bytes_per_launch",
     }
+    if world > 1 and args.schedule == "ready" and last.get("phases"):
+        # the phases of the last timed step on rank 0, beside what schedule.predict_scaling says for this world size from a single-GPU rate
+        # (--model-gbp-s / --model-host-s-per-gbp, defaults: the committed single-GPU line).  With PGA_BENCH_SINGLE_DEVICE=1 all ranks share ONE device:
+        # the measured times then say how the phases relate, not how fast N devices are.
+        model = sched.predict_scaling(pop, tasks, (world,), args.model_gbp_s, args.slots, host_cpu_s_per_gbp=args.model_host_s_per_gbp, host_cores=usable_cpus())[str(world)]
+        detail["phases_rank0"] = {"measured_s": {k: round(v, 3) for k, v in last["phases"].items()},
+                                  "model_s": {k: model[k] for k in ("phase1_s", "phase2_s", "step_s", "phase1_bound", "host_cores_per_rank", "calls_above_the_cut")},
+                                  "model_inputs": {"gbp_s_one_gpu": args.model_gbp_s, "host_cpu_s_per_gbp": args.model_host_s_per_gbp, "host_cores": usable_cpus()},
+                                  "single_device": bool(os.environ.get("PGA_BENCH_SINGLE_DEVICE"))}
     if rank == 0:
         if args.cpu_budget > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(waves, args.cpu_budget)

@@ -279,3 +279,28 @@ def test_bench_eight_ranks_on_one_device_equals_the_single_rank_build():
     a, b = outs[1], outs[8]
     assert b["n_gpus"] == 8 and a["n_matches_gathered"] == b["n_matches_gathered"] > 100
     assert a["build_sha256"] and a["build_sha256"] == b["build_sha256"]
+
+
+def test_bench_c5_eight_ranks_on_one_device_every_call_vs_reference_digests_and_phases():
+    """N = 8 at the BASELINE configuration without an 8-GPU node: eight gloo ranks share GPU 0 and the box's 16 usable cores (two per rank, what
+    an 8-GPU node with this grant gives a rank; four helper threads per batch).  Phase 1 (125 leaf groups and the subtrees above them per rank),
+    the gather, phase 2 (the merges above the cut, queries split eight ways), the second gather; bench.py digests the gathered list -- all 1998
+    calls against the compiled reference's digests, or it prints no value -- and writes the phases of rank 0 beside schedule.predict_scaling's
+    (`phases_rank0` in the detail file: on ONE device the measured times say how the phases relate, not how fast eight devices are)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGA_BENCH_SINGLE_DEVICE="1")
+    det = os.path.join(root, "gpurun_out", "bench_detail_8ranks_c5.json")
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--no-next-rows", "--detail", det]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    b = json.loads(r.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 8 and b["parity_checked_calls"] == 1998 and b["n_matches_gathered"] == 104928, b
+    ph = json.load(open(det))["phases_rank0"]
+    print("phases of rank 0, measured (eight ranks on one device) against the model (eight devices):", json.dumps(ph))
+    m = ph["measured_s"]
+    assert m["phase1_s"] > 0 and m["phase2_s"] > 0 and ph["model_s"]["phase1_s"] > 0 and ph["model_s"]["calls_above_the_cut"] > 0
+    assert 1e-3 * b["ms_per_step"] >= m["phase1_s"] + m["phase2_s"]
