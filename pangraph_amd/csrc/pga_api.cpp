@@ -30,6 +30,7 @@ static void mem_log(const char *what)
 	size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
 	fprintf(stderr, "[pga-mem] %-28s used %.1f GB of %.1f\n", what, (double)(tot - fr) / 1e9, (double)tot / 1e9);
 }
+static inline double cpu_s() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }   // (all threads of the process: clean with one batch in flight)
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---------------------------------------------------------------- options (options.c)
@@ -138,9 +139,9 @@ static void check_supported(const mm_mapopt_t &o, int k, int w)
 static void idx_sketch_index(PgaIdx &ix)
 {
 	const int w = ix.hdr.w, k = ix.hdr.k;
-	double t1 = now_s();
+	double t1 = now_s(); const double c1 = cpu_s();
 	sketch_all(ix.S, w, k, ix.M, ix.st, &ix.tm);
-	double t2 = now_s();
+	double t2 = now_s(); const double c2 = cpu_s();
 	{
 		EventTimer et(ix.st);
 		build_index_ex(ix.S, ix.M, w, k, ix.I, ix.grp, ix.st);
@@ -148,6 +149,7 @@ static void idx_sketch_index(PgaIdx &ix)
 		ks.ms += et.stop(K_INDEX); ks.launches += 1; ks.alg_bytes += 48.0 * (double)ix.M.n;
 	}
 	double t3 = now_s();
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   process cpu: sketch %.2f index %.2f ms\n", (c2 - c1) * 1e3, (cpu_s() - c2) * 1e3);
 	mem_log("after sketch+index");
 	ix.tm.sketch = t2 - t1, ix.tm.index = t3 - t2; ix.tm.n_mz = (double)ix.M.n;
 	ix.indexed = true;
@@ -162,7 +164,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	memset(&ix->hdr, 0, sizeof(ix->hdr));
 	ix->st = stream_lease();
 	if (w < 1) w = 1;
-	double t0 = now_s();
+	double t0 = now_s(); const double c0 = cpu_s();
 	const int64_t one_grp[2] = {0, n};
 	if (!grp_off) grp_off = one_grp, n_grp = 1;
 	upload_seqs(ix->S, n, seq, len, name, n_grp, grp_off, ix->st, from, from_probe);
@@ -191,6 +193,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	ix->hdr.n_seq = (uint32_t)n; ix->hdr.seq = ix->seq_hdr.data();
 	PGA_HIP(hipStreamSynchronize(ix->st));
 	ix->tm.upload = now_s() - t0;
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   process cpu: hand-over %.2f ms\n", (cpu_s() - c0) * 1e3);
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   hand-over: sequences %.2f ms, names and ranks %.2f ms\n", (t_up - t0) * 1e3, (now_s() - t_up) * 1e3);
 	if (do_index) idx_sketch_index(*ix);
 	return ix.release();
@@ -215,7 +218,7 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 {
 	ArenaScope arena_scope(ix.arena);
 	check_supported(opt, ix.I.k, ix.I.w);
-	double t0 = now_s();
+	double t0 = now_s(); const double c0 = cpu_s();
 	ix.d_mid_occ.upload(group_mid_occ(ix, opt), ix.st);
 	SeedResult SR;
 	{
@@ -224,18 +227,18 @@ static void run_batch(PgaIdx &ix, const mm_mapopt_t &opt, int n_threads)
 		KernelStat &ks = ix.tm.kern[K_SEED];         // query minimizers probe the table, anchors written, read and written by the sort
 		ks.ms += et.stop(K_SEED); ks.launches += 1; ks.alg_bytes += 16.0 * (double)ix.M.n + 32.0 * (double)SR.n_a;
 	}
-	double t1 = now_s();
+	double t1 = now_s(); const double c1 = cpu_s();
 	mem_log("after seed");
 	ChainResult CR;
 	CR.want_host_anchors = getenv("PGA_HOST_PLAN") != nullptr;            // (default: the anchors stay on the device and the regions are planned there, pga_plan.hip)
 	chain_all(ix.S, SR, opt, ix.I.k, CR, ix.st, &ix.tm, exact_sorts_forced());
-	double t2 = now_s();
+	double t2 = now_s(); const double c2 = cpu_s();
 	mem_log("after chain");
 	if (n_threads <= 0) { n_threads = usable_cpus(); }
 	set_thread_budget(n_threads);
 	align_batch(ix.S, opt, ix.I.k, SR.h_q_aoff, CR, SR.h_rep_len, ix.results, n_threads, &ix.tm, ix.st);
 	double t3 = now_s();
-	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   align_batch returned after %.4f s\n", t3 - t2);
+	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   align_batch returned after %.4f s\n[pga]   process cpu: seed %.2f chain %.2f align %.2f ms\n", t3 - t2, (c1 - c0) * 1e3, (c2 - c1) * 1e3, (cpu_s() - c2) * 1e3);
 	mem_log("after align");
 	ix.tm.seed = t1 - t0, ix.tm.chain = t2 - t1, ix.tm.align = t3 - t2; ix.tm.n_anchor = (double)SR.n_a;
 	ix.have_results = true; ix.res_opt = opt;

@@ -24,6 +24,8 @@
 #include <sched.h>
 #include <unistd.h>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
@@ -188,6 +190,15 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 	const uint64_t chunk = (uint64_t)16 << 20;      // (two staging buffers: a chunk is gathered while the one before it crosses PCIe)
 	const uint64_t n_chunks = (S.total + chunk - 1) / chunk;
 	if (n_chunks) {
+		// Large hand-overs take turns: the gather is bound by the host's memory bandwidth, so six of them side by side (the six leaf batches a build
+		// starts with) all finish late and together -- one after the other the first is on the device after a sixth of that time, and the batches no
+		// longer move through their stages in lockstep.  Small ones (the calls of the upper tree) never wait.  PGA_UPLOAD_GATE=0: off; =n: n at a time.
+		static const int gate_n = getenv("PGA_UPLOAD_GATE") ? atoi(getenv("PGA_UPLOAD_GATE")) : 1;
+		struct Gate { std::mutex mu; std::condition_variable cv; int in = 0; };
+		static Gate gate;
+		const bool gated = gate_n > 0 && S.total >= ((uint64_t)64 << 20);
+		if (gated) { std::unique_lock<std::mutex> lk(gate.mu); gate.cv.wait(lk, [&] { return gate.in < gate_n; }); ++gate.in; }
+		struct GateLeave { Gate &g; bool on; ~GateLeave() { if (on) { { std::lock_guard<std::mutex> lk(g.mu); --g.in; } g.cv.notify_one(); } } } gate_leave{gate, gated};
 		struct Stage { uint8_t *pin = nullptr; uint8_t *dev = nullptr; hipEvent_t sent; bool used = false; };
 		Stage sg[2];
 		bool staged = false; uint64_t n_staged = 0;
