@@ -117,6 +117,30 @@ void *dev_alloc(size_t bytes)
 			}
 		}
 	}
+	// A miss: the new block counts against the same 90 % of the device as the idle ones -- the cache gives up its oldest blocks FIRST.  (The limit used to
+	// be looked at only when a block came back: a process that had filled its cache with the sizes of one workload and then ran another -- the test suite: the
+	// level-synchronous C5 build, then the six-slot one -- took the device to its last MB with blocks that all were "live or within the limit when freed",
+	// and the runtime aborted the queue whose own allocation failed: HSA_STATUS_ERROR_OUT_OF_RESOURCES.)
+	{
+		std::vector<void*> drop;
+		{
+			std::lock_guard<std::mutex> lk(g_mu);
+			const size_t lim = cache_limit();                     // what idle blocks may hold beside the live ones
+			if (g_idle_total + r > lim) {
+				const size_t target = lim > r + ((size_t)2 << 30) ? lim - r - ((size_t)2 << 30) : 0;
+				while (g_idle_total > target && !g_idle_by_age.empty()) {
+					const IdleRef v = g_idle_by_age.begin()->second;
+					Pool &V = g_pools[v.pool];
+					auto rg = V.idle.equal_range(v.size);
+					for (auto jt = rg.first; jt != rg.second; ++jt) if (jt->second == v.p) { V.idle.erase(jt); break; }
+					V.idle_bytes -= v.size; g_idle_total -= v.size;
+					drop.push_back(v.p);
+					idle_forget(v.p);
+				}
+			}
+		}
+		for (void *q : drop) { NsScope sc(g_n_free, g_ns_free); (void)hipFree(q); }
+	}
 	void *p = nullptr;
 	hipError_t e;
 	{ NsScope sc(g_n_malloc, g_ns_malloc); e = hipMalloc(&p, r); }

@@ -69,12 +69,20 @@ void k_plan_regions(const PlanIn *__restrict__ in, uint32_t n_regions, u128 *__r
 		const int32_t q_lo = A.qpos(first) + 1 - sp0, q_hi = A.qpos(last) + 1;
 		if (rev) r_qs = qlen - q_hi, r_qe = qlen - q_lo; else r_qs = q_lo, r_qe = q_hi;
 		uint32_t cov = 0, blk = 0;
-		for (int i0 = first + 1; i0 <= last; i0 += 64) {
-			const int i = i0 + lane;
-			if (i <= last) {
-				const int32_t dt = A.tpos(i) - A.tpos(i - 1), dq = A.qpos(i) - A.qpos(i - 1), sp = A.span(i);
-				blk += (uint32_t)plan_max(dt, dq);
-				cov += (uint32_t)((dt > sp && dq > sp) ? sp : plan_min(dt, dq));
+		// (a whole-genome chain holds half a million anchors and ONE wave streams them: four windows of loads are in flight per trip -- the loop is bound
+		// by the latency of a load, not by its bytes)
+		for (int i0 = first + 1; i0 <= last; i0 += 256) {
+			u128 cur[4], prv[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; if (i <= last) { cur[u] = A.a[i]; prv[u] = A.a[i - 1]; } else { cur[u].x = cur[u].y = prv[u].x = prv[u].y = 0; } }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int i = i0 + 64 * u + lane;
+				if (i <= last) {
+					const int32_t dt = (int32_t)cur[u].x - (int32_t)prv[u].x, dq = (int32_t)cur[u].y - (int32_t)prv[u].y, sp = (int32_t)(cur[u].y >> 32 & 0xff);
+					blk += (uint32_t)plan_max(dt, dq);
+					cov += (uint32_t)((dt > sp && dq > sp) ? sp : plan_min(dt, dq));
+				}
 			}
 		}
 		r_mlen = (int32_t)((uint32_t)sp0 + (uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_sum_incl(cov), 63));
@@ -107,13 +115,18 @@ void k_plan_regions(const PlanIn *__restrict__ in, uint32_t n_regions, u128 *__r
 	}
 	// ---- long gaps of [as1, as1 + cnt1): chain-relative indices with |indel| > 10, in order ----
 	int n_g = 0;
-	for (int i0 = 1; i0 < cnt1; i0 += 64) {
-		const int i = i0 + lane;
-		bool lg = false;
-		if (i < cnt1) { const int32_t g = A.indel(as1 + i); lg = g < -10 || g > 10; }
-		const unsigned long long m = __ballot(lg);
-		if (lg) { const int o = n_g + __popcll(m & ((1ULL << lane) - 1)); if (o < PLAN_G_MAX) s_G[o] = i; }
-		n_g += __popcll(m);
+	for (int i0 = 1; i0 < cnt1; i0 += 256) {
+		int32_t g4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; g4[u] = i < cnt1 ? A.indel(as1 + i) : 0; }       // (four windows of loads in flight)
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int i = i0 + 64 * u + lane;
+			const bool lg = i < cnt1 && (g4[u] < -10 || g4[u] > 10);
+			const unsigned long long m = __ballot(lg);
+			if (lg) { const int o = n_g + __popcll(m & ((1ULL << lane) - 1)); if (o < PLAN_G_MAX) s_G[o] = i; }
+			n_g += __popcll(m);
+		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	if (n_g > P.g_max) { O.status = 2; if (lane == 0) out[rid_x] = O; return; }
@@ -291,11 +304,14 @@ void k_plan_cut(const PlanIn *__restrict__ in, uint32_t n_regions, const u128 *_
 	uint32_t n = 0;
 	int32_t seg_rs = O.rs, seg_qs = O.qs, seg_i_prev = 0;
 	int32_t re = O.rs, qe = O.qs;
+	u128 v_next; v_next.x = v_next.y = 0;
+	if (1 + lane < cnt1) v_next = A[as1 + 1 + lane];
 	for (int i0 = 1; i0 < cnt1; i0 += 64) {
 		const int i = i0 + lane;
 		bool use = false, lj = false; int32_t ce = 0, cq = 0;
+		const u128 v = v_next;
+		if (i + 64 < cnt1) v_next = A[as1 + i + 64];                                   // (the next window is on its way while this one is cut: one wave, half a million anchors)
 		if (i < cnt1) {
-			const u128 v = A[as1 + i];
 			const bool skip = (v.y & (PA_IGNORE | PA_TANDEM)) != 0 && i != cnt1 - 1;
 			use = !skip; lj = (v.y & PA_LONG_JOIN) != 0;
 			ce = (int32_t)v.x - half_k, cq = (int32_t)v.y - half_k;

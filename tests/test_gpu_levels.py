@@ -329,7 +329,24 @@ def test_c5_ready_set_six_slots_every_call_vs_reference_digests(gpu_lib, residen
     assert len(tasks) == 1998
     want = dg.expected_by_call(pop, gold)
     batch.lib().pga_warm_streams(6)
-    results, log = _run_build_ready_set(pop, tasks, 6, resident)
+    # what the device holds when this test starts (the tests before it leave their blocks in the library's cache), and the library's / the runtime's own
+    # stderr of the run in a file of its own: an abort inside the runtime takes pytest's captured output with it
+    import ctypes
+    import json
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    tag = "resident" if resident else "host"
+    a = (ctypes.c_int64 * 6)()
+    batch.lib().pga_mem_stats(a)
+    with open(os.path.join(out_dir, f"sixslot_mem_{tag}.json"), "w") as fh:
+        json.dump({"hipMalloc_calls": a[0], "hipFree_calls": a[2], "live_GB": a[4] / 2**30, "idle_in_cache_GB": a[5] / 2**30}, fh)
+    saved = os.dup(2)
+    fd = os.open(os.path.join(out_dir, f"sixslot_stderr_{tag}.txt"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.dup2(fd, 2)
+    try:
+        results, log = _run_build_ready_set(pop, tasks, 6, resident)
+    finally:
+        os.dup2(saved, 2); os.close(saved); os.close(fd)
     assert max(sum(1 for a, b, _, _ in log if a <= t < b) for t, _, _, _ in log) >= 4          # batches really were in flight together
     n, bad = dg.check_calls(results, want)
     assert n == 1998 and not bad, (n, bad[:10], len(bad))
