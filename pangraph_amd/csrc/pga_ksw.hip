@@ -441,7 +441,7 @@ template <class F> static void host_parallel(size_t n, F f)
 
 static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm, int band_level);   // 0: no banded kernels, 1: lane kernels + strips, 2: and the workgroup pipeline
 
-// Launch lanes: four priority streams (lane 0, the million-tile classes, at the lower priority) and four grow-only scratch slabs per SET.
+// Launch lanes: a grow-only scratch slab per lane and SET (and, with PGA_DP_SHARED=0, a priority stream per lane: lane 0, the million-tile class, at the lower priority).
 // Sets are pooled per device and leased for one dp_run call: as many sets exist as calls ever ran concurrently on a device, whatever
 // the number of host threads that came and went.  A slab lives in the set's own device-memory arena (blocks of a set are only ever
 // used on the set's streams); a set returns to the pool with its streams drained.
