@@ -645,7 +645,8 @@ def main():
                                f"({len(waves)} waves), U = {units / 1e9:.2f} Gbp per step (asm10 -c -X -s 90)" + (" [LEAF LEVEL ONLY]" if args.leaf_only else ""),
                    "genomes": args.genomes, "genome_length": args.length, "seed": args.seed,
                    "inputs": args.inputs, "timed_region": f"per batch: {timed}; + match-list gather (N > 1)",
-                   "schedule": f"ready set, {args.slots} batches in flight" if args.schedule == "ready" else "level-synchronous waves",
+                   "schedule": (f"ready set, {args.slots} batches in flight, decisions by " + ("the library (pga_sched_*)" if os.environ.get("PGA_NATIVE_SCHED", "0") not in ("", "0") else "schedule.ReadySet"))
+                               if args.schedule == "ready" else "level-synchronous waves",
                    "parallelism": f"{world} rank(s): subtrees per rank, no data-path collective, match-list gathers only"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "hbm_achieved_GBs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,

@@ -197,24 +197,26 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 	PGA_HIP(hipStreamSynchronize(st));
 }
 
-__global__ void k_grp_cnt_keys(const uint32_t *__restrict__ occ_off, const uint32_t *__restrict__ key_grp, uint64_t n_keys, uint64_t *__restrict__ comp)
+// comp = group << cbits | occurrence count: a count never exceeds the number of indexed minimizers, so cbits = bit length of n_occ holds it
+// and the sort below runs over gbits + cbits bits (four or five digit passes) instead of all 64 (eight)
+__global__ void k_grp_cnt_keys(const uint32_t *__restrict__ occ_off, const uint32_t *__restrict__ key_grp, uint64_t n_keys, int cbits, uint64_t *__restrict__ comp)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n_keys) comp[i] = (uint64_t)key_grp[i] << 32 | (uint64_t)(occ_off[i + 1] - occ_off[i]);
+	if (i < n_keys) comp[i] = (uint64_t)key_grp[i] << cbits | (uint64_t)(occ_off[i + 1] - occ_off[i]);
 }
-__global__ void k_grp_quantile(const uint64_t *__restrict__ comp, uint64_t n_keys, int n_grp, float f, int32_t *__restrict__ out)
+__global__ void k_grp_quantile(const uint64_t *__restrict__ comp, uint64_t n_keys, int n_grp, int cbits, float f, int32_t *__restrict__ out)
 {
 	int g = blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_grp) return;
 	uint64_t lo = 0, hi = n_keys, a, b;
-	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (comp[m] < ((uint64_t)g << 32)) lo = m + 1; else hi = m; }
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if ((comp[m] >> cbits) < (uint64_t)g) lo = m + 1; else hi = m; }
 	a = lo; hi = n_keys;
-	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (comp[m] < ((uint64_t)(g + 1) << 32)) lo = m + 1; else hi = m; }
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if ((comp[m] >> cbits) < (uint64_t)g + 1) lo = m + 1; else hi = m; }
 	b = lo;
 	const uint64_t n = b - a;
 	if (n == 0) { out[g] = 1; return; }
 	const uint64_t kk = (uint32_t)((1. - (double)f) * (double)n);      // index.c:204: double arithmetic on the float fraction
-	out[g] = (int32_t)((uint32_t)comp[a + kk] + 1u);
+	out[g] = (int32_t)((uint32_t)(comp[a + kk] & ((1ULL << cbits) - 1)) + 1u);
 }
 
 // mm_idx_cal_max_occ (index.c:186-207) of every group: the (uint32)((1-f)*n)-th smallest occurrence count, plus one.
@@ -225,13 +227,16 @@ std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f,
 	const uint64_t n = I.n_keys;
 	if (n == 0) { std::fill(out.begin(), out.end(), 1); return out; }
 	DBuf<uint64_t> comp(n), comp2(n);
-	hipLaunchKernelGGL(k_grp_cnt_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, I.occ_off.p, I.key_grp.p, n, comp.p);
+	int cbits = 1; while (cbits < 32 && (I.n_occ >> cbits) != 0) ++cbits;        // counts are <= n_occ < 2^32
+	int gbits = 0; while (gbits < 32 && (1LL << gbits) < S.n_grp) ++gbits;       // groups are < n_grp
+	const unsigned sort_bits = (unsigned)(getenv("PGA_MAXOCC_SORT64") ? 64 : gbits + cbits);
+	hipLaunchKernelGGL(k_grp_cnt_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, I.occ_off.p, I.key_grp.p, n, cbits, comp.p);
 	size_t tmp_bytes = 0;
-	PGA_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, comp.p, comp2.p, n, 0, 64, st));
+	PGA_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, comp.p, comp2.p, n, 0, sort_bits, st));
 	DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
-	PGA_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, comp.p, comp2.p, n, 0, 64, st));
+	PGA_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, comp.p, comp2.p, n, 0, sort_bits, st));
 	DBuf<int32_t> d_out((size_t)S.n_grp);
-	hipLaunchKernelGGL(k_grp_quantile, dim3((unsigned)((S.n_grp + 255) / 256)), dim3(256), 0, st, comp2.p, n, S.n_grp, f, d_out.p);
+	hipLaunchKernelGGL(k_grp_quantile, dim3((unsigned)((S.n_grp + 255) / 256)), dim3(256), 0, st, comp2.p, n, S.n_grp, cbits, f, d_out.p);
 	PGA_HIP(hipGetLastError());
 	return d_out.download(st);
 }

@@ -23,6 +23,7 @@ partition and a cost model calibrated on one GPU into the step time to expect at
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import time
 from dataclasses import dataclass, field
@@ -153,59 +154,67 @@ class TaskBatch:
         return [n for t in self.tasks for n in t.names]
 
 
-def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], slots: int = 6, cap_bases: float = 1.2e9,
-                  min_batch_bases: float = 0.0, done: Optional[set] = None, only: Optional[set] = None,
-                  on_result: Optional[Callable[[List[Task], object, float, float], None]] = None, express: int = 0, express_eps: float = 0.05,
-                  express_cap: float = 60e6):
-    """Runs `tasks` (all of them, or the subset `only`) in dependency order; `run_batch(list of tasks)` is called from up to `slots` host
-    threads.  `done`: tids that count as finished from the start (results that arrived from elsewhere).  Returns the batch log
-    [(t_start, t_end, n_tasks, bases)] relative to the start.
+class ReadySet:
+    """The DECISIONS of the ready-set schedule without threads or clocks: which calls are ready, what may start now, which calls a batch takes,
+    what a finished batch releases.  `run_ready_set` drives it from host threads; the library holds the same logic behind a C-ABI for hosts
+    that are not Python (include/pga_sched.h, pangraph_amd/csrc/pga_sched.cpp: pga_sched_take / pga_sched_finish), and tests/test_schedule_cpu.py
+    steps both through the same simulated builds and compares every batch."""
 
-    express > 0: that many of the slots are an EXPRESS LANE for the critical path.  A call whose remaining path (Task.prio) is within
-    `express_eps` seconds of the longest remaining path of the whole run is critical; it goes out the moment it is ready, alone or with the
-    few other calls that are just as critical (at most `express_cap` bases), instead of waiting for a slot to come free and then sharing a batch
-    -- and its latency -- with hundreds of Mbp of bulk work.  The bulk uses the other slots as before."""
-    want = set(range(len(tasks))) if only is None else set(only)
-    fin = set(done or ())
-    indeg = {}
-    for tid in want:
-        indeg[tid] = sum(1 for d in tasks[tid].deps if d not in fin)
-        for d in tasks[tid].deps:
-            if d not in fin and d not in want:
-                raise ValueError(f"task {tid} depends on {d}, which is neither done nor scheduled")
-    ready = [tid for tid in want if indeg[tid] == 0]
-    left = len(want)
-    in_flight = 0
-    express = max(0, min(int(express), max(0, slots - 1)))
-    n_express = 0                                   # express batches in flight
-    unfinished = sorted(want - fin, key=lambda tid: -tasks[tid].prio)   # for the longest remaining path
-    pos_top = [0]
+    def __init__(self, tasks: List[Task], slots: int = 6, cap_bases: float = 1.2e9, min_batch_bases: float = 0.0, done: Optional[set] = None,
+                 only: Optional[set] = None, express: int = 0, express_eps: float = 0.05, express_cap: float = 60e6):
+        self.tasks = tasks
+        self.slots, self.cap_bases, self.min_batch_bases = slots, cap_bases, min_batch_bases
+        self.express_eps, self.express_cap = express_eps, express_cap
+        want = set(range(len(tasks))) if only is None else set(only)
+        self.fin = set(done or ())
+        self.indeg = {}
+        for tid in sorted(want):
+            self.indeg[tid] = sum(1 for d in tasks[tid].deps if d not in self.fin)
+            for d in tasks[tid].deps:
+                if d not in self.fin and d not in want:
+                    raise ValueError(f"task {tid} depends on {d}, which is neither done nor scheduled")
+        self.ready = [tid for tid in sorted(want) if self.indeg[tid] == 0]
+        self.left = len(want)
+        self.in_flight = 0
+        self.express = max(0, min(int(express), max(0, slots - 1)))
+        self.n_express = 0                              # express batches in flight
+        self.unfinished = sorted(want - self.fin, key=lambda tid: -tasks[tid].prio)   # for the longest remaining path
+        self.pos_top = 0
 
-    def crit_level():
-        while pos_top[0] < len(unfinished) and unfinished[pos_top[0]] in fin:
-            pos_top[0] += 1
-        return tasks[unfinished[pos_top[0]]].prio if pos_top[0] < len(unfinished) else 0.0
-    cv = threading.Condition()
-    log, errs = [], []
-    t_origin = time.perf_counter()
+    def crit_level(self) -> float:
+        while self.pos_top < len(self.unfinished) and self.unfinished[self.pos_top] in self.fin:
+            self.pos_top += 1
+        return self.tasks[self.unfinished[self.pos_top]].prio if self.pos_top < len(self.unfinished) else 0.0
 
-    def take(kind):
-        nonlocal in_flight, n_express
+    def can_take(self) -> Optional[str]:
+        """what may start now: "express" (a critical call is ready and an express slot is free), "bulk" (a bulk slot is free), or None"""
+        tasks = self.tasks
+        if not self.ready:
+            return None
+        if self.express and self.n_express < self.express and max(tasks[tid].prio for tid in self.ready) >= self.crit_level() - self.express_eps:
+            return "express"
+        if self.in_flight - self.n_express < self.slots - self.express:
+            return "bulk"
+        return None
+
+    def take(self, kind: str) -> List[int]:
+        tasks, ready = self.tasks, self.ready
         # largest remaining path first; stop at the cap (one oversized task still goes alone)
         ready.sort(key=lambda tid: -tasks[tid].prio)
         if kind == "express":
-            lvl = crit_level() - express_eps
+            lvl = self.crit_level() - self.express_eps
             got, b = [], 0
             for tid in ready:
-                if tasks[tid].prio < lvl or (got and b + tasks[tid].bases > express_cap):
+                if tasks[tid].prio < lvl or (got and b + tasks[tid].bases > self.express_cap):
                     break
                 got.append(tid); b += tasks[tid].bases
-            ready[:] = [tid for tid in ready if tid not in set(got)]
-            in_flight += 1; n_express += 1
+            taken = set(got)
+            ready[:] = [tid for tid in ready if tid not in taken]
+            self.in_flight += 1; self.n_express += 1
             return got
         total = sum(tasks[tid].bases for tid in ready)
-        free = max(1, (slots - express) - (in_flight - n_express))
-        cap = max(min(cap_bases, total / free if free > 1 else cap_bases), min_batch_bases, 1.0)
+        free = max(1, (self.slots - self.express) - (self.in_flight - self.n_express))
+        cap = max(min(self.cap_bases, total / free if free > 1 else self.cap_bases), self.min_batch_bases, 1.0)
         got, b = [], 0
         rest = []
         for tid in ready:
@@ -214,30 +223,63 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
             else:
                 rest.append(tid)
         ready[:] = rest
-        in_flight += 1
+        self.in_flight += 1
         return got
 
-    def can_take():
-        # what may start now: "express" (a critical call is ready and an express slot is free), "bulk" (a bulk slot is free), or None
-        if not ready:
-            return None
-        if express and n_express < express and max(tasks[tid].prio for tid in ready) >= crit_level() - express_eps:
-            return "express"
-        if in_flight - n_express < slots - express:
-            return "bulk"
-        return None
+    def abandon(self, kind: str) -> None:
+        """a batch that failed: its slot comes back, its calls stay unfinished"""
+        self.in_flight -= 1
+        self.n_express -= kind == "express"
+
+    def finish(self, ids: Sequence[int], kind: str) -> None:
+        self.in_flight -= 1
+        self.n_express -= kind == "express"
+        for i in ids:
+            self.fin.add(i)
+            self.left -= 1
+            for u in self.tasks[i].users:
+                if u in self.indeg:
+                    self.indeg[u] -= 1
+                    if self.indeg[u] == 0:
+                        self.ready.append(u)
+
+
+def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], slots: int = 6, cap_bases: float = 1.2e9,
+                  min_batch_bases: float = 0.0, done: Optional[set] = None, only: Optional[set] = None,
+                  on_result: Optional[Callable[[List[Task], object, float, float], None]] = None, express: int = 0, express_eps: float = 0.05,
+                  express_cap: float = 60e6, native: Optional[bool] = None):
+    """Runs `tasks` (all of them, or the subset `only`) in dependency order; `run_batch(list of tasks)` is called from up to `slots` host
+    threads.  `done`: tids that count as finished from the start (results that arrived from elsewhere).  Returns the batch log
+    [(t_start, t_end, n_tasks, bases)] relative to the start.
+
+    express > 0: that many of the slots are an EXPRESS LANE for the critical path.  A call whose remaining path (Task.prio) is within
+    `express_eps` seconds of the longest remaining path of the whole run is critical; it goes out the moment it is ready, alone or with the
+    few other calls that are just as critical (at most `express_cap` bases), instead of waiting for a slot to come free and then sharing a batch
+    -- and its latency -- with hundreds of Mbp of bulk work.  The bulk uses the other slots as before.
+
+    native: the decisions come from the library's scheduler (pga_sched_*, the one a Rust or C++ host binds) instead of `ReadySet`; the
+    threads block inside pga_sched_take.  Default: PGA_NATIVE_SCHED=1 in the environment."""
+    if native is None:
+        native = os.environ.get("PGA_NATIVE_SCHED", "0") not in ("", "0")
+    if native:
+        from . import sched_native
+        return sched_native.run_ready_set(tasks, run_batch, slots=slots, cap_bases=cap_bases, min_batch_bases=min_batch_bases, done=done, only=only,
+                                          on_result=on_result, express=express, express_eps=express_eps, express_cap=express_cap)
+    rs = ReadySet(tasks, slots, cap_bases, min_batch_bases, done, only, express, express_eps, express_cap)
+    cv = threading.Condition()
+    log, errs = [], []
+    t_origin = time.perf_counter()
 
     def worker():
-        nonlocal left, in_flight, n_express
         while True:
             with cv:
-                kind = can_take()
-                while kind is None and left > 0 and not errs:
+                kind = rs.can_take()
+                while kind is None and rs.left > 0 and not errs:
                     cv.wait()
-                    kind = can_take()
-                if left <= 0 or errs:
+                    kind = rs.can_take()
+                if rs.left <= 0 or errs:
                     return
-                ids = take(kind)
+                ids = rs.take(kind)
             t0 = time.perf_counter()
             try:
                 res = run_batch([tasks[i] for i in ids])
@@ -247,22 +289,12 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
             except BaseException as e:   # noqa: BLE001
                 with cv:
                     errs.append(e)
-                    in_flight -= 1
-                    n_express -= kind == "express"
+                    rs.abandon(kind)
                     cv.notify_all()
                 return
             with cv:
                 log.append((t0 - t_origin, t1 - t_origin, len(ids), sum(tasks[i].bases for i in ids)))
-                in_flight -= 1
-                n_express -= kind == "express"
-                for i in ids:
-                    fin.add(i)
-                    left -= 1
-                    for u in tasks[i].users:
-                        if u in indeg:
-                            indeg[u] -= 1
-                            if indeg[u] == 0:
-                                ready.append(u)
+                rs.finish(ids, kind)
                 cv.notify_all()
 
     th = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, slots))]

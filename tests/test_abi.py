@@ -28,7 +28,7 @@ def _declared(header):
 def test_product_exports_every_declared_symbol(product_so):
     out = subprocess.run(["nm", "-D", "--defined-only", product_so], check=True, capture_output=True, text=True).stdout
     exported = set(line.split()[-1] for line in out.splitlines() if " T " in line)
-    declared = _declared("pga_mm2_abi.h") + _declared("pga_align.h")
+    declared = _declared("pga_mm2_abi.h") + _declared("pga_align.h") + _declared("pga_sched.h")
     assert len(declared) >= 20
     missing = [s for s in declared if s not in exported]
     assert not missing, f"libpgalign.so does not export {missing}"

@@ -145,3 +145,143 @@ def test_scaling_model_prices_the_host():
     assert abs(cheap["1"]["step_s"] - free["1"]["step_s"]) < 1e-9
     assert dear["8"]["phase1_bound"] == "host" and dear["8"]["gbp_s"] < 0.5 * free["8"]["gbp_s"]
     assert total > 0
+
+
+# ---- the library's scheduler (include/pga_sched.h) against schedule.ReadySet ---------------------------------------------------------
+def _simulate(tasks, taker, duration):
+    """Steps a scheduler through a build without threads or clocks: whatever may start starts, then the batch that ends first ends.
+    taker: object with try_take() -> (ids, handle) | ([], _) nothing may start | (None, _) run over, and finish(handle)."""
+    now, flying, batches, seq = 0.0, [], [], 0
+    while True:
+        ids, h = taker.try_take()
+        if ids:
+            batches.append(list(ids))
+            flying.append((now + duration(ids), seq, h)); seq += 1
+            continue
+        if not flying:
+            assert ids is None or taker.left() == 0, "nothing in flight, nothing may start, yet calls are left"
+            return batches
+        flying.sort()
+        now, _, h = flying.pop(0)
+        taker.finish(h)
+
+
+class _PyTaker:
+    def __init__(self, tasks, **kw):
+        self.rs = sched.ReadySet(tasks, **kw)
+
+    def try_take(self):
+        if self.rs.left <= 0:
+            return None, None
+        kind = self.rs.can_take()
+        if kind is None:
+            return [], None
+        ids = self.rs.take(kind)
+        return ids, (ids, kind)
+
+    def finish(self, h):
+        self.rs.finish(*h)
+
+    def left(self):
+        return self.rs.left
+
+
+class _NativeTaker:
+    def __init__(self, tasks, **kw):
+        from pangraph_amd import sched_native
+        self.ns = sched_native.NativeSched(tasks)
+        self.ns.start(**kw)
+
+    def try_take(self):
+        return self.ns.try_take()
+
+    def finish(self, h):
+        self.ns.finish(h)
+
+    def left(self):
+        return self.ns.left()
+
+
+def test_native_scheduler_cuts_the_same_batches(product_so):
+    """pga_sched_* (what a Rust host binds) and schedule.ReadySet (what bench.py drives) take the same calls into the same batches in the same
+    order, over whole simulated builds: slot counts, caps, the express lane, and the two phases of a multi-rank step (`only` / `done`)."""
+    from pangraph_amd import sched_native
+    pop = _pop(60)
+    tasks = sched.build_tasks(pop)
+    ns = sched_native.NativeSched(tasks)
+    assert [float(p) for p in ns.prio()] == [t.prio for t in tasks]                      # bit for bit: same sums in the same order
+    for b, n in ((0, 0), (1, 1), (123_456, 2), (5_000_001, 2), (10_000_000, 7), (4_000_000, 4)):
+        assert sched_native.cost(b, n) == sched.cost_estimate(b, n)
+    durs = {
+        "cost": lambda ids: sum(sched.cost_estimate(tasks[i].bases, len(tasks[i].seqs)) for i in ids),
+        "jitter": lambda ids: 0.001 + ((ids[0] * 2654435761) % 1000) * 1e-5,                # batches overtake each other
+    }
+    n_cmp = 0
+    for name, dur in durs.items():
+        for kw in (dict(slots=1), dict(slots=3, cap_bases=150_000), dict(slots=6, cap_bases=400_000, min_batch_bases=50_000),
+                   dict(slots=6, cap_bases=1.2e9, express=1, express_eps=0.004, express_cap=90_000), dict(slots=4, cap_bases=300_000, express=2, express_eps=0.01),
+                   dict(slots=2, cap_bases=1.0, express=5)):
+            a = _simulate(tasks, _PyTaker(tasks, **kw), dur)
+            b = _simulate(tasks, _NativeTaker(tasks, **kw), dur)
+            assert a == b, (name, kw)
+            assert sorted(i for ids in a for i in ids) == list(range(len(tasks)))
+            n_cmp += len(a)
+    # the phases of a multi-rank step
+    for world in (2, 8):
+        owner, _ = sched.partition_subtrees(pop, tasks, world)
+        assert sched_native.partition(pop, tasks, world) == owner
+        for r in range(world):
+            mine = {t.tid for t in tasks if owner[t.tid] == r}
+            if mine:
+                kw = dict(slots=3, cap_bases=200_000, only=mine)
+                assert _simulate(tasks, _PyTaker(tasks, **kw), durs["jitter"]) == _simulate(tasks, _NativeTaker(tasks, **kw), durs["jitter"])
+        kw = dict(slots=3, cap_bases=200_000, only={t.tid for t in tasks if owner[t.tid] == -1}, done={t.tid for t in tasks if owner[t.tid] != -1})
+        a = _simulate(tasks, _PyTaker(tasks, **kw), durs["cost"])
+        assert a == _simulate(tasks, _NativeTaker(tasks, **kw), durs["cost"]) and sorted(i for ids in a for i in ids) == sorted(kw["only"])
+    assert n_cmp > 200
+    assert sched_native.partition(pop, tasks, 1) == [0] * len(tasks)
+    for per_rank in (1, 2, 7):
+        assert sched_native.partition(pop, tasks, 4, per_rank) == sched.partition_subtrees(pop, tasks, 4, per_rank)[0]
+
+
+def test_native_scheduler_from_threads_and_its_errors(product_so):
+    """the blocking entry from host threads (the way bench.py --native-sched and a Rust host use it): every call once, dependencies first; a
+    failing batch ends the run; a dependency that is neither done nor scheduled, a cycle and a bad id are errors with a text."""
+    import pytest
+    from pangraph_amd import sched_native
+    tasks = sched.build_tasks(_pop(40))
+    done_at, lock = {}, threading.Lock()
+
+    def run_batch(ts):
+        with lock:
+            for t in ts:
+                assert t.tid not in done_at
+                for d in t.deps:
+                    assert d in done_at, (t.tid, d)
+        time.sleep(0.001)
+        with lock:
+            for t in ts:
+                done_at[t.tid] = time.perf_counter()
+        return len(ts)
+
+    seen = []
+    log = sched.run_ready_set(tasks, run_batch, slots=4, cap_bases=150_000, native=True, on_result=lambda ts, res, t0, t1: seen.append(res))
+    assert sorted(done_at) == list(range(len(tasks))) and sum(n for _, _, n, _ in log) == len(tasks) == sum(seen)
+
+    def boom(ts):
+        raise RuntimeError("boom")
+    with pytest.raises(RuntimeError, match="boom"):
+        sched.run_ready_set(tasks, boom, slots=3, native=True)
+    ns = sched_native.NativeSched(tasks)
+    with pytest.raises(ValueError, match="neither done nor scheduled"):
+        ns.start(only={t.tid for t in tasks if t.deps})
+    with pytest.raises(ValueError, match="out of range"):
+        ns.start(only={len(tasks) + 5})
+
+    class T:
+        def __init__(self, deps):
+            self.deps, self.bases, self.seqs = deps, 10, [b"A"]
+    with pytest.raises(ValueError, match="cycle"):
+        sched_native.NativeSched([T([1]), T([0])])
+    with pytest.raises(ValueError, match="bad dependency"):
+        sched_native.NativeSched([T([0])])
