@@ -78,6 +78,20 @@ int pga_batch_derive(const pga_batch_t *old, int32_t n_groups, const int64_t *gr
  * align_with_minimap2_lib.rs:64-74): every shard indexes ALL sequences of the batch and maps, of every group, a contiguous range of the
  * queries (balanced by length).  The shards' match lists are disjoint; their union ordered by (group, query) is pga_batch_align's list. */
 int pga_batch_align_shard(pga_batch_t *batch, const pga_params_t *params, int32_t shard, int32_t n_shards, pga_result_t **out);
+/* The exchange step of a multi-GPU build is a gather of match lists and nothing else; transport is the host's (RCCL / MPI point to point: the
+ * CIGAR pool dominates the payload and only the owner of the graph needs it).  These two are the host logic either side of it (no device work;
+ * pangraph_amd/dist.py holds the same for the Python host, tests/test_dist_cpu.py compares them):
+ *   pga_shard_groups_balanced  deals n_groups groups to `world` ranks, heaviest first, each to the rank that is lightest so far (ties: lower
+ *                              rank); rank_of_group[g] receives the owner.  Deterministic: every rank computes the same plan without talking.
+ *   pga_merge_match_lists      puts the lists of n_parts ranks together as ONE rank would have produced them: group ids become global
+ *                              (local_to_global[r][g], or unchanged where local_to_global or local_to_global[r] is NULL), CIGAR offsets point into
+ *                              the concatenated pool, records ordered by (group, query, the aligner's own order inside a query) -- also when the
+ *                              queries of one group were split over the ranks (pga_batch_align_shard).  out_matches holds sum n_matches records,
+ *                              out_cigars sum n_cigar_words words; returns 0, -1 on a group id outside its table. */
+void pga_shard_groups_balanced(int32_t n_groups, const double *weights, int32_t world, int32_t *rank_of_group);
+int pga_merge_match_lists(int32_t n_parts, const pga_match_t *const *matches, const int64_t *n_matches, const uint32_t *const *cigars,
+                          const int64_t *n_cigar_words, const int32_t *const *local_to_global, const int32_t *n_local_groups,
+                          pga_match_t *out_matches, uint32_t *out_cigars);
 void pga_batch_free(pga_batch_t *batch);
 int64_t pga_result_n_matches(const pga_result_t *r);
 const pga_match_t *pga_result_matches(const pga_result_t *r);

@@ -7,6 +7,7 @@
 // The decisions are those of pangraph_amd/schedule.py (class ReadySet) statement by statement -- the same sort (stable, by falling priority),
 // the same caps in the same arithmetic -- so that a build driven from Rust or C++ cuts the batches the measured Python host cuts.
 #include "../../include/pga_sched.h"
+#include "../../include/pga_align.h"
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
@@ -300,6 +301,52 @@ int32_t pga_sched_partition(int32_t n_nodes, const int32_t *child0, const int32_
 		else owner[t] = owner_of_node[v];
 	}
 	return above;
+}
+
+// ---- multi-GPU: the host logic either side of the match-list gather (pangraph_amd/dist.py: shard_groups_balanced, merge_match_lists) ----
+void pga_shard_groups_balanced(int32_t n_groups, const double *weights, int32_t world, int32_t *rank_of_group)
+{
+	if (n_groups <= 0 || !weights || !rank_of_group) return;
+	if (world < 1) world = 1;
+	std::vector<int32_t> order((size_t)n_groups);
+	for (int32_t g = 0; g < n_groups; ++g) order[(size_t)g] = g;
+	std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weights[a] != weights[b] ? weights[a] > weights[b] : a < b; });
+	std::vector<double> load((size_t)world, 0.0);
+	for (int32_t g : order) {
+		size_t k = 0;
+		for (size_t i = 1; i < (size_t)world; ++i) if (load[i] < load[k]) k = i;
+		rank_of_group[g] = (int32_t)k;
+		load[k] = load[k] + weights[g];
+	}
+}
+
+int pga_merge_match_lists(int32_t n_parts, const pga_match_t *const *matches, const int64_t *n_matches, const uint32_t *const *cigars,
+                          const int64_t *n_cigar_words, const int32_t *const *local_to_global, const int32_t *n_local_groups,
+                          pga_match_t *out_matches, uint32_t *out_cigars)
+{
+	if (n_parts < 0 || (n_parts > 0 && (!matches || !n_matches || !cigars || !n_cigar_words))) { t_err = "pga_merge_match_lists: bad arguments"; return -1; }
+	int64_t total = 0, base = 0;
+	for (int32_t r = 0; r < n_parts; ++r) total += n_matches[r];
+	std::vector<pga_match_t> all;
+	all.reserve((size_t)total);
+	for (int32_t r = 0; r < n_parts; ++r) {
+		const int32_t *l2g = local_to_global ? local_to_global[r] : nullptr;
+		for (int64_t i = 0; i < n_matches[r]; ++i) {
+			pga_match_t m = matches[r][i];
+			if (l2g) {
+				if (m.group < 0 || (n_local_groups && m.group >= n_local_groups[r])) { t_err = "pga_merge_match_lists: part " + std::to_string(r) + " holds a group id outside its table"; return -1; }
+				m.group = l2g[m.group];
+			}
+			m.cigar_off += (uint64_t)base;
+			all.push_back(m);
+		}
+		if (n_cigar_words[r] > 0) std::copy(cigars[r], cigars[r] + n_cigar_words[r], out_cigars + base);
+		base += n_cigar_words[r];
+	}
+	// a rank's records are already in (group, query, own order) order: a stable sort by (group, query) restores the single-rank order
+	std::stable_sort(all.begin(), all.end(), [](const pga_match_t &a, const pga_match_t &b) { return a.group != b.group ? a.group < b.group : a.qry < b.qry; });
+	std::copy(all.begin(), all.end(), out_matches);
+	return 0;
 }
 
 } // extern "C"

@@ -127,3 +127,47 @@ def sum_over_ranks(x: float, device: torch.device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---- the same host logic behind the C-ABI (include/pga_align.h: what a host that is not Python calls either side of its own transport) ----
+def native_merge_match_lists(parts_m: Sequence[np.ndarray], parts_c: Sequence[np.ndarray], local_to_global: Optional[Sequence[Optional[Sequence[int]]]] = None):
+    """merge_match_lists through pga_merge_match_lists"""
+    import ctypes as C
+    from .batch import lib, pga_match_t
+    d = lib()
+    d.pga_merge_match_lists.restype = C.c_int
+    n = len(parts_m)
+    ms = [np.ascontiguousarray(np.asarray(m).view(np.uint8)) for m in parts_m]
+    cs = [np.ascontiguousarray(np.asarray(c).view(np.uint8)).view(np.uint32) if len(c) else np.zeros(0, np.uint32) for c in parts_c]
+    nm = np.asarray([len(m) // MATCH_DTYPE.itemsize for m in ms], dtype=np.int64)
+    nc = np.asarray([len(c) for c in cs], dtype=np.int64)
+    mp = (C.c_void_p * max(1, n))(*[m.ctypes.data if len(m) else None for m in ms])
+    cp = (C.c_void_p * max(1, n))(*[c.ctypes.data if len(c) else None for c in cs])
+    tabs, lp, nl = [], None, None
+    if local_to_global is not None:
+        tabs = [None if t is None else np.ascontiguousarray(t, dtype=np.int32) for t in local_to_global]
+        lp = (C.c_void_p * max(1, n))(*[None if t is None or not len(t) else t.ctypes.data for t in tabs])
+        nl = np.asarray([0 if t is None else len(t) for t in tabs], dtype=np.int32)
+    out_m = np.zeros(int(nm.sum()), MATCH_DTYPE)
+    out_c = np.zeros(int(nc.sum()), np.uint32)
+    rc = d.pga_merge_match_lists(C.c_int32(n), mp, nm.ctypes.data_as(C.c_void_p), cp, nc.ctypes.data_as(C.c_void_p), lp,
+                                 None if nl is None else nl.ctypes.data_as(C.c_void_p), out_m.ctypes.data_as(C.c_void_p), out_c.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        d.pga_sched_error.restype = C.c_char_p
+        raise ValueError(d.pga_sched_error().decode())
+    return out_m, out_c
+
+
+def native_shard_groups_balanced(weights: Sequence[float], world: int) -> List[List[int]]:
+    """shard_groups_balanced through pga_shard_groups_balanced"""
+    import ctypes as C
+    from .batch import lib
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    owner = np.zeros(max(1, len(w)), dtype=np.int32)
+    d = lib()
+    d.pga_shard_groups_balanced.restype = None
+    d.pga_shard_groups_balanced(C.c_int32(len(w)), w.ctypes.data_as(C.c_void_p), C.c_int32(world), owner.ctypes.data_as(C.c_void_p))
+    out: List[List[int]] = [[] for _ in range(world)]
+    for g in range(len(w)):
+        out[int(owner[g])].append(g)
+    return out

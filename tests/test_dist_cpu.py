@@ -132,3 +132,47 @@ def test_shard_groups_balanced():
         assert all(p == sorted(p) for p in plan)
         loads = [sum(w[g] for g in p) for p in plan]
         assert max(loads) <= sum(w) / world + max(w)
+
+
+def test_native_merge_and_sharding_equal_the_python_host(product_so):
+    """pga_merge_match_lists / pga_shard_groups_balanced (include/pga_align.h: what a host that is not Python calls either side of its transport)
+    against dist.merge_match_lists / shard_groups_balanced: whole groups per rank, the queries of single groups split over ranks
+    (pga_batch_align_shard), empty parts, records that already carry global ids."""
+    import numpy as np
+    import pytest
+    from pangraph_amd import dist as pd
+    for seed in (3, 4, 5):
+        groups = _fake_wave(23, seed)
+        weights = [1 + sum(len(c) for _, _, c in g) for g in groups]
+        for world in (1, 2, 3, 8):
+            plan = pd.shard_groups_balanced(weights, world)
+            assert pd.native_shard_groups_balanced(weights, world) == plan
+            parts = [_pack(groups, ids) for ids in plan]
+            a = pd.merge_match_lists([m for m, _ in parts], [c for _, c in parts], plan)
+            b = pd.native_merge_match_lists([m.view(np.uint8) for m, _ in parts], [c.view(np.uint8) for _, c in parts], plan)
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and (world == 1 or len(a[0]) > 5)
+            want_m, want_c = _pack(groups, list(range(len(groups))))
+            assert [int(x) for x in b[0]["group"]] == [int(x) for x in want_m["group"]] and [int(x) for x in b[0]["qry"]] == [int(x) for x in want_m["qry"]]
+        # one group over all ranks: rank r holds the records of the queries q with q % world == r, global ids already in place
+        full_m, full_c = _pack(groups, list(range(len(groups))))
+        for world in (2, 3):
+            parts = []
+            for r in range(world):
+                sel = full_m[full_m["qry"] % world == r].copy()
+                pool, off = [], 0
+                for rec in sel:
+                    cg = full_c[int(rec["cigar_off"]):int(rec["cigar_off"]) + int(rec["n_cigar"])]
+                    rec["cigar_off"] = off; pool.append(cg); off += len(cg)
+                parts.append((sel, np.concatenate(pool) if pool else np.zeros(0, np.uint32)))
+            ident = [list(range(len(groups)))] * world
+            a = pd.merge_match_lists([m for m, _ in parts], [c for _, c in parts], ident)
+            b = pd.native_merge_match_lists([m for m, _ in parts], [c for _, c in parts], None)
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+            for x, y in zip(b[0], full_m):
+                assert all(x[f] == y[f] for f in ("group", "qry", "ref", "n_cigar", "matches"))
+                assert (b[1][int(x["cigar_off"]):int(x["cigar_off"]) + int(x["n_cigar"])] == full_c[int(y["cigar_off"]):int(y["cigar_off"]) + int(y["n_cigar"])]).all()
+    m, c = _pack(_fake_wave(5), [0, 1, 2, 3, 4])
+    with pytest.raises(ValueError, match="outside its table"):
+        pd.native_merge_match_lists([m], [c], [[7, 8]])
+    e = pd.native_merge_match_lists([], [], [])
+    assert len(e[0]) == 0 and len(e[1]) == 0
