@@ -277,6 +277,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)
+    # the interpreter hands its lock from a thread that does not release it to a waiting one after this many seconds (CPython's default: 5 ms); the six
+    # driving threads wait for it whenever a batch ends or starts, and the calls of the upper tree take 5-15 ms each
+    if os.environ.get("PGA_BENCH_SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["PGA_BENCH_SWITCH_INTERVAL"]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -388,6 +392,10 @@ def main():
         batch.lib().pga_mem_stats(a)
         return {"hipMalloc_calls": a[0], "hipMalloc_s": a[1] * 1e-9, "hipFree_calls": a[2], "hipFree_s": a[3] * 1e-9, "live_GB": a[4] / 2**30, "idle_in_cache_GB": a[5] / 2**30}
 
+    # who takes the schedule's decisions: the library (pga_sched_*, what a Rust host binds; the default) or schedule.ReadySet (PGA_NATIVE_SCHED=0).
+    # Same batches either way (tests/test_schedule_cpu.py); medians of six steps, ABAB on one box: 2 013 / 2 007 against 2 077 / 2 028 ms
+    native_sched = os.environ.get("PGA_NATIVE_SCHED", "1") not in ("", "0")
+
     def step_ready():
         from pangraph_amd.dist import MATCH_DTYPE, gather_blobs, merge_match_lists
         agg = {"create_s": 0.0, "align_s": 0.0, "gather_s": 0.0, "n_matches": 0, "stats": None, "per_wave": [], "batches": [], "results": []}
@@ -434,7 +442,7 @@ def main():
             res.close()
 
         if world == 1:
-            sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, on_result=on_result, express=args.express,
+            sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, on_result=on_result, express=args.express, native=native_sched,
                                 express_eps=float(os.environ.get("PGA_BENCH_EXPRESS_EPS", 0.05)), express_cap=float(os.environ.get("PGA_BENCH_EXPRESS_CAP", 60e6)))
             return agg
         # phase 1: this rank's subtrees, no communication; one gather.  Phase 2: the merges above the cut -- few, large, one after the other
@@ -443,7 +451,7 @@ def main():
         tph0 = time.perf_counter()
         mine_ids = {t.tid for t in tasks if owner[t.tid] == rank}
         if mine_ids:
-            sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=mine_ids, on_result=on_result)
+            sched.run_ready_set(tasks, run_batch, slots=args.slots, cap_bases=args.cap_gbp * 1e9, only=mine_ids, on_result=on_result, native=native_sched)
 
         def gather_all():
             t0 = time.perf_counter()
@@ -645,7 +653,7 @@ def main():
                                f"({len(waves)} waves), U = {units / 1e9:.2f} Gbp per step (asm10 -c -X -s 90)" + (" [LEAF LEVEL ONLY]" if args.leaf_only else ""),
                    "genomes": args.genomes, "genome_length": args.length, "seed": args.seed,
                    "inputs": args.inputs, "timed_region": f"per batch: {timed}; + match-list gather (N > 1)",
-                   "schedule": (f"ready set, {args.slots} batches in flight, decisions by " + ("the library (pga_sched_*)" if os.environ.get("PGA_NATIVE_SCHED", "0") not in ("", "0") else "schedule.ReadySet"))
+                   "schedule": (f"ready set, {args.slots} batches in flight, decisions by " + ("the library (pga_sched_*)" if os.environ.get("PGA_NATIVE_SCHED", "1") not in ("", "0") else "schedule.ReadySet"))
                                if args.schedule == "ready" else "level-synchronous waves",
                    "parallelism": f"{world} rank(s): subtrees per rank, no data-path collective, match-list gathers only"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
