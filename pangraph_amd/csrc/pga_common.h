@@ -166,7 +166,7 @@ struct Index {
 	DBuf<uint64_t> key;
 	DBuf<uint32_t> occ_off;             // n_keys+1
 	DBuf<uint64_t> occ;
-	DBuf<uint32_t> key_grp;             // group of every key (keys are sorted by (group, hash))
+	DBuf<uint32_t> key_grp;             // group of every key (keys are sorted by (group, hash); nothing reads the order, but the lists of a group lie together)
 };
 
 // device kernels timed with HIP events (order is part of pga_stats_t, include/pga_align.h)

@@ -107,8 +107,9 @@ __global__ void k_groups_ck(const uint64_t *__restrict__ ck, int hash_bits, cons
 	if (i == n - 1) occ_off[g + 1] = (uint32_t)n;                          // the end of the last key's list (was a 4-byte copy from the host and a wait)
 }
 
-// Sort minimizers by (group, x) keeping y ascending inside a key.  ONE stable sort over the composite key group << 2k | hash when it fits
-// 64 bits (always with pangraph's k <= 28 and fewer than 2^8 ... 2^26 groups); otherwise a stable sort on x, then one on the group id.
+// Bring the minimizers of equal (group, x) together keeping y ascending inside a key.  ONE stable sort of the composite key group << 2k | hash
+// when it fits 64 bits (always with pangraph's k <= 28 and fewer than 2^8 ... 2^26 groups); otherwise a stable
+// sort on x, then one on the group id.
 void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I, DBuf<uint32_t> &grp_of_mz, hipStream_t st)
 {
 	I.w = w, I.k = k; I.n_occ = M.n; I.n_keys = 0;
@@ -125,10 +126,18 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 			DBuf<uint64_t> ck(n), ck2(n), vy(n);
 			DBuf<uint32_t> orig(n), orig2(n);
 			hipLaunchKernelGGL(k_split_ck, dim3(nb), dim3(256), 0, st, M.mz.p, n, S.d_grp_of_seq.p, hash_bits, ck.p, vy.p, orig.p);
+			// The group digit could be left out: the sort is stable and the minimizers arrive group by group, so a sort over the hash bits alone
+			// keeps the groups apart inside a run of equal hashes -- the same lists in (hash, group) order, and the order of the KEYS is not
+			// observable (a minimizer finds its list through grp_of_mz).  PGA_INDEX_HASH_ORDER=1 does that (one digit pass of six saved; all
+			// 1998 calls of the BASELINE build keep their digests).  It is NOT the default: the step measured 11 % slower with it (medians of four
+			// steps, one box: 2 397 against 2 146 ms) -- in (group, hash) order the lists a group's queries read lie together (~2 MB per
+			// whole-genome pair: resident in an XCD's L2), in hash order they are spread over the whole array of the batch (120 MB).
+			static const bool hash_order = getenv("PGA_INDEX_HASH_ORDER") != nullptr;
+			const unsigned sort_end = (unsigned)(hash_bits + (hash_order ? 0 : gbits));
 			size_t tmp_bytes = 0;
-			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, hash_bits + gbits, st));
+			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, sort_end, st));
 			DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
-			PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, hash_bits + gbits, st));
+			PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, ck.p, ck2.p, orig.p, orig2.p, n, 0, sort_end, st));
 			DBuf<uint32_t> flag(n), gid(n);
 			hipLaunchKernelGGL(k_head_flags_ck, dim3(nb), dim3(256), 0, st, ck2.p, n, flag.p);
 			size_t tmp2 = 0;
