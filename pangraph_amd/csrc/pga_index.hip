@@ -129,9 +129,10 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 			// The group digit could be left out: the sort is stable and the minimizers arrive group by group, so a sort over the hash bits alone
 			// keeps the groups apart inside a run of equal hashes -- the same lists in (hash, group) order, and the order of the KEYS is not
 			// observable (a minimizer finds its list through grp_of_mz).  PGA_INDEX_HASH_ORDER=1 does that (one digit pass of six saved; all
-			// 1998 calls of the BASELINE build keep their digests).  It is NOT the default: the step measured 11 % slower with it (medians of four
-			// steps, one box: 2 397 against 2 146 ms) -- in (group, hash) order the lists a group's queries read lie together (~2 MB per
-			// whole-genome pair: resident in an XCD's L2), in hash order they are spread over the whole array of the batch (120 MB).
+			// 1998 calls of the BASELINE build keep their digests).  It is NOT the default: the one time it was measured the step was 11 % slower
+			// (medians of four steps, one box: 2 397 against 2 146 ms; the host's CPU time per step was 12 % higher in that run too, so the box
+			// may have been disturbed -- not measured again).  A possible mechanism: in (group, hash) order the lists a group's queries read lie
+			// together (~2 MB per whole-genome pair: resident in an XCD's L2), in hash order they are spread over the batch's whole array.
 			static const bool hash_order = getenv("PGA_INDEX_HASH_ORDER") != nullptr;
 			const unsigned sort_end = (unsigned)(hash_bits + (hash_order ? 0 : gbits));
 			size_t tmp_bytes = 0;
