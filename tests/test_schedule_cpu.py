@@ -285,3 +285,34 @@ def test_native_scheduler_from_threads_and_its_errors(product_so):
         sched_native.NativeSched([T([1]), T([0])])
     with pytest.raises(ValueError, match="bad dependency"):
         sched_native.NativeSched([T([0])])
+
+
+def test_native_scheduler_small_buffer_and_abort(product_so):
+    """pga_sched_take with a buffer that cannot hold the batch takes nothing (-1, the size needed in *ticket) and the next call with room gets the very
+    batch the first would have got; after pga_sched_abort every take returns 0."""
+    import ctypes as C
+    import numpy as np
+    from pangraph_amd import sched_native
+    tasks = sched.build_tasks(_pop(40))
+    d = sched_native.lib()
+    want = _simulate(tasks, _PyTaker(tasks, slots=2, cap_bases=1.2e9), lambda ids: 1.0)
+    assert len(want[0]) > 4                                                    # the first batch: half of the leaf calls (two free slots)
+    ns = sched_native.NativeSched(tasks)
+    ns.start(slots=2, cap_bases=1.2e9)
+    small = np.zeros(2, dtype=np.int32)
+    ticket = C.c_int32(-7)
+    assert d.pga_sched_try_take(ns.h, small.ctypes.data_as(sched_native.I32P), 2, C.byref(ticket)) == -1 and ticket.value == len(want[0])
+    assert d.pga_sched_take(ns.h, small.ctypes.data_as(sched_native.I32P), 2, C.byref(ticket)) == -1 and ticket.value == len(want[0])
+    assert ns.left() == len(tasks)
+    ids, t = ns.try_take()
+    assert ids == want[0]
+    ids2, t2 = ns.try_take()                                                   # the second slot: the rest of the ready set
+    assert ids2 == want[1] and t2 != t
+    assert ns.try_take() == ([], -1)                                           # both slots taken
+    ns.finish(t)
+    ns.finish(t)                                                               # a ticket is good for one finish
+    ns.finish(12345)
+    assert ns.left() == len(tasks) - len(ids)
+    ns.abort()
+    assert ns.take() == (None, -1) and ns.try_take() == (None, -1)
+    ns.close()
