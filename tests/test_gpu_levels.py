@@ -278,7 +278,7 @@ def test_busy_interval_log_and_stream_pool(gpu_lib):
     assert batch.busy_end()["intervals"] == 0                             # closed: nothing is logged any more
 
 
-def _run_build_ready_set(pop, tasks, slots, resident):
+def _run_build_ready_set(pop, tasks, slots, resident, native=False):
     """the benchmark's execution mode (bench.py:step_ready): the find_matches calls of the build under the ready-set schedule, `slots` batches in
     flight from `slots` host threads, inputs handed over as host strings (pga_batch_create) or derived from a resident library (pga_batch_derive)"""
     from pangraph_amd import batch
@@ -307,7 +307,7 @@ def _run_build_ready_set(pop, tasks, slots, resident):
         with lock:
             results.append((ts, m, cg, None))
 
-    log = sched.run_ready_set(tasks, run_batch, slots=slots, cap_bases=1.2e9, on_result=on_result)
+    log = sched.run_ready_set(tasks, run_batch, slots=slots, cap_bases=1.2e9, on_result=on_result, native=native)
     if lib is not None:
         lib.close()
     return results, log
@@ -318,7 +318,8 @@ def test_c5_ready_set_six_slots_every_call_vs_reference_digests(gpu_lib, residen
     """The execution mode bench.py times -- NOT level-synchronous waves: the 1998 find_matches calls of the BASELINE build (config C5) in
     dependency order (graph_merging.rs:26-69, build_run.rs:111-128: round 0 of a merge needs the last round of both children, round r needs
     round r - 1), SIX batches in flight from six host threads (own stream, own arena, shared DP lane pools), inputs as host strings and, second
-    run, device-to-device out of a resident library.  Every call against the digest the compiled reference produced for it."""
+    run, device-to-device out of a resident library.  Every call against the digest the compiled reference produced for it.  The first run takes its
+    batches from schedule.ReadySet, the second from the library's scheduler (pga_sched_*: what bench.py and a Rust host are driven by)."""
     from pangraph_amd import batch
     from pangraph_amd import digest as dg
     from pangraph_amd import schedule as sched
@@ -344,7 +345,7 @@ def test_c5_ready_set_six_slots_every_call_vs_reference_digests(gpu_lib, residen
     fd = os.open(os.path.join(out_dir, f"sixslot_stderr_{tag}.txt"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     os.dup2(fd, 2)
     try:
-        results, log = _run_build_ready_set(pop, tasks, 6, resident)
+        results, log = _run_build_ready_set(pop, tasks, 6, resident, native=resident)
     finally:
         os.dup2(saved, 2); os.close(saved); os.close(fd)
     assert max(sum(1 for a, b, _, _ in log if a <= t < b) for t, _, _, _ in log) >= 4          # batches really were in flight together
