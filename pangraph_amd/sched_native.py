@@ -89,9 +89,11 @@ class NativeSched:
 
     def start(self, slots: int = 6, cap_bases: float = 1.2e9, min_batch_bases: float = 0.0, done=None, only=None, express: int = 0,
               express_eps: float = 0.05, express_cap: float = 60e6) -> None:
-        o = _i32(sorted(only)) if only is not None else (None, None)
+        # (an empty `only` is an empty run, not "all tasks": the array handed over is never NULL then)
+        n_only = 0 if only is None else len(only)
+        o = _i32(sorted(only) or [0]) if only is not None else (None, None)
         dn = _i32(sorted(done)) if done else (None, None)
-        rc = lib().pga_sched_start(self.h, o[1], 0 if o[0] is None else len(o[0]), dn[1], 0 if dn[0] is None else len(dn[0]), int(slots), float(cap_bases),
+        rc = lib().pga_sched_start(self.h, o[1], n_only, dn[1], 0 if dn[0] is None else len(dn[0]), int(slots), float(cap_bases),
                                    float(min_batch_bases), int(express), float(express_eps), float(express_cap))
         if rc != 0:
             raise ValueError(lib().pga_sched_error().decode())

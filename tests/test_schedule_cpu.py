@@ -315,4 +315,7 @@ def test_native_scheduler_small_buffer_and_abort(product_so):
     assert ns.left() == len(tasks) - len(ids)
     ns.abort()
     assert ns.take() == (None, -1) and ns.try_take() == (None, -1)
+    ns.start(only=set())                                                       # an empty run is over at once (not "all tasks")
+    assert ns.left() == 0 and ns.take() == (None, -1)
+    assert sched.run_ready_set(tasks, lambda ts: 1 / 0, slots=2, only=set(), native=True) == []
     ns.close()
