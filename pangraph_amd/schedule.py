@@ -307,6 +307,40 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
     return sorted(log)
 
 
+# ---- the compiled host (pangraph_amd/host/build_driver.cpp): a build as a task file, its records back ------------------------------------
+def write_task_file(tasks: List[Task], path: str, sensitivity: int = 10, n_threads: int = 8) -> None:
+    """the calls of a build -- dependencies, block names, block sequences -- in the little-endian layout build_driver.cpp reads"""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"PGAB1\0\0\0" + struct.pack("<4i", len(tasks), sensitivity, n_threads, 0))
+        for t in tasks:
+            f.write(struct.pack("<i", len(t.deps)) + struct.pack(f"<{len(t.deps)}i", *t.deps) + struct.pack("<i", len(t.seqs)))
+            for a, name in zip(t.seqs, t.names):
+                nb = name.encode()
+                f.write(struct.pack("<II", len(a), len(nb)) + nb)
+                f.write(np.ascontiguousarray(a).tobytes())
+
+
+def read_driver_results(path: str):
+    """(per task: (pga_match_t records, CIGAR pool as uint32), number of batches) from build_driver's output file"""
+    import struct
+    from .dist import MATCH_DTYPE
+    buf = open(path, "rb").read()
+    if buf[:8] != b"PGAR1\0\0\0":
+        raise ValueError(f"{path} is not a result file of build_driver")
+    n, n_batches = struct.unpack_from("<2i", buf, 8)
+    pos, out = 16, []
+    for _ in range(n):
+        (nm,) = struct.unpack_from("<q", buf, pos); pos += 8
+        m = np.frombuffer(buf, dtype=MATCH_DTYPE, count=nm, offset=pos).copy(); pos += nm * MATCH_DTYPE.itemsize
+        (nc,) = struct.unpack_from("<q", buf, pos); pos += 8
+        c = np.frombuffer(buf, dtype=np.uint32, count=nc, offset=pos).copy(); pos += 4 * nc
+        out.append((m, c))
+    if pos != len(buf):
+        raise ValueError(f"{path}: {len(buf) - pos} bytes behind the last task")
+    return out, n_batches
+
+
 # ---- multi-GPU: subtrees -------------------------------------------------------------------------------------------------------------
 def partition_subtrees(pop, tasks: List[Task], world: int, per_rank: int = 4):
     """Cuts the guide tree into at least world * per_rank subtrees (splitting the heaviest one at its root until there are enough), deals

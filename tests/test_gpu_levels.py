@@ -24,6 +24,40 @@ def exp():
     return load_golden("levels_expected.json.gz")
 
 
+def test_native_build_driver_equals_the_python_host(gpu_lib, tmp_path):
+    """A whole build driven from the compiled host (pangraph_amd/host/build_driver.cpp: task file -> pga_sched_* -> six worker threads over
+    pga_batch_create / pga_batch_align -> result file; no Python in that process) gives, call by call, the records the Python host gets for the same
+    build: every field of every record and every CIGAR.  (What the records must BE is held against the reference elsewhere in this file.)
+    First in the file: the driver is a process of its own and should find the device before this process's block cache has filled it."""
+    import subprocess
+    from conftest import ROOT
+    from pangraph_amd import schedule as sched
+    exe = os.path.join(ROOT, "pangraph_amd", "host", "build_driver")
+    assert os.path.exists(exe), "built by make -C pangraph_amd/csrc"
+    pop = Population(5, 12, 150_000)
+    tasks = sched.build_tasks(pop)
+    tf, of = str(tmp_path / "tasks.bin"), str(tmp_path / "out.bin")
+    sched.write_task_file(tasks, tf, sensitivity=10, n_threads=8)
+    r = subprocess.run([exe, tf, of, "6"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got, n_batches = sched.read_driver_results(of)
+    assert len(got) == len(tasks) and n_batches >= 1
+    results, _ = _run_build_ready_set(pop, tasks, 6, False, native=True)
+    fields = [f for f in got[0][0].dtype.names if f not in ("group", "cigar_off", "pad")]
+    seen, n_rec = set(), 0
+    for ts, m, cg, _ in results:
+        for g, t in enumerate(ts):
+            mine = m[m["group"] == g]
+            dm, dc = got[t.tid]
+            assert len(mine) == len(dm), (t.tid, len(mine), len(dm))
+            assert (dm["group"] == t.tid).all()
+            for a, b in zip(mine, dm):
+                assert all(a[f] == b[f] for f in fields), (t.tid, a, b)
+                assert (cg[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] == dc[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["n_cigar"])]).all(), t.tid
+            seen.add(t.tid); n_rec += len(dm)
+    assert seen == set(range(len(tasks))) and n_rec > len(tasks)
+
+
 def test_plasmid_block_set_real_ids(gpu_lib, exp):
     names, seqs = read_fasta(os.path.join(GOLDEN, "plasmids_blocks.fa.gz"))
     assert len(names) == 137

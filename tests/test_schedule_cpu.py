@@ -319,3 +319,29 @@ def test_native_scheduler_small_buffer_and_abort(product_so):
     assert ns.left() == 0 and ns.take() == (None, -1)
     assert sched.run_ready_set(tasks, lambda ts: 1 / 0, slots=2, only=set(), native=True) == []
     ns.close()
+
+
+def test_compiled_host_loop_without_a_device(product_so, tmp_path):
+    """pangraph_amd/host/build_driver (a whole build driven from C++: task file, pga_sched_*, worker threads, result file) with PGA_DRIVER_DRY=1 -- no
+    device work, every call "finds" nothing: all calls run, the files round-trip; without the switch and without a GPU it says so (exit 3)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "pangraph_amd", "host", "build_driver")
+    assert os.path.exists(exe), "built by make -C pangraph_amd/csrc"
+    tasks = sched.build_tasks(_pop(24))
+    tf, of = str(tmp_path / "tasks.bin"), str(tmp_path / "out.bin")
+    sched.write_task_file(tasks, tf)
+    assert os.path.getsize(tf) > sum(t.bases for t in tasks)
+    r = subprocess.run([exe, tf, of, "4", "150000"], env=dict(os.environ, PGA_DRIVER_DRY="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res, n_batches = sched.read_driver_results(of)
+    assert len(res) == len(tasks) and all(len(m) == 0 and len(c) == 0 for m, c in res)
+    want = _simulate(tasks, _PyTaker(tasks, slots=1, cap_bases=150_000), lambda ids: 1.0)
+    assert n_batches >= len(want) // 4 and f"{len(tasks)} calls in {n_batches} batches" in r.stdout
+    (tmp_path / "bad.bin").write_bytes(b"PGAB1\0\0\0" + b"\xff" * 7)
+    assert subprocess.run([exe, str(tmp_path / "bad.bin"), of], capture_output=True, text=True).returncode == 2
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, tf, of], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3 and "no HIP device" in r.stderr
