@@ -1,0 +1,47 @@
+"""The sort-free index build (pangraph_amd/csrc/pga_index_buckets.h: a candidate route, PGA_INDEX_BUCKETS=1, never run on a device yet) under
+dev/emu/hip_emu.h -- the product's kernels, every workgroup as fibers on the host, against a std::map: every minimizer finds, through its key id,
+exactly the occurrence words of its (group, hash), ascending (what mm_idx_get returns: packages/minimap2-sys/minimap2/index.c:84-98,252).
+CPU-only: this checks the kernels' logic (indexing, barriers, the overflow report), not that they are fast or that hipcc's code is right."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def emu_bins(tmp_path_factory):
+    d = tmp_path_factory.mktemp("emu")
+    src = os.path.join(ROOT, "tests", "emu", "index_buckets_emu.cpp")
+    out = {}
+    for tag, extra in (("lds", []), ("global", ["-DPGA_IXB_HB=16"])):
+        exe = str(d / f"ixb_{tag}")
+        subprocess.run(["g++", "-O1", "-std=c++17", "-DPGA_EMU", "-Wall", "-Werror", "-o", exe, src] + extra, check=True, capture_output=True, text=True)
+        out[tag] = exe
+    return out
+
+
+@pytest.mark.parametrize("tag,args,expect", [
+    ("lds", ["1", "7", "3000", "2000", "0"], "keys"),                       # a few groups, one or two tiles, buckets of one group side by side
+    ("lds", ["2", "5", "120000", "90000", "0"], "keys"),                    # groups of up to 360 k minimizers: hundreds of buckets per group, a dozen tiles
+    ("lds", ["6", "40", "2500", "40", "0"], "keys"),                        # few distinct k-mers per group: long lists, buckets near their cap
+    ("lds", ["4", "6", "3000", "2000", "2500"], "keys"),                    # one k-mer 2 500 times in one group: a list of thousands inside one bucket
+    ("lds", ["5", "6", "20000", "50", "6000"], "overflow reported"),        # ... 6 000 times: the bucket cannot be sorted in LDS, the scan says so
+    ("global", ["1", "7", "3000", "2000", "0"], "keys"),                    # 16 histogram bins: tiles span more buckets than the histogram holds
+    ("global", ["7", "300", "60", "30", "0"], "keys"),                      # hundreds of small groups, empty ones among them
+])
+def test_bucket_index_under_emulation(emu_bins, tag, args, expect):
+    r = subprocess.run([emu_bins[tag]] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok:") and expect in r.stdout, r.stdout + r.stderr
+
+
+def test_emulator_reports_a_divergent_barrier(tmp_path):
+    """hip_emu.h itself: threads that leave a kernel while others of the workgroup wait at a barrier are an error, not a silent pass"""
+    src = tmp_path / "div.cpp"
+    src.write_text('#include "%s"\n__global__ void k(int *p) { if (threadIdx.x & 1) return; __syncthreads(); p[threadIdx.x] = 1; }\n'
+                   'int main() { int p[8] = {0}; emu_launch(dim3(1), dim3(8), [&] { k(p); }); return 0; }\n' % os.path.join(ROOT, "dev", "emu", "hip_emu.h"))
+    exe = str(tmp_path / "div")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, str(src)], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "wait at a barrier" in r.stderr
