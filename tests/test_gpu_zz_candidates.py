@@ -40,7 +40,8 @@ print("RESULT " + json.dumps(out))
 
 
 def _run(extra_env):
-    env = dict(os.environ, **extra_env)
+    # (the runs are processes of their own beside a pytest process whose block cache may hold most of the device by now: each keeps to a fifth of it)
+    env = dict(os.environ, PGA_MEM_SHARE="0.2", **extra_env)
     r = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
