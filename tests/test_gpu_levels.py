@@ -38,7 +38,7 @@ def test_native_build_driver_equals_the_python_host(gpu_lib, tmp_path):
     tasks = sched.build_tasks(pop)
     tf, of = str(tmp_path / "tasks.bin"), str(tmp_path / "out.bin")
     sched.write_task_file(tasks, tf, sensitivity=10, n_threads=8)
-    r = subprocess.run([exe, tf, of, "6"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, tf, of, "6"], env=dict(os.environ, PGA_MEM_SHARE="0.3"), capture_output=True, text=True, timeout=600)   # a process of its own beside this one's block cache
     assert r.returncode == 0, r.stdout + r.stderr
     got, n_batches = sched.read_driver_results(of)
     assert len(got) == len(tasks) and n_batches >= 1
