@@ -681,6 +681,11 @@ def main():
         ach = kcells / (kms * 1e-3) / 1e9
         out["roofline"].update({"bound": "valu", "achieved": ach, "peak": peak, "unit": "Gcell/s", "frac": ach / peak, "cells_per_launch": kcells / klaunch if klaunch else None,
                                 "cycles_per_cell_of_one_wave": cyc})
+        # what a DP kernel moves through HBM is its direction matrix (a byte or two per cell, written for the backtrack and read by it), not the bases its
+        # alg_bytes count: traffic per CELL says whether that is all it moves
+        tr, cpl = out["roofline"].get("traffic"), out["roofline"].get("cells_per_launch")
+        if tr and cpl:
+            out["roofline"]["traffic_bytes_per_cell"] = tr / cpl
     out["roofline"].update(profile_counts(ms_step))
     out.update(parity)
     detail = {
