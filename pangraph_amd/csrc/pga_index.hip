@@ -11,6 +11,7 @@
 #include "pga_common.h"
 #include "pga_pipeline.h"
 #include "pga_index_buckets.h"
+#include "pga_maxocc_hist.h"
 #include <rocprim/rocprim.hpp>
 
 namespace pga {
@@ -277,6 +278,20 @@ std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f,
 	if (f <= 0.) return out;
 	const uint64_t n = I.n_keys;
 	if (n == 0) { std::fill(out.begin(), out.end(), 1); return out; }
+	// candidate route (PGA_MAXOCC_HIST=1, pga_maxocc_hist.h: checked under the host emulation only): a histogram of the counts per group instead of a
+	// sort of all keys; a group whose answer is a count the histogram does not resolve sends the batch to the sort below
+	static const bool hist_route = getenv("PGA_MAXOCC_HIST") != nullptr;
+	if (hist_route && n < (1ULL << 32) && (size_t)S.n_grp * MO_BINS * sizeof(uint32_t) <= ((size_t)1 << 30)) {
+		DBuf<uint32_t> hist((size_t)S.n_grp * MO_BINS); hist.zero(st);
+		DBuf<int32_t> d_sel((size_t)S.n_grp);
+		hipLaunchKernelGGL(k_mo_hist, dim3((unsigned)((n + MO_KEYS - 1) / MO_KEYS)), dim3(MO_NT), 0, st, I.occ_off.p, I.key_grp.p, (uint32_t)n, hist.p);
+		hipLaunchKernelGGL(k_mo_select, dim3((unsigned)S.n_grp), dim3(MO_NT), 0, st, hist.p, S.n_grp, f, d_sel.p);
+		PGA_HIP(hipGetLastError());
+		std::vector<int32_t> sel = d_sel.download(st);
+		bool resolved = true;
+		for (int32_t v : sel) if (v < 0) { resolved = false; break; }
+		if (resolved) return sel;
+	}
 	DBuf<uint64_t> comp(n), comp2(n);
 	int cbits = 1; while (cbits < 32 && (I.n_occ >> cbits) != 0) ++cbits;        // counts are <= n_occ < 2^32
 	int gbits = 0; while (gbits < 32 && (1LL << gbits) < S.n_grp) ++gbits;       // groups are < n_grp

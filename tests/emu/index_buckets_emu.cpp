@@ -10,6 +10,8 @@
 #include "../../dev/emu/hip_emu.h"
 struct u128 { uint64_t x, y; };
 #include "../../pangraph_amd/csrc/pga_index_buckets.h"
+#include "../../pangraph_amd/csrc/pga_maxocc_hist.h"
+#include <algorithm>
 using namespace pga;
 
 int main(int argc, char **argv)
@@ -94,7 +96,26 @@ int main(int argc, char **argv)
 	for (uint32_t g = 0; g < n_keys; ++g) if (!key_seen[g]) { printf("FAIL: key %u belongs to no minimizer\n", g); return 1; }
 	// the lists of a group lie together: key ids (and list offsets) of a group form one range
 	for (uint32_t g = 1; g < n_keys; ++g) if (key_grp[g] < key_grp[g - 1]) { printf("FAIL: groups are not consecutive in key order at %u\n", g); return 1; }
+	// ---- mid_occ of every group from histograms (pga_maxocc_hist.h) against the sorted counts (index.c:186-207) ----
+	int n_unresolved = 0;
+	for (float f : {2e-4f, 0.05f, 0.5f}) {
+		std::vector<uint32_t> hist((size_t)n_grp * MO_BINS, 0);
+		std::vector<int32_t> got((size_t)n_grp, -7);
+		emu_launch(dim3((n_keys + MO_KEYS - 1) / MO_KEYS), dim3(MO_NT), [&] { k_mo_hist(occ_off.data(), key_grp.data(), n_keys, hist.data()); });
+		emu_launch(dim3((unsigned)n_grp), dim3(MO_NT), [&] { k_mo_select(hist.data(), n_grp, f, got.data()); });
+		std::vector<std::vector<uint32_t>> counts((size_t)n_grp);
+		for (uint32_t g = 0; g < n_keys; ++g) counts[key_grp[g]].push_back(occ_off[g + 1] - occ_off[g]);
+		for (int g = 0; g < n_grp; ++g) {
+			std::vector<uint32_t> &c = counts[(size_t)g];
+			int32_t want = 1;
+			if (!c.empty()) { std::sort(c.begin(), c.end()); want = (int32_t)(c[(uint32_t)((1. - (double)f) * (double)c.size())] + 1u); }
+			if (got[(size_t)g] == -1) { if (want - 1 < (int32_t)MO_BINS - 1) { printf("FAIL: group %d unresolved although its answer is %d\n", g, want); return 1; } ++n_unresolved; continue; }
+			if (got[(size_t)g] != want) { printf("FAIL: max_occ of group %d at f = %g: %d, reference %d\n", g, f, got[(size_t)g], want); return 1; }
+		}
+	}
 	uint32_t biggest = 0; for (uint32_t b = 0; b < nb; ++b) biggest = std::max(biggest, off[b + 1] - off[b]);
+
 	printf("ok: %u minimizers, %d groups, %u buckets (largest %u), %u keys, %u tiles\n", n, n_grp, nb, biggest, n_keys, tiles);
+	if (n_unresolved) printf("(max_occ: %d group answers beyond the histogram: the sort route)\n", n_unresolved);
 	return 0;
 }

@@ -5,7 +5,9 @@ without a device at hand, its first runs at size happen here, and a candidate th
 product.  An XPASS in the driver's record is what lets the next round switch a candidate on and measure it.
 
   PGA_INDEX_BUCKETS=1   the minimizer index without a device-wide sort (pangraph_amd/csrc/pga_index_buckets.h; logic checked under host emulation in
-                        tests/test_index_buckets_emu.py; smoke() passed with it once on an MI355X)"""
+                        tests/test_index_buckets_emu.py; smoke() passed with it once on an MI355X)
+  PGA_MAXOCC_HIST=1     mm_idx_cal_max_occ of every group from per-group histograms of the occurrence counts instead of a sort of all keys
+                        (pangraph_amd/csrc/pga_maxocc_hist.h; logic checked under host emulation in the same file; never run on a device)"""
 import json
 import os
 import subprocess
@@ -32,6 +34,9 @@ for w in (0, 1, len(waves) - 2):                       # leaf pairs (two sequenc
 groups, names = high_occ_groups()                      # k-mers that occur 520 and 4 200 times inside a group: long lists; the second overflows a bucket (sort route for that batch)
 rows = product_align_groups(groups, names, sensitivity=10)
 out["high_occ"] = [[len(r), digest(r)] for r in rows]
+import ctypes, stagebind                              # mid_occ itself (options.c:70-76 over index.c:186-207), one group at a time, through the stage tap
+dll = ctypes.CDLL(os.path.join(root, "pangraph_amd", "libpgalign.so"))
+out["mid_occ"] = [[0, stagebind.product_chain(dll, g[:80], n[:80], sensitivity=10)[1]] for g, n in zip(groups, names)]
 big = Population(4, 2, 3_000_000).build_waves()[0]     # one whole-genome-sized pair: ~600 k minimizers in one group, hundreds of buckets, dozens of tiles
 rows = product_align_groups(big[1], big[2], sensitivity=10)
 out["big pair"] = [[len(r), digest(r)] for r in rows]
@@ -48,9 +53,29 @@ def _run(extra_env):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.xfail(strict=False, reason="candidate route (off by default): first runs at size on a device; not part of any parity claim -- see the file's docstring")
+_BASE = {}
+
+
+def _base():
+    if not _BASE:
+        _BASE.update(_run({}))
+        assert sum(n for v in _BASE.values() for n, _ in v) > 100
+    return _BASE
+
+
+CANDIDATE = pytest.mark.xfail(strict=False, reason="candidate route (off by default): first runs at size on a device; not part of any parity claim -- see the file's docstring")
+
+
+@CANDIDATE
 def test_bucket_index_gives_the_records_of_the_sort_index():
-    base = _run({})
-    cand = _run({"PGA_INDEX_BUCKETS": "1"})
-    assert sum(n for v in base.values() for n, _ in v) > 100
-    assert cand == base
+    assert _run({"PGA_INDEX_BUCKETS": "1"}) == _base()
+
+
+@CANDIDATE
+def test_mid_occ_from_histograms_gives_the_records_of_the_sort():
+    assert _run({"PGA_MAXOCC_HIST": "1"}) == _base()
+
+
+@CANDIDATE
+def test_both_candidates_together():
+    assert _run({"PGA_INDEX_BUCKETS": "1", "PGA_MAXOCC_HIST": "1"}) == _base()

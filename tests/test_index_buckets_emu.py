@@ -1,4 +1,5 @@
-"""The sort-free index build (pangraph_amd/csrc/pga_index_buckets.h: a candidate route, PGA_INDEX_BUCKETS=1, never run on a device yet) under
+"""The sort-free index build (pangraph_amd/csrc/pga_index_buckets.h: a candidate route, PGA_INDEX_BUCKETS=1) and the sort-free mid_occ statistic
+(pga_maxocc_hist.h: PGA_MAXOCC_HIST=1; checked on the key table the index build produced, against the sorted counts, at three fractions) under
 dev/emu/hip_emu.h -- the product's kernels, every workgroup as fibers on the host, against a std::map: every minimizer finds, through its key id,
 exactly the occurrence words of its (group, hash), ascending (what mm_idx_get returns: packages/minimap2-sys/minimap2/index.c:84-98,252).
 CPU-only: this checks the kernels' logic (indexing, barriers, the overflow report), not that they are fast or that hipcc's code is right."""
@@ -26,7 +27,7 @@ def emu_bins(tmp_path_factory):
     ("lds", ["1", "7", "3000", "2000", "0"], "keys"),                       # a few groups, one or two tiles, buckets of one group side by side
     ("lds", ["2", "5", "120000", "90000", "0"], "keys"),                    # groups of up to 360 k minimizers: hundreds of buckets per group, a dozen tiles
     ("lds", ["6", "40", "2500", "40", "0"], "keys"),                        # few distinct k-mers per group: long lists, buckets near their cap
-    ("lds", ["4", "6", "3000", "2000", "2500"], "keys"),                    # one k-mer 2 500 times in one group: a list of thousands inside one bucket
+    ("lds", ["4", "6", "3000", "2000", "2500"], "beyond the histogram"),    # one k-mer 2 500 times in one group: a list of thousands inside one bucket; a count the mid_occ histogram does not resolve
     ("lds", ["5", "6", "20000", "50", "6000"], "overflow reported"),        # ... 6 000 times: the bucket cannot be sorted in LDS, the scan says so
     ("global", ["1", "7", "3000", "2000", "0"], "keys"),                    # 16 histogram bins: tiles span more buckets than the histogram holds
     ("global", ["7", "300", "60", "30", "0"], "keys"),                      # hundreds of small groups, empty ones among them
