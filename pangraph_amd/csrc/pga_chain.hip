@@ -18,6 +18,7 @@
 #include "pga_sort_wave.h"
 #include "pga_wave.h"
 #include "pga_pipeline.h"
+#include "pga_wg_sort.h"
 #include <rocprim/rocprim.hpp>
 #include <cstdio>
 
@@ -1153,7 +1154,11 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	// longest segments first, so that the lanes of a wave carry similar work
 	DBuf<uint32_t> neg_len(n_seg), ord0(n_seg), neg_len2(n_seg), ord(n_seg);
 	hipLaunchKernelGGL(k_seg_len, dim3((n_seg + 255) / 256), dim3(256), 0, st, seg_start.p, n_seg, n_a, neg_len.p, ord0.p);
-	{
+	// (candidate, PGA_WG_SORT=1: sorts of at most WGS_CAP pairs in one launch of one workgroup, pga_wg_sort.h -- checked under the host emulation only)
+	static const bool wg_sort = getenv("PGA_WG_SORT") != nullptr;
+	if (wg_sort && n_seg > 0 && n_seg <= WGS_CAP)
+		hipLaunchKernelGGL((k_wg_sort_pairs<uint32_t>), dim3(1), dim3(WGS_NT), 0, st, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 32);
+	else {
 		size_t tb = 0;
 		PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 0, 32, st));
 		DBuf<uint8_t> tmp(tb ? tb : 1);
@@ -1235,10 +1240,14 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 			q_tie.zero(st);
 			hipLaunchKernelGGL(k_z_keys, dim3(nba), dim3(256), 0, st, z.p, q_aoff.p, n_z.p, n_seq, n_a, key0.p, idx0.p);
 			int bits = 1; while ((1LL << bits) < n_seq) ++bits;
+			if (wg_sort && n_a <= WGS_CAP)
+				hipLaunchKernelGGL((k_wg_sort_pairs<uint64_t>), dim3(1), dim3(WGS_NT), 0, st, key0.p, key1.p, idx0.p, idx1.p, (uint32_t)n_a, 32 + bits);
+			else {
 			size_t tb = 0;
 			PGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, key0.p, key1.p, idx0.p, idx1.p, n_a, 0, 32 + bits, st));
 			DBuf<uint8_t> tmp(tb ? tb : 1);
 			PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tb, key0.p, key1.p, idx0.p, idx1.p, n_a, 0, 32 + bits, st));
+			}
 			hipLaunchKernelGGL(k_z_sorted, dim3(nba), dim3(256), 0, st, z.p, key1.p, idx1.p, n_a, q_aoff.p, n_z.p, sx.p, sy.p, q_tie.p);
 			{
 				struct Dp { const uint64_t *k; };

@@ -7,7 +7,9 @@ product.  An XPASS in the driver's record is what lets the next round switch a c
   PGA_INDEX_BUCKETS=1   the minimizer index without a device-wide sort (pangraph_amd/csrc/pga_index_buckets.h; logic checked under host emulation in
                         tests/test_index_buckets_emu.py; smoke() passed with it once on an MI355X)
   PGA_MAXOCC_HIST=1     mm_idx_cal_max_occ of every group from per-group histograms of the occurrence counts instead of a sort of all keys
-                        (pangraph_amd/csrc/pga_maxocc_hist.h; logic checked under host emulation in the same file; never run on a device)"""
+                        (pangraph_amd/csrc/pga_maxocc_hist.h; logic checked under host emulation in the same file; never run on a device)
+  PGA_WG_SORT=1         the chaining stage's sorts of at most 4 096 pairs (segment lengths, chain candidates) in one launch of one workgroup instead of
+                        rocPRIM's block sort + merge passes (pangraph_amd/csrc/pga_wg_sort.h; under emulation against std::stable_sort; never run on a device)"""
 import json
 import os
 import subprocess
@@ -77,5 +79,10 @@ def test_mid_occ_from_histograms_gives_the_records_of_the_sort():
 
 
 @CANDIDATE
-def test_both_candidates_together():
-    assert _run({"PGA_INDEX_BUCKETS": "1", "PGA_MAXOCC_HIST": "1"}) == _base()
+def test_small_sorts_of_the_chaining_stage_in_one_launch_give_the_records_of_rocprim():
+    assert _run({"PGA_WG_SORT": "1"}) == _base()
+
+
+@CANDIDATE
+def test_all_candidates_together():
+    assert _run({"PGA_INDEX_BUCKETS": "1", "PGA_MAXOCC_HIST": "1", "PGA_WG_SORT": "1"}) == _base()

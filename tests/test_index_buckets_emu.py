@@ -37,6 +37,16 @@ def test_bucket_index_under_emulation(emu_bins, tag, args, expect):
     assert r.returncode == 0 and r.stdout.startswith("ok:") and expect in r.stdout, r.stdout + r.stderr
 
 
+def test_workgroup_sort_under_emulation(tmp_path):
+    """pga_wg_sort.h (candidate, PGA_WG_SORT=1: the small sorts of the chaining stage in one launch) against std::stable_sort on the compared key
+    bits -- the order rocprim::radix_sort_pairs(..., 0, end_bit) gives: sizes around the powers of two and at the cap, 32- and 64-bit keys, few
+    distinct keys (stability), partial bit ranges."""
+    exe = str(tmp_path / "wgs")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DPGA_EMU", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "emu", "wg_sort_emu.cpp")], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
 def test_emulator_reports_a_divergent_barrier(tmp_path):
     """hip_emu.h itself: threads that leave a kernel while others of the workgroup wait at a barrier are an error, not a silent pass"""
     src = tmp_path / "div.cpp"
