@@ -118,6 +118,26 @@ static void require_device()
 		throw std::runtime_error("pga: no HIP device visible -- libpgalign.so is a gfx950 backend and has no CPU fallback");
 	const int d = g_default_dev.load();
 	if (d >= 0) { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != d) PGA_HIP(hipSetDevice(d)); }
+	// How a host thread waits for the device.  The runtime's default SPINS inside hipStreamSynchronize / hipEventSynchronize: the six threads that drive the
+	// batches in flight each held a core for the whole step -- 13.7 core-seconds per 2.0 s step, of which 7.5 were that spinning (round 6, ABAB on one box:
+	// 6.9 / 6.5 cores busy against 3.0 / 3.1 with blocking waits, the step the same within its spread, 2 005 / 2 112 against 2 010 / 2 023 ms).  A host with eight
+	// ranks on one node has two cores per rank, so the library asks for BLOCKING waits on every device it is used on, once; PGA_SYNC=spin | yield | auto
+	// leaves the choice to the host.
+	{
+		static std::mutex mu; static std::vector<int> flagged;
+		int cur = 0;
+		if (hipGetDevice(&cur) == hipSuccess) {
+			std::lock_guard<std::mutex> lk(mu);
+			if (std::find(flagged.begin(), flagged.end(), cur) == flagged.end()) {
+				flagged.push_back(cur);
+				const char *e = getenv("PGA_SYNC");
+				const unsigned f = !e || !strcmp(e, "block") ? hipDeviceScheduleBlockingSync : !strcmp(e, "yield") ? hipDeviceScheduleYield : !strcmp(e, "spin") ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
+				const hipError_t r = hipSetDeviceFlags(f);
+				if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga] device %d: hipSetDeviceFlags(%u) -> %s\n", cur, f, hipGetErrorString(r));
+				(void)hipGetLastError();
+			}
+		}
+	}
 }
 
 static void check_supported(const mm_mapopt_t &o, int k, int w)

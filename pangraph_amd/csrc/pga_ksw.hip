@@ -624,6 +624,15 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// A single extension into unrelated sequence takes 4.4 ms there against 6.3 ms on the lane kernel (the waves the band has not reached cost nothing,
 	// and no barrier paces the diagonal), 64 of them 4.8 against 6.7 ms; with more than a problem per CU in the launch the lane kernel's
 	// throughput is the same (512: 9.3 against 8.9 ms, 4 096: 72 against 65 ms): the pipeline takes the launches of at most PGA_PIPE_MAX problems.
+	// PGA_LB=check: only the lane kernel sweeps on behind the length-bound stop and compares (pga_ksw_lanes.hip); the pipeline and the wave strips would take the
+	// stop unchecked -- so in the checked mode every problem the stop applies to stays with the lane kernel, and the check covers all of them
+	const int lb_mode_now = dp_lb_mode();
+	auto lb_kept_for_check = [&](const DpJob &j) {
+		if (lb_mode_now != 2) return false;
+		int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+		if (q2 + e2 < q + e) { std::swap(q, q2); std::swap(e, e2); }
+		return lb_stop_of(j.qlen, j.tlen, j.w < 0 ? std::max(j.qlen, j.tlen) : j.w, j.flag, q, e, q2, e2, P.sc_mch, P.sc_mis, P.sc_ambi == 0 ? -e2 : P.sc_ambi, 0).on != 0;
+	};
 	static const size_t pipe_max = getenv("PGA_PIPE_MAX") ? (size_t)atoi(getenv("PGA_PIPE_MAX")) : 256;
 	// (a launch that holds so few banded problems that the wave strips take them all keeps them there: a problem spread over two dozen CUs runs
 	// its diagonal in 0.76 us, a pipeline on one CU in 1.35)
@@ -633,7 +642,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			if (c == 11 && pipe_mode() < 2) continue;
 			std::vector<uint32_t> rest;
 			for (uint32_t id : cls[c]) {
-				if (pipe_eligible(jobs[id])) { cls[13].push_back(id); cls_of[id] = 13; slab_max[13] = std::max(slab_max[13], need[id]); } else rest.push_back(id);
+				if (pipe_eligible(jobs[id]) && !lb_kept_for_check(jobs[id])) { cls[13].push_back(id); cls_of[id] = 13; slab_max[13] = std::max(slab_max[13], need[id]); } else rest.push_back(id);
 			}
 			cls[c].swap(rest);
 		}
@@ -654,7 +663,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			bool slow = false;
 			if (!(j.flag & EZ_APPROX_MAX) && (int64_t)j.qlen + j.tlen > 600 && bstrips_eligible(j, P) && stragglers.size() < 64) {      // (a target window of more than 64 bases: never covered)
 				const LbStop S = lb_stop_of(j.qlen, j.tlen, j.w < 0 ? std::max(j.qlen, j.tlen) : j.w, j.flag, q, e, q2, e2, P.sc_mch, P.sc_mis, sc_N, 0);
-				slow = !S.on || S.tail > -100;
+				slow = lb_mode_now == 2 ? !S.on : (!S.on || S.tail > -100);
 			}
 			if (slow) stragglers.push_back(id); else rest.push_back(id);
 		}
@@ -662,7 +671,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	}
 	if (allow_band && bstrips_mode() > 0) {
 		std::vector<uint32_t> elig;
-		for (int c : {10, 11}) for (uint32_t id : cls[c]) if (bstrips_eligible(jobs[id], P)) elig.push_back(id);
+		for (int c : {10, 11}) for (uint32_t id : cls[c]) if (bstrips_eligible(jobs[id], P) && !lb_kept_for_check(jobs[id])) elig.push_back(id);
 		const size_t cap = (size_t)std::max(1, bstrips_max_problems());
 		std::vector<uint32_t> take;
 		if (bstrips_mode() == 2 || elig.size() <= cap) take = elig;
@@ -778,6 +787,13 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// four streams + four scratch slabs of this device, exclusive for the call (concurrent callers do not queue behind each other): the
 	// idle set whose slabs fit the need best
 	LaneLease lanes(dev_id, lane_need);
+	// Leaves the scope BEFORE the lease does (declared after it): if anything throws between the first launch and the last collection, the launches that were
+	// not collected are still running on the pool's shared streams -- they are drained here, and their estimates taken off the pool, before the slabs go back
+	// to the idle list and the launches' device blocks to the arena.  (On the normal path every launch has been collected: si == -1, nothing to do.)
+	struct DrainUncollected {
+		std::vector<Launch> &L; int dev;
+		~DrainUncollected() { for (Launch &X : L) if (X.si >= 0) { (void)hipStreamSynchronize(X.cs); dp_stream_done(dp_stream_pool(dev), X.si, X.est); X.si = -1; } }
+	} drain_uncollected{L, dev_id};
 	hipStream_t *lane_stream = lanes.set->stream;
 	DBuf<uint8_t> *lane_slab = lanes.set->slab;
 	for (int l = 0; l < DP_NLANE; ++l) if (lane_need[l] > lane_slab[l].cap) {      // (the set is idle: its last user drained the streams)

@@ -18,7 +18,8 @@
 // 4 on MI355X, 12 and more slow every kernel down.  The runtime reads the variable when the process makes its first HIP
 // call, so the library sets the default when it is loaded -- for hosts that are not Python too (pangraph_amd/__init__.py does the same);
 // a value the host exported itself stays.
-__attribute__((constructor(101))) static void pga_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "6", 0); }
+// The variable is process-wide: every other HIP user of the host process sees it.  PGA_KEEP_RUNTIME_DEFAULTS=1 leaves the runtime alone.
+__attribute__((constructor(101))) static void pga_runtime_defaults() { if (!getenv("PGA_KEEP_RUNTIME_DEFAULTS")) setenv("GPU_MAX_HW_QUEUES", "6", 0); }
 
 namespace pga {
 

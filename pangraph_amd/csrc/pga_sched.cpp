@@ -170,9 +170,11 @@ int pga_sched_start(pga_sched_t *s, const int32_t *only, int32_t n_only, const i
 	s->want.assign(n, only ? 0 : 1); s->fin.assign(n, 0); s->indeg.assign(n, 0);
 	for (int32_t k = 0; only && k < n_only; ++k) { if (only[k] < 0 || only[k] >= s->n) { t_err = "pga_sched_start: task id out of range"; return -1; } s->want[(size_t)only[k]] = 1; }
 	for (int32_t k = 0; done && k < n_done; ++k) { if (done[k] < 0 || done[k] >= s->n) { t_err = "pga_sched_start: task id out of range"; return -1; } s->fin[(size_t)done[k]] = 1; }
+	if (slots < 1) { t_err = "pga_sched_start: slots must be at least 1 (with none pga_sched_take would wait forever)"; return -1; }
 	s->ready.clear(); s->unfinished.clear(); s->tickets.clear();
 	s->left = 0;
 	for (size_t i = 0; i < n; ++i) {
+		if (s->want[i] && s->fin[i]) s->want[i] = 0;          // a task given as done is not handed out again, whether or not `only` names it
 		if (!s->want[i]) continue;
 		++s->left;
 		for (int32_t d : s->deps[i]) {

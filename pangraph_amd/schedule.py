@@ -165,8 +165,10 @@ class ReadySet:
         self.tasks = tasks
         self.slots, self.cap_bases, self.min_batch_bases = slots, cap_bases, min_batch_bases
         self.express_eps, self.express_cap = express_eps, express_cap
-        want = set(range(len(tasks))) if only is None else set(only)
+        if slots < 1:
+            raise ValueError("slots must be at least 1")
         self.fin = set(done or ())
+        want = (set(range(len(tasks))) if only is None else set(only)) - self.fin      # a task given as done is not handed out again
         self.indeg = {}
         for tid in sorted(want):
             self.indeg[tid] = sum(1 for d in tasks[tid].deps if d not in self.fin)

@@ -103,6 +103,20 @@ def test_c3_small_every_wave(gpu_lib, exp):
         assert [dict(n=len(r), sha256=digest(r)) for r in got] == e["groups"], label
 
 
+@pytest.mark.parametrize("mode", ["check", "off"])
+def test_c3_small_every_wave_length_bound_stop_checked_and_off(gpu_lib, exp, monkeypatch, mode):
+    """The length-bound stop of end extensions (pga_dp.h) is on by default in the lane, pipeline and wave-strip kernels and ends a sweep on an analytic bound:
+    the same multi-level build against the reference-made digests (a) with PGA_LB=check -- every problem the stop applies to stays with the lane kernel, which
+    sweeps on behind the stop and fails the call if the record still changes -- and (b) with PGA_LB=off (the reference's full sweep everywhere).  Together with
+    test_c3_small_every_wave (default: the stop taken unchecked) the three routes give the same records."""
+    monkeypatch.setenv("PGA_LB", mode)
+    p = exp["c3_small"]["params"]
+    pop = Population(p["seed"], p["n"], p["length"], Rates(**p["rates"]))
+    for (label, groups, names), e in zip(pop.build_waves(), exp["c3_small"]["waves"]):
+        got = product_align_groups(groups, names, sensitivity=10)
+        assert [dict(n=len(r), sha256=digest(r)) for r in got] == e["groups"], (mode, label)
+
+
 @pytest.mark.parametrize("kw", [dict(sensitivity=5), dict(sensitivity=20), dict(sensitivity=10, kmer_length=15), dict(sensitivity=20, kmer_length=16),
                                 dict(sensitivity=5, kmer_length=17)], ids=lambda k: "asm%d%s" % (k["sensitivity"], "-k%d" % k["kmer_length"] if "kmer_length" in k else ""))
 def test_c3_small_every_wave_other_presets_live_vs_reference(gpu_lib, ref_lib, exp, kw):
