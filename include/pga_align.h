@@ -106,6 +106,10 @@ int pga_device_count(void);
 int pga_set_device(int dev);
 /* optional: create n streams ahead of time for the batch handles a host keeps in flight at once (they land on different hardware queues) */
 int pga_warm_streams(int32_t n);
+/* Gives back what the library holds of the device between calls: the idle blocks of its device-memory cache and the scratch slabs of the DP launch-lane
+ * sets no call is using at the moment (both are bought again, at hipMalloc's price, by the next calls that need them).  For a host that shares the device
+ * with another process or is done aligning for a while; hipFree synchronises the device.  Returns the bytes released. */
+int64_t pga_trim(void);
 /* the library's device-memory cache (diagnostics): out[0..5] = hipMalloc calls behind the cache, ns spent in them, hipFree calls, ns, bytes handed
  * out at the moment, bytes idle in the cache.  A host that sees hipFree calls grow from batch to batch has filled the device: the cache gives
  * the blocks that have been idle longest back, down to 4 GB below its limit (PGA_CACHE_GB, 90 % of the device), and hipFree synchronises the

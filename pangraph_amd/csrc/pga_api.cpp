@@ -663,6 +663,17 @@ extern "C" int pga_warm_streams(int32_t n)
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
+namespace pga { size_t dp_trim_lane_sets(); }
+extern "C" int64_t pga_trim(void)
+{
+	apply_default_device();
+	long long lv0[2], lv1[2]; dev_mem_levels(lv0);
+	const size_t slabs = dp_trim_lane_sets();       // (idle sets only; their slabs go to the block cache, which the next line empties)
+	dev_trim();
+	dev_mem_levels(lv1);
+	(void)slabs;
+	return (int64_t)((lv0[0] + lv0[1]) - (lv1[0] + lv1[1]));
+}
 extern "C" void pga_mem_stats(int64_t out[6])
 {
 	long long a[4], b[2]; pga::dev_mem_stats(a); pga::dev_mem_levels(b);

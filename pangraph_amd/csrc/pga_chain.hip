@@ -1154,8 +1154,9 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	// longest segments first, so that the lanes of a wave carry similar work
 	DBuf<uint32_t> neg_len(n_seg), ord0(n_seg), neg_len2(n_seg), ord(n_seg);
 	hipLaunchKernelGGL(k_seg_len, dim3((n_seg + 255) / 256), dim3(256), 0, st, seg_start.p, n_seg, n_a, neg_len.p, ord0.p);
-	// (candidate, PGA_WG_SORT=1: sorts of at most WGS_CAP pairs in one launch of one workgroup, pga_wg_sort.h -- checked under the host emulation only)
-	static const bool wg_sort = getenv("PGA_WG_SORT") != nullptr;
+	// (the default since round 6: sorts of at most WGS_CAP pairs in ONE launch of one workgroup, pga_wg_sort.h, where rocPRIM issues a block sort and up to ten
+	// merge passes of two kernels each; all 1998 calls of the BASELINE build keep their digests; PGA_WG_SORT=0: rocPRIM)
+	static const bool wg_sort = !(getenv("PGA_WG_SORT") && getenv("PGA_WG_SORT")[0] == '0');
 	if (wg_sort && n_seg > 0 && n_seg <= WGS_CAP)
 		hipLaunchKernelGGL((k_wg_sort_pairs<uint32_t>), dim3(1), dim3(WGS_NT), 0, st, neg_len.p, neg_len2.p, ord0.p, ord.p, n_seg, 32);
 	else {

@@ -10,7 +10,6 @@
 // packages/pangraph/src/align/minimap2_lib/align_with_minimap2_lib.rs:62-74).
 #include "pga_common.h"
 #include "pga_pipeline.h"
-#include "pga_index_buckets.h"
 #include "pga_maxocc_hist.h"
 #include <rocprim/rocprim.hpp>
 
@@ -109,44 +108,6 @@ __global__ void k_groups_ck(const uint64_t *__restrict__ ck, int hash_bits, cons
 	if (i == n - 1) occ_off[g + 1] = (uint32_t)n;                          // the end of the last key's list (was a 4-byte copy from the host and a wait)
 }
 
-// The index of a batch without a device-wide sort (pga_index_buckets.h: a candidate route behind PGA_INDEX_BUCKETS=1 -- its kernels are checked under
-// the host emulation only, see the status note there).  false: a bucket is too large to be sorted in LDS (or the batch does not fit the scheme); the
-// caller takes the sort route, nothing the caller reads has been written.
-static bool build_index_buckets(const SeqSet &S, const Minimizers &M, int hash_bits, Index &I, DBuf<uint32_t> &grp_of_mz, hipStream_t st)
-{
-	const uint64_t n = M.n;
-	const int n_grp = S.n_grp;
-	if (n == 0 || n >= (1ULL << 32) || S.grp_off.size() != (size_t)n_grp + 1 || M.h_seq_off.size() <= (size_t)S.grp_off.back()) return false;
-	std::vector<uint64_t> mz_begin((size_t)n_grp + 1);
-	for (int g = 0; g <= n_grp; ++g) mz_begin[(size_t)g] = M.h_seq_off[(size_t)S.grp_off[(size_t)g]];
-	if (mz_begin[(size_t)n_grp] != n) return false;
-	std::vector<IxbGroup> gt((size_t)n_grp + 1);
-	const uint32_t nb = ixb_make_table(n_grp, mz_begin.data(), hash_bits, gt.data());
-	DBuf<IxbGroup> d_gt; d_gt.upload(gt, st);
-	DBuf<uint32_t> ctr((size_t)2 * nb + 8); ctr.zero(st);                      // counts | cursors | flags of the two scans: one fill
-	uint32_t *cnt = ctr.p, *cursor = ctr.p + nb, *flags = ctr.p + 2 * (size_t)nb, *flags2 = flags + 4;
-	DBuf<uint32_t> off((size_t)nb + 1), nk(nb), kbase((size_t)nb + 1), so(n), orig2(n);
-	DBuf<uint64_t> sck(n), sy(n), ck2(n);
-	const unsigned tiles = (unsigned)((n + IXB_TILE - 1) / IXB_TILE);
-	hipLaunchKernelGGL(k_ixb_count, dim3(tiles), dim3(IXB_NT), 0, st, M.mz.p, (uint32_t)n, S.d_grp_of_seq.p, d_gt.p, hash_bits, cnt);
-	hipLaunchKernelGGL(k_ixb_scan, dim3(1), dim3(1024), 0, st, cnt, nb, off.p, IXB_CAP, flags);
-	hipLaunchKernelGGL(k_ixb_scatter, dim3(tiles), dim3(IXB_NT), 0, st, M.mz.p, (uint32_t)n, S.d_grp_of_seq.p, d_gt.p, hash_bits, off.p, cursor, sck.p, sy.p, so.p);
-	hipLaunchKernelGGL(k_ixb_sort, dim3(nb), dim3(IXB_NT), 0, st, off.p, sck.p, sy.p, so.p, ck2.p, orig2.p, I.occ.p, nk.p);
-	hipLaunchKernelGGL(k_ixb_scan, dim3(1), dim3(1024), 0, st, nk.p, nb, kbase.p, 0xffffffffu, flags2);
-	uint32_t h_flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	PGA_HIP(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
-	if (h_flags[0] > IXB_CAP || h_flags[1] != (uint32_t)n) return false;
-	const uint32_t n_keys = h_flags[5];
-	I.n_keys = n_keys;
-	I.key.alloc(n_keys);
-	I.occ_off.alloc((size_t)n_keys + 1);
-	I.key_grp.alloc(n_keys);
-	hipLaunchKernelGGL(k_ixb_groups, dim3(nb), dim3(IXB_NT), 0, st, off.p, kbase.p, ck2.p, orig2.p, hash_bits, (uint32_t)n, n_keys, I.key.p, I.occ_off.p, I.key_grp.p, grp_of_mz.p);
-	PGA_HIP(hipGetLastError());
-	return true;
-}
-
 // Bring the minimizers of equal (group, x) together keeping y ascending inside a key.  ONE stable sort of the composite key group << 2k | hash
 // when it fits 64 bits (always with pangraph's k <= 28 and fewer than 2^8 ... 2^26 groups); otherwise a stable
 // sort on x, then one on the group id.
@@ -163,8 +124,6 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 		int gbits = 0; while ((1LL << gbits) < S.n_grp) ++gbits;
 		const int hash_bits = std::min(64, 2 * k);
 		if (hash_bits + gbits <= 64 && !getenv("PGA_INDEX_TWO_SORTS")) {
-			static const bool buckets = getenv("PGA_INDEX_BUCKETS") != nullptr;
-			if (buckets && build_index_buckets(S, M, hash_bits, I, grp_of_mz, st)) return;
 			DBuf<uint64_t> ck(n), ck2(n), vy(n);
 			DBuf<uint32_t> orig(n), orig2(n);
 			hipLaunchKernelGGL(k_split_ck, dim3(nb), dim3(256), 0, st, M.mz.p, n, S.d_grp_of_seq.p, hash_bits, ck.p, vy.p, orig.p);
@@ -278,9 +237,10 @@ std::vector<int32_t> index_cal_max_occ(const SeqSet &S, const Index &I, float f,
 	if (f <= 0.) return out;
 	const uint64_t n = I.n_keys;
 	if (n == 0) { std::fill(out.begin(), out.end(), 1); return out; }
-	// candidate route (PGA_MAXOCC_HIST=1, pga_maxocc_hist.h: checked under the host emulation only): a histogram of the counts per group instead of a
-	// sort of all keys; a group whose answer is a count the histogram does not resolve sends the batch to the sort below
-	static const bool hist_route = getenv("PGA_MAXOCC_HIST") != nullptr;
+	// The default since round 6 (pga_maxocc_hist.h): a histogram of the counts per group instead of a sort of all keys -- one fill and two launches for the
+	// ~14 dispatches of the key sort; a group whose answer is a count the histogram does not resolve (1 023 or more) sends the batch to the sort below.
+	// All 1998 calls of the BASELINE build keep their digests (mid_occ itself is compared in tests/test_gpu_zz_candidates.py); PGA_MAXOCC_HIST=0: the sort.
+	static const bool hist_route = !(getenv("PGA_MAXOCC_HIST") && getenv("PGA_MAXOCC_HIST")[0] == '0');
 	if (hist_route && n < (1ULL << 32) && (size_t)S.n_grp * MO_BINS * sizeof(uint32_t) <= ((size_t)1 << 30)) {
 		DBuf<uint32_t> hist((size_t)S.n_grp * MO_BINS); hist.zero(st);
 		DBuf<int32_t> d_sel((size_t)S.n_grp);

@@ -535,6 +535,15 @@ struct LaneLease {
 	LaneLease(const LaneLease&) = delete; LaneLease &operator=(const LaneLease&) = delete;
 };
 
+// pga_trim(): the slabs of the sets no call holds at the moment go back to the block cache (an idle set's last user drained its launches)
+size_t dp_trim_lane_sets()
+{
+	std::lock_guard<std::mutex> lk(g_lane_mu);
+	size_t bytes = 0;
+	for (LaneSet *s : g_lane_idle) for (int l = 0; l < DP_NLANE; ++l) { bytes += s->slab[l].cap; g_slab_total -= s->slab[l].cap; s->slab[l].release(); }
+	return bytes;
+}
+
 int dp_lb_mode() { const char *e = getenv("PGA_LB"); return !e ? 0 : !strcmp(e, "off") || !strcmp(e, "0") ? 1 : !strcmp(e, "check") ? 2 : 0; }
 
 void dp_run(PkBases d_bases, const std::vector<DpJob> &jobs, const DpParams &P, std::vector<DpRes> &res, PinVec<uint32_t> &cigars, hipStream_t st, Timers *tm)

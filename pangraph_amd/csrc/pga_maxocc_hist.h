@@ -1,4 +1,4 @@
-// pga_maxocc_hist.h -- mm_idx_cal_max_occ of every group of a batch WITHOUT a sort (candidate route: PGA_MAXOCC_HIST=1, see the status note).
+// pga_maxocc_hist.h -- mm_idx_cal_max_occ of every group of a batch WITHOUT a sort (the default since round 6; PGA_MAXOCC_HIST=0: the sort of all keys).
 //
 // mm_idx_cal_max_occ (packages/minimap2-sys/minimap2/index.c:186-207) is an order statistic: of the occurrence counts of a group's n distinct
 // minimizers, the (uint32)((1 - f) * n)-th smallest, plus one -- with f = 2e-4 one of the few largest counts.  The sort route
@@ -10,9 +10,9 @@
 //                 the LAST bin collects every count >= MO_BINS - 1: if the answer lies there the group reports -1 and the caller takes the sort route.
 // One fill + two launches.
 //
-// STATUS: as pga_index_buckets.h -- written in round 5 without a device, checked under dev/emu/hip_emu.h (tests/test_index_buckets_emu.py: against the
-// sorted counts at three fractions), held against the sort route on the device by tests/test_gpu_zz_candidates.py (tolerant), never run on an MI355X
-// before that, not reachable unless PGA_MAXOCC_HIST=1 is set, no claim rests on it.
+// STATUS: written in round 5 without a device and checked under dev/emu/hip_emu.h against the sorted counts at three fractions (tests/test_routes_emu.py);
+// round 6: on the device every one of the 1998 calls of the BASELINE build keeps its digest with it, tests/test_gpu_zz_candidates.py compares mid_occ itself
+// against the sort route; alone it leaves a build step where it was (2 078 against 2 073 / 2 078 ms) and takes ~2.7 k dispatches out of it.
 #pragma once
 #ifndef PGA_EMU
 #include "pga_common.h"
