@@ -939,7 +939,7 @@ struct RoundRunner {
 				set_thread_budget(1);
 				ss = stream_lease();
 				dp_run(bases, A.jb, Pc, A.rs, A.cg, ss, keep_tm ? &A.tm : nullptr);
-				PGA_HIP(hipStreamSynchronize(ss));
+				PGA_HIP(sync_stream(ss));
 			} catch (std::exception &e) { A.err = e.what(); if (A.err.empty()) A.err = "unknown error"; }
 			if (ss) stream_release(ss);
 			if (arena >= 0) dev_release_arena(arena);

@@ -101,7 +101,7 @@ struct PgaIdx {
 	hipStream_t st = 0;              // the part's own (non-blocking) stream
 	int arena = 0;                   // device-memory arena of the index, leased for its lifetime (pga_mem.cpp)
 	PgaIdx() : arena(dev_lease_arena()) {}
-	~PgaIdx() { if (st) { (void)hipStreamSynchronize(st); } release_buffers(); if (st) stream_release(st); dev_release_arena(arena); }
+	~PgaIdx() { if (st) { (void)sync_stream(st); } release_buffers(); if (st) stream_release(st); dev_release_arena(arena); }
 	void release_buffers() { S.d_pk2.release(); S.d_nmask.release(); S.d_off.release(); S.d_len.release(); S.d_grp_of_seq.release(); S.d_grp_base.release(); M.mz.release(); M.seq_off.release();
 		I.key.release(); I.occ_off.release(); I.occ.release(); I.key_grp.release(); grp.release(); d_name_rank.release(); d_mid_occ.release(); }
 };
@@ -211,7 +211,7 @@ static PgaIdx *idx_build(int w, int k, int n, const char *const *seq, const uint
 	ix->d_name_rank.upload(rank, ix->st);
 	ix->hdr.b = 14 < 2 * k ? 14 : 2 * k, ix->hdr.w = w, ix->hdr.k = k, ix->hdr.flag = name ? 0 : MM_I_NO_NAME;
 	ix->hdr.n_seq = (uint32_t)n; ix->hdr.seq = ix->seq_hdr.data();
-	PGA_HIP(hipStreamSynchronize(ix->st));
+	PGA_HIP(sync_stream(ix->st));
 	ix->tm.upload = now_s() - t0;
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   process cpu: hand-over %.2f ms\n", (cpu_s() - c0) * 1e3);
 	if (getenv("PGA_VERBOSE")) fprintf(stderr, "[pga]   hand-over: sequences %.2f ms, names and ranks %.2f ms\n", (t_up - t0) * 1e3, (now_s() - t_up) * 1e3);
@@ -663,7 +663,7 @@ extern "C" int pga_warm_streams(int32_t n)
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }
 extern "C" int pga_stats_version(void) { return PGA_STATS_VERSION; }
-namespace pga { size_t dp_trim_lane_sets(); }
+namespace pga { size_t dp_trim_lane_sets(); void dp_lane_dump(); }
 extern "C" int64_t pga_trim(void)
 {
 	apply_default_device();
@@ -676,6 +676,7 @@ extern "C" int64_t pga_trim(void)
 }
 extern "C" void pga_mem_stats(int64_t out[6])
 {
+	if (getenv("PGA_MEM_DUMP")) { dev_mem_dump(); dp_lane_dump(); }
 	long long a[4], b[2]; pga::dev_mem_stats(a); pga::dev_mem_levels(b);
 	for (int i = 0; i < 4; ++i) out[i] = a[i];
 	out[4] = b[0], out[5] = b[1];
@@ -701,7 +702,7 @@ extern "C" int pga_busy_begin(void)
 	apply_default_device();
 	std::lock_guard<std::mutex> lk(pga::g_busy.mu);
 	if (pga::g_busy.ref) { (void)hipEventDestroy(pga::g_busy.ref); pga::g_busy.ref = nullptr; }
-	if (hipEventCreate(&pga::g_busy.ref) != hipSuccess || hipEventRecord(pga::g_busy.ref, nullptr) != hipSuccess || hipEventSynchronize(pga::g_busy.ref) != hipSuccess) { set_err("pga_busy_begin: no reference event"); return -1; }
+	if (hipEventCreate(&pga::g_busy.ref) != hipSuccess || hipEventRecord(pga::g_busy.ref, nullptr) != hipSuccess || sync_event(pga::g_busy.ref) != hipSuccess) { set_err("pga_busy_begin: no reference event"); return -1; }
 	pga::g_busy.iv.clear(); pga::g_busy.open = true;
 	return 0;
 }
@@ -936,7 +937,7 @@ extern "C" int pga_stage_sort(int32_t n_seg, const uint64_t *seg_off, uint64_t *
 		DBuf<int64_t> dl; dl.upload(len, 0);
 		DBuf<uint32_t> df; df.upload(flag, 0);
 		replay_sort_segments(a.p, n, off.p, dl.p, n_seg, df.p, 0);
-		if (n) { PGA_HIP(hipMemcpyAsync(xy, a.p, n * sizeof(u128), hipMemcpyDeviceToHost, 0)); PGA_HIP(hipStreamSynchronize(0)); }
+		if (n) { PGA_HIP(hipMemcpyAsync(xy, a.p, n * sizeof(u128), hipMemcpyDeviceToHost, 0)); PGA_HIP(sync_stream(0)); }
 		return 0;
 	} catch (std::exception &e) { set_err(e.what()); return -1; }
 }

@@ -1124,7 +1124,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	const bool vmarks = getenv("PGA_VERBOSE") != nullptr;
 	auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double t_mark = vmarks ? wall() : 0.0; std::string marks;
-	auto mark = [&](const char *what) { if (!vmarks) return; (void)hipStreamSynchronize(st); const double t = wall(); char b[96]; snprintf(b, sizeof b, " %s %.1f", what, (t - t_mark) * 1e3); marks += b; t_mark = t; };
+	auto mark = [&](const char *what) { if (!vmarks) return; (void)sync_stream(st); const double t = wall(); char b[96]; snprintf(b, sizeof b, " %s %.1f", what, (t - t_mark) * 1e3); marks += b; t_mark = t; };
 	// segments
 	DBuf<uint32_t> flag(n_a + 1); flag.zero(st);
 	hipLaunchKernelGGL(k_mark_query_starts, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, st, q_aoff.p, n_seq, n_a, flag.p);
@@ -1139,7 +1139,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 	}
 	uint64_t n_seg64 = 0;
 	PGA_HIP(hipMemcpyAsync(&n_seg64, pos.p + n_a, 8, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	const uint32_t n_seg = (uint32_t)n_seg64;
 	DBuf<uint64_t> seg_start(n_seg);
 	hipLaunchKernelGGL(k_seg_starts, dim3(nba), dim3(256), 0, st, flag.p, pos.p, n_a, seg_start.p);
@@ -1261,7 +1261,7 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 			}
 			hipLaunchKernelGGL(k_z_take_sorted, dim3(nba), dim3(256), 0, st, z.p, sx.p, sy.p, q_aoff.p, n_z.p, n_seq, spec ? (const uint32_t*)nullptr : q_tie.p, n_a);
 			const RsHint hint{sx.p, sy.p, dupc.p};
-			if (!spec) { replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint); PGA_HIP(hipStreamSynchronize(st)); }
+			if (!spec) { replay_sort_segments(z.p, n_a, q_aoff.p, n_z.p, n_seq, q_tie.p, st, tm, &hint); PGA_HIP(sync_stream(st)); }
 			// (the buffers of this scope go back to the call's arena: whoever takes them next is queued behind these kernels on the same stream)
 		}
 		et2.mark();
@@ -1377,7 +1377,7 @@ void chain_all(const SeqSet &S, SeedResult &SR, const mm_mapopt_t &opt, int k, C
 		if (O.want_host_anchors) memcpy(O.a.data() + src[(size_t)i], R.a.data() + dst[(size_t)i], n * sizeof(u128));
 		PGA_HIP(hipMemcpyAsync(O.d_a.p + src[(size_t)i], R.d_a.p + dst[(size_t)i], n * sizeof(u128), hipMemcpyDeviceToDevice, st));
 	}
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	if (verbose) fprintf(stderr, "[pga]   chain: the reference's procedure for those %d queries (%llu anchors): %.1f ms\n", n_sub, (unsigned long long)n_sub_a,
 	                     (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3);
 }

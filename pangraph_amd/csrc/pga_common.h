@@ -20,10 +20,19 @@
 
 namespace pga {
 
+// ---- waiting for the device (pga_mem.cpp) ----
+// The library asks the runtime for BLOCKING waits (pga_api.cpp: require_device): a thread that waits holds no core.  A blocked thread comes back ~100 us
+// after its kernel has ended, though, and a call of the upper tree waits two dozen times for kernels of a few microseconds: these two first POLL the stream /
+// event for a bounded time (PGA_SPIN_US, default 60 us; 0: never) and block only when the work outlasts it -- the short waits cost what they cost under the
+// runtime's spinning default, the long ones no core.
+hipError_t sync_stream(hipStream_t s);
+hipError_t sync_event(hipEvent_t e);
+
 // ---- device memory: cached blocks (pga_mem.cpp) ----
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_trim();        // release every idle block
+void dev_mem_dump();    // diagnostics to stderr: live and idle bytes per arena
 void dev_mem_levels(long long out[2]);   // bytes handed out, bytes idle in the cache
 void dev_mem_stats(long long out[4]);   // hipMalloc calls, ns spent in them, hipFree calls, ns (since the library was loaded)
 void dev_set_arena(int arena);
@@ -55,7 +64,7 @@ template <class T> struct DBuf {
 	void upload(const std::vector<T> &h, hipStream_t s = 0) { upload(h.data(), h.size(), s); }
 	std::vector<T> download(hipStream_t s = 0) const {
 		std::vector<T> h(n);
-		if (n) { PGA_HIP(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(hipStreamSynchronize(s)); }
+		if (n) { PGA_HIP(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(sync_stream(s)); }
 		return h;
 	}
 };
@@ -85,7 +94,7 @@ template <class T> struct PinVec {          // the small subset of std::vector t
 template <class T> static inline void download_to(PinVec<T> &h, const T *d, size_t n, hipStream_t s)
 {
 	h.resize(n);
-	if (n) { PGA_HIP(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(hipStreamSynchronize(s)); }
+	if (n) { PGA_HIP(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, s)); PGA_HIP(sync_stream(s)); }
 }
 
 // several device arrays to the host behind ONE synchronisation (each DBuf::download() pays a copy and a synchronisation of its own)
@@ -102,7 +111,7 @@ struct Downloads {
 		PGA_HIP(hipMemcpyAsync(it.pin, src, it.bytes, hipMemcpyDeviceToHost, st));
 		items.push_back(it);
 	}
-	void wait() { if (!items.empty()) PGA_HIP(hipStreamSynchronize(st)); for (Item &it : items) { memcpy(it.dst, it.pin, it.bytes); pin_free(it.pin); } items.clear(); }
+	void wait() { if (!items.empty()) PGA_HIP(sync_stream(st)); for (Item &it : items) { memcpy(it.dst, it.pin, it.bytes); pin_free(it.pin); } items.clear(); }
 	~Downloads() { for (Item &it : items) pin_free(it.pin); }
 };
 
@@ -191,7 +200,7 @@ struct EventTimer {
 	hipEvent_t a, b; hipStream_t st; bool marked = false;
 	explicit EventTimer(hipStream_t s) : st(s) { PGA_HIP(hipEventCreate(&a)); PGA_HIP(hipEventCreate(&b)); PGA_HIP(hipEventRecord(a, st)); }
 	void mark() { if (!marked) { PGA_HIP(hipEventRecord(b, st)); marked = true; } }
-	double finish(int kern = -1) { float ms = 0; mark(); PGA_HIP(hipEventSynchronize(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); if (kern >= 0) busy_note(kern, a, b); return ms; }
+	double finish(int kern = -1) { float ms = 0; mark(); PGA_HIP(sync_event(b)); PGA_HIP(hipEventElapsedTime(&ms, a, b)); if (kern >= 0) busy_note(kern, a, b); return ms; }
 	double stop(int kern = -1) { mark(); return finish(kern); }
 	~EventTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 };

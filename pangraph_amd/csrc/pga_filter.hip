@@ -217,17 +217,17 @@ void filter_matches_dev(int64_t n_in, const pga_match_t *h_m, const uint32_t *h_
 		uint32_t tot[2];
 		PGA_HIP(hipMemcpyAsync(&tot[0], orr.p + n_in, 4, hipMemcpyDeviceToHost, st));
 		PGA_HIP(hipMemcpyAsync(&tot[1], oo.p + n_in, 4, hipMemcpyDeviceToHost, st));
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		m1.alloc((size_t)tot[0] + 1); c1.alloc((size_t)tot[1] + 1);
 		hipLaunchKernelGGL(k_split<true>, dim3(nb), dim3(128), 0, st, m0.p, c0.p, n_in, fp.thr, (uint32_t*)nullptr, (uint32_t*)nullptr, orr.p, oo.p, m1.p, c1.p, bad.p);
 		PGA_HIP(hipGetLastError());
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		m = m1.p; cig = c1.p; n = tot[0];
 		if (!(fp.flags & 2)) {
 			out_m.resize(n); out_cig.resize(tot[1]);
 			if (n) PGA_HIP(hipMemcpyAsync(out_m.data(), m1.p, (size_t)n * sizeof(pga_match_t), hipMemcpyDeviceToHost, st));
 			if (tot[1]) PGA_HIP(hipMemcpyAsync(out_cig.data(), c1.p, (size_t)tot[1] * 4, hipMemcpyDeviceToHost, st));
-			PGA_HIP(hipStreamSynchronize(st));
+			PGA_HIP(sync_stream(st));
 			return;
 		}
 	} else if (!(fp.flags & 2)) {
@@ -251,7 +251,7 @@ void filter_matches_dev(int64_t n_in, const pga_match_t *h_m, const uint32_t *h_
 	{ DBuf<uint8_t> tmp(tb + 16); PGA_HIP(rocprim::inclusive_scan(tmp.p, tb, head.p, rank.p, n, rocprim::plus<uint32_t>(), st)); }
 	uint32_t n_grp = 0;
 	PGA_HIP(hipMemcpyAsync(&n_grp, rank.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	DBuf<uint32_t> seg((size_t)n_grp + 1), accepted(n), aops((size_t)n + 1), rex((size_t)n + 1), oex((size_t)n + 1);
 	hipLaunchKernelGGL(k_seg_starts, dim3(nb), dim3(256), 0, st, head.p, rank.p, n, seg.p);
 	DBuf<int4> acc(2 * (size_t)n + 2);
@@ -266,14 +266,14 @@ void filter_matches_dev(int64_t n_in, const pga_match_t *h_m, const uint32_t *h_
 	uint32_t tot[2];
 	PGA_HIP(hipMemcpyAsync(&tot[0], rex.p + n, 4, hipMemcpyDeviceToHost, st));
 	PGA_HIP(hipMemcpyAsync(&tot[1], oex.p + n, 4, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	DBuf<pga_match_t> fm((size_t)tot[0] + 1); DBuf<uint32_t> fc((size_t)tot[1] + 1);
 	hipLaunchKernelGGL(k_compact, dim3(n), dim3(64), 0, st, m, cig, ord.p, accepted.p, rex.p, oex.p, n, fm.p, fc.p);
 	PGA_HIP(hipGetLastError());
 	out_m.resize(tot[0]); out_cig.resize(tot[1]);
 	if (tot[0]) PGA_HIP(hipMemcpyAsync(out_m.data(), fm.p, (size_t)tot[0] * sizeof(pga_match_t), hipMemcpyDeviceToHost, st));
 	if (tot[1]) PGA_HIP(hipMemcpyAsync(out_cig.data(), fc.p, (size_t)tot[1] * 4, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 } // namespace pga

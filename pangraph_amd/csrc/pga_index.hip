@@ -148,7 +148,7 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 			PGA_HIP(rocprim::inclusive_scan(tmpb.p, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
 			uint32_t n_keys = 0;
 			PGA_HIP(hipMemcpyAsync(&n_keys, gid.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-			PGA_HIP(hipStreamSynchronize(st));
+			PGA_HIP(sync_stream(st));
 			I.n_keys = n_keys;
 			I.key.alloc(n_keys);
 			I.occ_off.alloc((size_t)n_keys + 1);
@@ -182,7 +182,7 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 		PGA_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, gk0.p, gk.p, idx0.p, idx1.p, n, 0, bits, st));
 		hipLaunchKernelGGL(k_apply_perm, dim3(nb), dim3(256), 0, st, kx2.p, orig2.p, idx1.p, n, kx.p, orig.p);
 		kxs = kx.p, origs = orig.p, gks = gk.p;
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 	}
 	{   // occ[i] = y of the i-th sorted minimizer
 		auto gather = rocprim::make_transform_iterator(origs, [vyp = vy.p] __device__ (uint32_t o) { return vyp[o]; });
@@ -196,7 +196,7 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 	PGA_HIP(rocprim::inclusive_scan(tmpb.p, tmp2, flag.p, gid.p, n, rocprim::plus<uint32_t>(), st));
 	uint32_t n_keys = 0;
 	PGA_HIP(hipMemcpyAsync(&n_keys, gid.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	I.n_keys = n_keys;
 	I.key.alloc(n_keys);
 	I.occ_off.alloc((size_t)n_keys + 1);
@@ -205,7 +205,7 @@ void build_index_ex(const SeqSet &S, const Minimizers &M, int w, int k, Index &I
 	uint32_t n32 = (uint32_t)n;
 	PGA_HIP(hipMemcpyAsync(I.occ_off.p + n_keys, &n32, 4, hipMemcpyHostToDevice, st));
 	PGA_HIP(hipGetLastError());
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 // comp = group << cbits | occurrence count: a count never exceeds the number of indexed minimizers, so cbits = bit length of n_occ holds it

@@ -524,7 +524,7 @@ struct LaneLease {
 	}
 	~LaneLease()
 	{
-		for (int l = 0; l < DP_NLANE; ++l) if (set->stream[l]) (void)hipStreamSynchronize(set->stream[l]);
+		for (int l = 0; l < DP_NLANE; ++l) if (set->stream[l]) (void)sync_stream(set->stream[l]);
 		// the slabs stay with the set as long as all sets together hold a reasonable share of the device; beyond that this set gives its
 		// slabs back (to the block cache, which may drop them)
 		static const size_t keep = (size_t)(getenv("PGA_SLAB_KEEP_GB") ? atof(getenv("PGA_SLAB_KEEP_GB")) : 96.0) << 30;
@@ -535,6 +535,15 @@ struct LaneLease {
 	LaneLease(const LaneLease&) = delete; LaneLease &operator=(const LaneLease&) = delete;
 };
 
+void dp_lane_dump()
+{
+	std::lock_guard<std::mutex> lk(g_lane_mu);
+	for (LaneSet *s : g_lane_idle) {
+		fprintf(stderr, "[pga]   idle lane set (arena %d): slabs MB", s->arena);
+		for (int l = 0; l < DP_NLANE; ++l) fprintf(stderr, " %zu", s->slab[l].cap >> 20);
+		fprintf(stderr, "\n");
+	}
+}
 // pga_trim(): the slabs of the sets no call holds at the moment go back to the block cache (an idle set's last user drained its launches)
 size_t dp_trim_lane_sets()
 {
@@ -715,7 +724,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	DBuf<uint32_t> d_pool((size_t)cig_total + 1);
 	// the CIGAR pool's cursor and every class's queue counters in one block, zeroed once (a memset dispatch per class before)
 	DBuf<unsigned long long> d_cursor(1 + DP_NCLASS); d_cursor.zero(st);
-	PGA_HIP(hipStreamSynchronize(st));                      // the only use of the caller's stream: everything below is ordered inside the lane streams
+	PGA_HIP(sync_stream(st));                      // the only use of the caller's stream: everything below is ordered inside the lane streams
 	// The classes are independent persistent launches: each gets its own stream, so the handful of huge problems
 	// (one workgroup each, latency-bound) run beside the millions of small tiles instead of after them.
 	// (four streams, not one per class: HIP multiplexes streams onto a handful of hardware queues, and two classes that
@@ -782,7 +791,12 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			const size_t chunk = lanes_chunk_bytes(c == 11 ? 64 : 256);
 			for (uint32_t id : cls[c]) { q_cap = std::max(q_cap, jobs[id].qlen); t_cap = std::max(t_cap, jobs[id].tlen); tot += need[id] + chunk; }
 			const size_t cigb = n_waves * lanes_cig_bytes(q_cap, t_cap);
-			size_t pool = std::min(tot, std::max(budget / 2, 4 * n_waves * chunk));
+			// (round 6: a workgroup holds its first two chunks and asks one ahead; the bulk rounds of the BASELINE build -- 2 400 ... 3 150 extensions on 512
+			// workgroups -- take 1 360 ... 1 614 chunks, and the pool used to be budget / 2 = 12 GB, which the block cache rounds to 16 GB per lane set: 96 GB
+			// of the device held by six sets.  A quarter of the budget, CIGAR buffers included, so that the slab lands on a size class of the cache: 6 GB =
+			// 3 000 chunks, twice what was seen; a dry pool still hands problems back)
+			const size_t want = std::max(budget / 4, 5 * n_waves * chunk);
+			size_t pool = std::min(tot, want > cigb + 256 + 2 * n_waves * chunk ? want - cigb - 256 : want);
 			pool = std::max(pool, 2 * n_waves * chunk) / chunk * chunk;
 			lanes_pool_chunks[c - 10] = (uint32_t)(pool / chunk) | (pool >= tot ? 0x80000000u : 0u);   // (top bit: the pool covers every problem in full: no reservation tiers)
 			waves_of[c] = n_waves;
@@ -801,7 +815,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	// to the idle list and the launches' device blocks to the arena.  (On the normal path every launch has been collected: si == -1, nothing to do.)
 	struct DrainUncollected {
 		std::vector<Launch> &L; int dev;
-		~DrainUncollected() { for (Launch &X : L) if (X.si >= 0) { (void)hipStreamSynchronize(X.cs); dp_stream_done(dp_stream_pool(dev), X.si, X.est); X.si = -1; } }
+		~DrainUncollected() { for (Launch &X : L) if (X.si >= 0) { (void)sync_stream(X.cs); dp_stream_done(dp_stream_pool(dev), X.si, X.est); X.si = -1; } }
 	} drain_uncollected{L, dev_id};
 	hipStream_t *lane_stream = lanes.set->stream;
 	DBuf<uint8_t> *lane_slab = lanes.set->slab;
@@ -941,7 +955,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	for (Launch &X : L) {
 		const int c = X.c;
 		std::vector<uint32_t> &ids = *X.ids;
-		PGA_HIP(hipEventSynchronize(X.e1));
+		PGA_HIP(sync_event(X.e1));
 		float msf = 0, ms_off = 0; PGA_HIP(hipEventElapsedTime(&msf, X.e0, X.e1)); (void)hipEventElapsedTime(&ms_off, ready, X.e0);
 		const double ms = msf;
 		busy_note(c == 6 ? K_LL : c == 8 ? K_BAND : (c == 9 || c == 12) ? K_STRIPS : (c == 10 || c == 11) ? K_LANES : c == 13 ? K_PIPE : c <= 1 ? K_EXTD2 : X.nt >= 1024 ? K_WIDE1024 : X.nt >= 512 ? K_WIDE512 : K_EXTD2_WIDE, X.e0, X.e1);
@@ -1012,7 +1026,10 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 	}
 	(void)hipEventDestroy(ready);
 	const double t_waited = now();
-	unsigned long long used = d_cursor.download(st)[0];
+	const std::vector<unsigned long long> h_cursor = d_cursor.download(st);
+	unsigned long long used = h_cursor[0];
+	if (verbose) for (int c : {10, 11}) if (!cls[c].empty())
+		fprintf(stderr, "[pga]       class %d: %llu of %u direction-matrix chunks taken (%zu problems on %zu workgroups)\n", c, h_cursor[(size_t)1 + c] >> 32, lanes_pool_chunks[c - 10] & 0x7fffffffu, cls[c].size(), waves_of[c]);
 	if (used > cig_total) throw std::runtime_error("pga: CIGAR pool overflow");
 	if (tm) { tm->kern[K_EXTD2].alg_bytes += 4.0 * (double)used; tm->dp_cigar_ops += (double)used; }
 	download_to(cigars, d_pool.p, (size_t)used, st);

@@ -617,7 +617,7 @@ static void mv_run_rounds(std::vector<MvJob> &pending, const uint8_t *d_codes_p,
 		if (hcm[0].dels) PGA_HIP(hipMemcpyAsync(h_dels.data() + b_dels, d_dels.p, hcm[0].dels * sizeof(pga_del_t), hipMemcpyDeviceToHost, st));
 		if (hcm[0].inss) PGA_HIP(hipMemcpyAsync(h_inss.data() + b_inss, d_inss.p, hcm[0].inss * sizeof(pga_ins_t), hipMemcpyDeviceToHost, st));
 		if (hcm[0].ib) PGA_HIP(hipMemcpyAsync(h_seq.data() + b_seq, d_seq.p, hcm[0].ib, hipMemcpyDeviceToHost, st));
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		for (size_t k = b_inss; k < h_inss.size(); ++k) h_inss[k].seq_off += b_seq;
 		std::vector<MvJob> next;
 		size_t n_over = 0;

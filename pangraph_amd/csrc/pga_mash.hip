@@ -197,7 +197,7 @@ static void mash_sketch_all(const SeqSet &S, int k, int w, MashSketch &M, hipStr
 	if (staged && !overflow) hipLaunchKernelGGL(k_mash_unstage, dim3((nc + 3) / 4), dim3(256), 0, st, sval.p, spos.p, d_cnt.p, d_off.p, nc, stage_cap, M.val.p, M.pos.p);
 	else launch(1, nullptr, d_off.p, M.val.p, M.pos.p, 0);
 	PGA_HIP(hipGetLastError());
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 // ---- distance ----
@@ -280,7 +280,7 @@ static void mash_distance_dev(const SeqSet &S, int k, int w, DBuf<double> &D, hi
 	PGA_HIP(rocprim::inclusive_scan(tmpb.p, tmp2, head.p, rank.p, N, rocprim::plus<uint32_t>(), st));
 	uint32_t V = 0;
 	PGA_HIP(hipMemcpyAsync(&V, rank.p + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	// the bit matrix in slabs of the value axis: n x slab bits, at most ~2 GB
 	const uint64_t budget_words = (uint64_t)(getenv("PGA_MASH_SLAB_MB") ? atof(getenv("PGA_MASH_SLAB_MB")) * (1 << 20) : 2048.0 * (1 << 20)) / 8;
 	uint64_t slab_words = std::max<uint64_t>(MW, budget_words / (uint64_t)std::max(1, n));
@@ -479,13 +479,13 @@ void mash_distance_host(int n, const char *const *seqs, const uint32_t *lens, in
 	const double t0 = now();
 	SeqSet S; const int64_t one_grp[2] = {0, n};
 	upload_seqs(S, n, seqs, lens, nullptr, 1, one_grp, 0);
-	PGA_HIP(hipStreamSynchronize(0));
+	PGA_HIP(sync_stream(0));
 	const double t1 = now();
 	DBuf<double> D;
 	mash_distance_dev(S, k, w, D, 0);
-	PGA_HIP(hipStreamSynchronize(0));
+	PGA_HIP(sync_stream(0));
 	const double t2 = now();
-	if (dist) { PGA_HIP(hipMemcpyAsync(dist, D.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, 0)); PGA_HIP(hipStreamSynchronize(0)); }
+	if (dist) { PGA_HIP(hipMemcpyAsync(dist, D.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, 0)); PGA_HIP(sync_stream(0)); }
 	if (merges) { std::vector<int32_t> m; nj_dev(n, D.p, m, 0); if (!m.empty()) memcpy(merges, m.data(), m.size() * sizeof(int32_t)); }
 	if (verbose) fprintf(stderr, "[pga] guide tree: %d sequences, %.3f Gbp: hand-over %.3f s, sketch + distance %.3f s, neighbor joining %.3f s\n", n, S.total * 1e-9, t1 - t0, t2 - t1, now() - t2);
 }

@@ -9,6 +9,7 @@
 #include "pga_common.h"
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <mutex>
 #include <atomic>
 #include <chrono>
@@ -94,6 +95,39 @@ void dev_release_arena(int arena)
 	std::lock_guard<std::mutex> lk(g_mu);
 	g_arena_free.push_back(arena);
 	g_arena_leased[arena] = false;
+}
+
+static int spin_us() { static const int v = [] { const char *e = getenv("PGA_SPIN_US"); return e ? atoi(e) : 60; }(); return v; }
+static inline long long mono_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+hipError_t sync_stream(hipStream_t s)
+{
+	const int us = spin_us();
+	if (us > 0) {
+		const long long t_end = mono_ns() + 1000LL * us;
+		for (;;) {
+			const hipError_t q = hipStreamQuery(s);
+			if (q == hipSuccess) return hipSuccess;
+			if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+			if (mono_ns() >= t_end) break;
+			__builtin_ia32_pause();
+		}
+	}
+	return hipStreamSynchronize(s);
+}
+hipError_t sync_event(hipEvent_t e)
+{
+	const int us = spin_us();
+	if (us > 0) {
+		const long long t_end = mono_ns() + 1000LL * us;
+		for (;;) {
+			const hipError_t q = hipEventQuery(e);
+			if (q == hipSuccess) return hipSuccess;
+			if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+			if (mono_ns() >= t_end) break;
+			__builtin_ia32_pause();
+		}
+	}
+	return hipEventSynchronize(e);
 }
 
 void *dev_alloc(size_t bytes)
@@ -230,6 +264,23 @@ void stream_release(hipStream_t s)
 
 void dev_mem_stats(long long out[4]) { out[0] = g_n_malloc; out[1] = g_ns_malloc; out[2] = g_n_free; out[3] = g_ns_free; }
 void dev_mem_levels(long long out[2]) { std::lock_guard<std::mutex> lk(g_mu); out[0] = (long long)g_live_total; out[1] = (long long)g_idle_total; }
+
+// diagnostics (PGA_MEM_DUMP=1, from pga_mem_stats): what every arena holds, live and idle, and the largest idle size classes
+void dev_mem_dump()
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	std::map<std::pair<int, int>, size_t> live;
+	for (auto &kv : g_live) live[{kv.second.dev, kv.second.arena}] += kv.second.size;
+	fprintf(stderr, "[pga] device memory: %.1f GB live, %.1f GB idle in the cache\n", g_live_total / 1073741824.0, g_idle_total / 1073741824.0);
+	for (auto &kv : g_pools) {
+		std::map<size_t, int> classes; for (auto &b : kv.second.idle) ++classes[b.first];
+		std::string top; int k = 0;
+		for (auto it = classes.rbegin(); it != classes.rend() && k < 6; ++it, ++k) top += " " + std::to_string(it->first >> 20) + "MBx" + std::to_string(it->second);
+		auto ls = g_arena_leased.find(kv.first.second);
+		fprintf(stderr, "[pga]   device %d arena %d%s: live %.2f GB, idle %.2f GB in %zu blocks; largest idle classes:%s\n", kv.first.first, kv.first.second,
+		        ls != g_arena_leased.end() && ls->second ? " (leased)" : "", live[kv.first] / 1073741824.0, kv.second.idle_bytes / 1073741824.0, kv.second.idle.size(), top.c_str());
+	}
+}
 
 void dev_trim()
 {

@@ -476,7 +476,7 @@ void plan_regions(const std::vector<PlanIn> &in_, u128 *d_anchors, PkBases bases
 	hipLaunchKernelGGL(k_plan_regions, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_anchors, d_seq_len, P, p_out);
 	PGA_HIP(hipGetLastError());
 	if (!zc) PGA_HIP(hipMemcpyAsync(out.data(), d_out.p, n * sizeof(PlanOut), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	if (zc) memcpy(out.data(), h_out.data(), n * sizeof(PlanOut));
 	// segment slices: a segment spans at least min_ksw_len bases on both sequences unless it ends at a LONG_JOIN anchor (a long gap) or at the chain's end
 	uint64_t slots = 0;
@@ -495,7 +495,7 @@ void plan_regions(const std::vector<PlanIn> &in_, u128 *d_anchors, PkBases bases
 	hipLaunchKernelGGL(k_plan_collapse<false>, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_segs.p, d_nseg.p, p_out, (PlanItem*)nullptr, (const uint64_t*)nullptr);
 	PGA_HIP(hipGetLastError());
 	if (!zc) PGA_HIP(hipMemcpyAsync(out.data(), d_out.p, n * sizeof(PlanOut), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	if (zc) memcpy(out.data(), h_out.data(), n * sizeof(PlanOut));
 	for (size_t i = 0; i < n; ++i) if (out[i].status == 1) throw std::runtime_error("pga: plan_regions: a region cut more segments than its span allows");
 	// the items of all regions, one region after the other (the order the caller takes them in)
@@ -511,7 +511,7 @@ void plan_regions(const std::vector<PlanIn> &in_, u128 *d_anchors, PkBases bases
 		hipLaunchKernelGGL(k_plan_collapse<true>, dim3((unsigned)n), dim3(64), 0, st, p_in, (uint32_t)n, d_segs.p, d_nseg.p, p_out, p_items, p_ioff);
 		PGA_HIP(hipGetLastError());
 		if (!zci) PGA_HIP(hipMemcpyAsync(items.data(), d_items.p, (size_t)ioff[n] * sizeof(PlanItem), hipMemcpyDeviceToHost, st));
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		if (zci) memcpy(items.data(), h_items.data(), (size_t)ioff[n] * sizeof(PlanItem));
 	}
 }
@@ -525,7 +525,7 @@ void gather_anchors(const std::vector<uint64_t> &idx, const u128 *d_anchors, std
 		PinVec<u128> h_o; h_o.resize(idx.size());
 		hipLaunchKernelGGL(k_gather_anchors, dim3((unsigned)((idx.size() + 255) / 256)), dim3(256), 0, st, h_idx.data(), (uint32_t)idx.size(), d_anchors, h_o.data());
 		PGA_HIP(hipGetLastError());
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		memcpy(out.data(), h_o.data(), idx.size() * sizeof(u128));
 		return;
 	}
@@ -533,7 +533,7 @@ void gather_anchors(const std::vector<uint64_t> &idx, const u128 *d_anchors, std
 	DBuf<u128> d_o(idx.size());
 	hipLaunchKernelGGL(k_gather_anchors, dim3((unsigned)((idx.size() + 255) / 256)), dim3(256), 0, st, d_idx.p, (uint32_t)idx.size(), d_anchors, d_o.p);
 	PGA_HIP(hipMemcpyAsync(out.data(), d_o.p, idx.size() * sizeof(u128), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 } // namespace pga

@@ -68,7 +68,7 @@ void post_identity(PkBases d_bases, const PinVec<PostProbe> &probes, int m_max, 
 	if (n <= 4096) {                                              // (few probes: the kernel takes them from, and answers into, the caller's pinned lists)
 		hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, st, probes.data(), (uint32_t)n, d_bases, m_max, out.data());
 		PGA_HIP(hipGetLastError());
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		return;
 	}
 	DBuf<PostProbe> d; d.alloc(n);
@@ -77,7 +77,7 @@ void post_identity(PkBases d_bases, const PinVec<PostProbe> &probes, int m_max, 
 	hipLaunchKernelGGL(k_seg_identity, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, st, d.p, (uint32_t)n, d_bases, m_max, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 // ------------------------------------------------------------------------------------------------ z-drop walk
@@ -130,7 +130,7 @@ void post_zdrop_walk(PkBases d_bases, const std::vector<PostWalk> &reqs, const s
 		PinVec<PostWalkRes> hr; hr.resize(n);
 		hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, hd.data(), (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, hr.data());
 		PGA_HIP(hipGetLastError());
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		memcpy(out.data(), hr.data(), n * sizeof(PostWalkRes));
 		return;
 	}
@@ -139,7 +139,7 @@ void post_zdrop_walk(PkBases d_bases, const std::vector<PostWalk> &reqs, const s
 	hipLaunchKernelGGL(k_zdrop_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d.p, (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, r.p);
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostWalkRes), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 // ------------------------------------------------------------------------------------------------ CIGAR finish
@@ -364,7 +364,7 @@ void post_cigar_finish(PkBases d_bases, const std::vector<PostFin> &reqs, PinVec
 		hipLaunchKernelGGL(k_cigar_finish, dim3(grid), dim3(64), 0, st, hd.data(), (uint32_t)n, c.p, d_bases, P.sc_mch, P.sc_mis, P.sc_ambi, P.q, P.e, hr.data());
 		PGA_HIP(hipGetLastError());
 		if (cig.size()) PGA_HIP(hipMemcpyAsync(cig.data(), c.p, cig.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		memcpy(out.data(), hr.data(), n * sizeof(PostFinRes));
 		return;
 	}
@@ -374,7 +374,7 @@ void post_cigar_finish(PkBases d_bases, const std::vector<PostFin> &reqs, PinVec
 	PGA_HIP(hipGetLastError());
 	PGA_HIP(hipMemcpyAsync(out.data(), r.p, n * sizeof(PostFinRes), hipMemcpyDeviceToHost, st));
 	if (cig.size()) PGA_HIP(hipMemcpyAsync(cig.data(), c.p, cig.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 // bases of one window, back on the host (only the rare local-alignment windows the LL kernel does not take need them)

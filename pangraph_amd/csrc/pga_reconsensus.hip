@@ -279,7 +279,7 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 		std::vector<char> cat(cons_off[n_blocks] + 1);
 		for (int64_t b = 0; b < n_blocks; ++b) if (blocks[b].cons_len) memcpy(cat.data() + cons_off[b], blocks[b].consensus, blocks[b].cons_len);
 		PGA_HIP(hipMemcpyAsync(d_cons.p, cat.data(), cons_off[n_blocks], hipMemcpyHostToDevice, st));
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 	}
 	// ---- majority edits ----
 	DBuf<uint64_t> sub_key(n_subs + 1), sub_key2(n_subs + 1), ins_key(n_inss + 1), ins_hash(n_inss + 1);
@@ -295,7 +295,7 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 		DBuf<uint32_t> flag(n_subs + 1), pos(n_subs + 1); flag.zero(st);
 		hipLaunchKernelGGL(k_rc_sub_major, dim3((unsigned)((n_subs + 255) / 256)), dim3(256), 0, st, sub_key2.p, (int64_t)n_subs, d_depth.p, flag.p);
 		scan_u32(flag.p, pos.p, n_subs + 1);
-		uint32_t n_maj = 0; PGA_HIP(hipMemcpyAsync(&n_maj, pos.p + n_subs, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st));
+		uint32_t n_maj = 0; PGA_HIP(hipMemcpyAsync(&n_maj, pos.p + n_subs, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(sync_stream(st));
 		if (n_maj) { DBuf<uint64_t> o(n_maj); hipLaunchKernelGGL(k_rc_compact<uint64_t>, dim3((unsigned)((n_subs + 255) / 256)), dim3(256), 0, st, flag.p, pos.p, n_subs, sub_key2.p, o.p); maj_sub_keys = o.download(st); }
 	}
 	if (n_dels) {
@@ -307,7 +307,7 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 		DBuf<uint32_t> fs(n_cov + 1), fe(n_cov + 1), ps(n_cov + 1), pe(n_cov + 1); fs.zero(st); fe.zero(st);
 		hipLaunchKernelGGL(k_rc_del_flags, dim3((unsigned)((n_cov + 255) / 256)), dim3(256), 0, st, covs.p, n_cov, (const uint32_t*)nullptr, d_cov_base.p, d_depth.p, (int)n_blocks, fs.p, fe.p);
 		scan_u32(fs.p, ps.p, n_cov + 1); scan_u32(fe.p, pe.p, n_cov + 1);
-		uint32_t ns = 0, ne = 0; PGA_HIP(hipMemcpyAsync(&ns, ps.p + n_cov, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipMemcpyAsync(&ne, pe.p + n_cov, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st));
+		uint32_t ns = 0, ne = 0; PGA_HIP(hipMemcpyAsync(&ns, ps.p + n_cov, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipMemcpyAsync(&ne, pe.p + n_cov, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(sync_stream(st));
 		if (ns != ne) throw std::runtime_error("pga_reconsensus: interval starts and ends disagree");
 		if (ns) {
 			DBuf<uint64_t> os(ns), oe(ns);
@@ -336,7 +336,7 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 		DBuf<int> coll(1); coll.zero(st);
 		hipLaunchKernelGGL(k_rc_ins_major, dim3((unsigned)((n_inss + 255) / 256)), dim3(256), 0, st, k2.p, hs.p, i2.p, (int64_t)n_inss, d_inss.p, d_iseq.p, d_depth.p, flag.p, coll.p);
 		scan_u32(flag.p, pos.p, n_inss + 1);
-		uint32_t n_maj = 0; PGA_HIP(hipMemcpyAsync(&n_maj, pos.p + n_inss, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(hipStreamSynchronize(st));
+		uint32_t n_maj = 0; PGA_HIP(hipMemcpyAsync(&n_maj, pos.p + n_inss, 4, hipMemcpyDeviceToHost, st)); PGA_HIP(sync_stream(st));
 		if (coll.download(st)[0]) ins_exact_on_host = true;
 		else if (n_maj) { DBuf<uint32_t> o(n_maj); hipLaunchKernelGGL(k_rc_compact<uint32_t>, dim3((unsigned)((n_inss + 255) / 256)), dim3(256), 0, st, flag.p, pos.p, n_inss, i2.p, o.p); maj_ins_idx = o.download(st); }
 	}
@@ -458,7 +458,7 @@ void reconsensus_host(int64_t n_blocks, const pga_rc_block_t *blocks, const pga_
 		new_cons_all.resize(a_out);
 		for (int64_t b : blocks2) if (R[b].kind == 2) PGA_HIP(hipMemcpyAsync(new_cons_all.data() + nc[b].off, d_out.p + nc[b].off, nc[b].len, hipMemcpyDeviceToHost, st));
 		if (!mvj.empty()) { memset(v_res.data(), 0, v_res.size() * sizeof(pga_mapvar_res_t)); map_variations_dev((int64_t)mvj.size(), mvj.data(), d_out.p, a_out, prm, v_res.data(), v_subs, v_dels, v_inss, v_iseq, st); }
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 	}
 	// ---- pack ----
 	std::vector<size_t> rj_of_member((size_t)n_mem, (size_t)-1), mv_of_member((size_t)n_mem, (size_t)-1);

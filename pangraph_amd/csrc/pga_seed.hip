@@ -321,7 +321,7 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	}
 	uint64_t n_kept = 0;
 	PGA_HIP(hipMemcpyAsync(&n_kept, pos64.p + n, 8, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	DBuf<uint32_t> kept_idx; DBuf<uint64_t> seq_off2((size_t)n_seq + 1);
 	const uint32_t *kept_p = nullptr;
 	if (n_kept != n) {
@@ -371,14 +371,14 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	}
 	uint64_t n_ub = 0;
 	PGA_HIP(hipMemcpyAsync(&n_ub, ub_off.p + n_kept, 8, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	DBuf<u128> ub(n_ub ? n_ub : 1);
 	hipLaunchKernelGGL(k_anchors, dim3(nbk), dim3(256), 0, st, M.mz.p, kept_p, n_kept, sd_n.p, sd_occ.p, sd_qpos.p, sd_flag.p, I.occ.p, C,
 	                   (int32_t)I.k, cnt.p, ub_off.p, ub.p);
 	excl_scan(cnt.p, a_off.p, n_kept + 1, st);
 	uint64_t n_a = 0;
 	PGA_HIP(hipMemcpyAsync(&n_a, a_off.p + n_kept, 8, hipMemcpyDeviceToHost, st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	O.n_a = n_a;
 	hipLaunchKernelGGL(k_query_anchor_off, dim3(nbq), dim3(256), 0, st, a_off.p, seq_off2.p, n_seq, n_kept, n_a, O.q_aoff.p);
 	{ Downloads dl(st); dl.add(O.h_rep_len, rep_len.p, rep_len.n); dl.add(O.h_q_aoff, O.q_aoff.p, O.q_aoff.n); dl.wait(); }
@@ -440,7 +440,7 @@ void seed_all(const SeqSet &S, const Minimizers &M, const Index &I, const DBuf<u
 	O.exact = false;
 	if (exact_order) seed_exact_order(O, nullptr, n_seq, st, tm);
 	PGA_HIP(hipGetLastError());
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	if (getenv("PGA_VERBOSE")) {
 		std::vector<uint32_t> tf = q_tie.download(st); size_t nt = 0; for (uint32_t v : tf) nt += v;
 		fprintf(stderr, "[pga]   seed: %llu anchors, %zu of %d queries hold equal anchor keys (%s)\n", (unsigned long long)n_a, nt, n_seq,
@@ -464,7 +464,7 @@ void seed_exact_order(SeedResult &O, const uint32_t *d_need, int n_seq, hipStrea
 	hipLaunchKernelGGL(k_copy_tied, dim3((unsigned)n_seq, 64), dim3(256), 0, st, n_seq, fl.p, O.q_aoff.p, O.raw_x.p, O.raw_y.p, O.a.p);
 	const RsHint hint{O.srt_x.p, O.srt_y.p, O.dupc.p};
 	replay_sort_segments(O.a.p, O.n_a, O.q_aoff.p, nullptr, n_seq, fl.p, st, tm, getenv("PGA_NO_SORT_HINT") ? nullptr : &hint);
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 	if (!d_need) O.exact = true;
 }
 

@@ -218,7 +218,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			}
 			if (!staged) { for (Stage &x : sg) { x.pin = (uint8_t*)pin_alloc(chunk); x.dev = (uint8_t*)dev_alloc(chunk); PGA_HIP(hipEventCreateWithFlags(&x.sent, hipEventDisableTiming)); } staged = true; }
 			Stage &x = sg[n_staged++ & 1];
-			if (x.used) PGA_HIP(hipEventSynchronize(x.sent));          // the staging buffer's previous chunk has left the host
+			if (x.used) PGA_HIP(sync_event(x.sent));          // the staging buffer's previous chunk has left the host
 			x.used = true;
 			// gather [b, e) of the concatenation: every thread copies a contiguous slice
 			auto gather = [&](uint64_t lo, uint64_t hi) {
@@ -249,7 +249,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 		}
 		PGA_HIP(hipGetLastError());
 		const double tw0 = now_s();
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		tu_w = now_s() - tw0;
 		if (staged) for (Stage &x : sg) { pin_free(x.pin); dev_free(x.dev); (void)hipEventDestroy(x.sent); }
 	}
@@ -284,7 +284,7 @@ void upload_seqs(SeqSet &S, int n, const char *const *seq, const uint32_t *len, 
 			const uint64_t n_words = padded / 16;
 			hipLaunchKernelGGL(k_repack, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, S.d_pk2.p, S.d_nmask.p, n_words, S.d_off.p, n, d_from.p);
 			PGA_HIP(hipGetLastError());
-			PGA_HIP(hipStreamSynchronize(st));
+			PGA_HIP(sync_stream(st));
 		}
 	}
 }
@@ -701,7 +701,7 @@ template <class T> static void exclusive_scan_u64(const T *in, uint64_t *out, si
 	PGA_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in_it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), st));
 	DBuf<uint8_t> tmp(tmp_bytes ? tmp_bytes : 1);
 	PGA_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, in_it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), st));
-	PGA_HIP(hipStreamSynchronize(st));
+	PGA_HIP(sync_stream(st));
 }
 
 void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Timers *tm)
@@ -726,7 +726,9 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 		DBuf<uint32_t> d_cnt(nt + 1); d_cnt.zero(st);
 		DBuf<uint64_t> d_toff(nt + 1);
 		DBuf<int> d_ovf(1); d_ovf.zero(st);
-		uint32_t cap = SK_TILE / 4;                           // expected density is 2/(w+1) per base
+		// expected density is 2/(w+1) per base: 205 per tile of 2048 with w = 19, 372 with w = 10 (asm20).  The staging slab is nt x cap x 16 bytes -- 2.3 GB per leaf
+		// batch (0.57 Gbp) at a quarter of a tile, the largest single block of a batch's arena; 1.7x the expectation instead of 2.5x (an overflow retries at 4x)
+		uint32_t cap = w >= 16 ? SK_TILE / 6 : SK_TILE / 3;
 		for (;;) {
 			DBuf<u128> stage(nt * (size_t)cap);
 			EventTimer et(st);
@@ -768,13 +770,13 @@ void sketch_all(const SeqSet &S, int w, int k, Minimizers &M, hipStream_t st, Ti
 		exclusive_scan_u64(d_cnt.p, M.seq_off.p, (size_t)n + 1, st);
 		uint64_t total = 0;
 		PGA_HIP(hipMemcpyAsync(&total, M.seq_off.p + n, 8, hipMemcpyDeviceToHost, st));
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 		M.n = total;
 		M.mz.alloc(total ? total : 1);
 		hipLaunchKernelGGL(k_sketch_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S.bases(), S.d_off.p, S.d_len.p, n, w, k,
 		                   M.mz.p, M.seq_off.p, (uint64_t*)nullptr, ring.p);
 		PGA_HIP(hipGetLastError());
-		PGA_HIP(hipStreamSynchronize(st));
+		PGA_HIP(sync_stream(st));
 	}
 	M.h_seq_off = M.seq_off.download(st);
 }
