@@ -91,6 +91,65 @@ DP_CELL_CYCLES = {"k_extd2_lanes": 1370.0 / 512.0, "k_ext_pipe": 820.0 / 256.0}
 N_SIMD, CLOCK_HZ = 1024, 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 
 
+VALU_PEAK_WAVE_INST_S = N_SIMD * CLOCK_HZ / 2.0   # MI355X_MICROARCH.md "Wave scheduling": a SIMD-32 issues one wave64 VALU instruction over 2 cycles
+
+
+def _short(k: str) -> str:
+    return k.replace("void ", "").replace("pga::", "").split("(")[0]
+
+
+def pmc_valu_insts(names):
+    """VALU wave-instructions per STEP of the kernels whose names contain one of `names`, from the committed rocprofv3 --pmc pass of this same workload
+    (profiles/r*_pmc_issue*kernels.json: SQ_INSTS_VALU summed over all dispatches of one step).  NOT measured in this run; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue*kernels.json")))
+    if not files:
+        return None
+    tot = 0.0
+    for k, v in json.load(open(files[-1])).get("kernels", {}).items():
+        if any(nm in k for nm in names):
+            tot += float(v.get("SQ_INSTS_VALU", 0.0))
+    return tot or None
+
+
+def rocprof_top_kernel():
+    """The kernel with the largest total duration in the committed `rocprofv3 --kernel-trace --stats` summary of this same command
+    (profiles/r*_c5_kernel_stats.csv: warm-up step + one timed step in the file), with BOTH fractions for it: VALU issue (SQ_INSTS_VALU of the PMC pass
+    over its rocprof time, against 1024 SIMDs x 2.4 GHz / 2) and HBM (counter bytes FETCH x 2 + WRITE over its rocprof time, against 8 TB/s).
+    HIP events on a stream see a launch from the moment it is queued behind the stream's earlier work; rocprof sees the kernel itself -- the two rankings
+    can differ, hence both in the line.  NOT measured in this run; None if there is no summary."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = []
+    with open(files[-1], newline="") as fh:
+        for r in csv.DictReader(fh):
+            try:
+                rows.append((_short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["MaxNs"])))
+            except (KeyError, ValueError):
+                continue
+    rows = [r for r in rows if r[0].startswith("k_")]
+    if not rows:
+        return None
+    steps_in_file = 2.0
+    name, calls, tot_ns, avg_ns, max_ns = max(rows, key=lambda r: r[2])
+    fam = name.split("<")[0]
+    out = {"name": name, "calls_per_step": calls / steps_in_file, "avg_ms": avg_ns * 1e-6, "max_ms": max_ns * 1e-6, "kernel_ms_per_step": tot_ns * 1e-6 / steps_in_file,
+           "source": os.path.relpath(files[-1], ROOT)}
+    secs = tot_ns * 1e-9 / steps_in_file
+    vi = pmc_valu_insts([name if "<" in name else fam + "("]) or pmc_valu_insts([fam])
+    if vi and secs > 0:
+        out["valu_wave_insts_per_s"] = vi / secs
+        out["valu_frac"] = vi / secs / VALU_PEAK_WAVE_INST_S
+    tr = pmc_traffic(fam, 1.0)            # bytes per step
+    if tr and secs > 0:
+        out["hbm_counter_GBs"] = tr / secs / 1e9
+        out["hbm_frac"] = tr / secs / 1e9 / HBM_PEAK_GBS
+    return out
+
+
 def profile_counts(ms_step: float):
     """From the committed rocprofv3 summaries of this same workload (profiles/r*_kernel_concurrency.json: kernel trace of warm-up + one step;
     profiles/r*_pmc_issue*kernels.json: SQ_WAVE_CYCLES of one step, in quad-cycles): kernel dispatches per step and the average number of waves
@@ -665,27 +724,38 @@ def main():
                      "whole_path": {"alg_bytes_per_step": alg_step, "achieved": alg_step / (ms_step * 1e-3) / 1e9, "frac": alg_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      "valu_issue_frac": valu_frac,
                      "note": "kernel = largest summed HIP-event time (own stream); batches overlap, see busy_ms; traffic: profiles/ PMC passes, same unit as alg_bytes_per_launch; "
-                             "an integer DP kernel is bound by VALU issue of its waves, not by HBM or MFMA: bound valu = cells/s over 1024 SIMDs x 2.4 GHz / (cycles one wave spends "
-                             "on the recurrence per cell, measured in the kernel); valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of its largest instantiation; "
+                             "an integer DP kernel is bound by VALU issue, not by HBM or MFMA: bound valu = VALU wave-instructions/s (SQ_INSTS_VALU of the committed PMC pass / this "
+                             "run's summed launch time) against 1024 SIMDs x 2.4 GHz / 2; valu_model_frac = round 5's cells/s against a ceiling from the kernel's own cycles per cell "
+                             "(self-referential, kept for continuity); valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of its largest instantiation; rocprof_top_kernel = the "
+                             "largest kernel of the committed rocprofv3 --stats summary with both fractions; "
                              "dispatches_per_step, resident_waves_per_simd: profiles/ (rocprofv3 passes of this workload, not this run)"},
         "n_matches_gathered": last["n_matches"],
         "build_sha256": build_sha,
         "resident_gbp_s": resident["gbp_s"] if resident else (units * args.steps / dt / 1e9 if inp["lib"] is not None else None),
     }
-    # an integer DP kernel is bound by the VALU issue of its waves, not by HBM: cells per second against what the device's SIMDs could do at the
-    # kernel's own measured cost of a cell (the HBM figures of the same kernel stay beside it)
+    # An integer DP kernel is bound by the VALU issue of its waves, not by HBM or MFMA.  frac is held against a HARDWARE peak: VALU wave-instructions per second
+    # of the family (SQ_INSTS_VALU of the committed PMC pass of this workload, per step) over the family's summed launch time of THIS run, against what the chip
+    # can issue (1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction).  The round-5 figure -- cells per second against a ceiling derived from the kernel's
+    # own measured cycles per cell -- is self-referential (it says how much of its own arithmetic the kernel keeps busy, not how good that arithmetic is) and
+    # stays beside it as valu_model_*; the HBM figures of the same kernel stay too.
     if batch.KERNEL_BOUND[ki] == "dp" and kms > 0:
         kcells = st["kern_cells"][ki]
         cyc = DP_CELL_CYCLES.get(kname.split("+")[0].split("<")[0], DP_CELL_CYCLES["k_extd2_lanes"])
-        peak = N_SIMD * CLOCK_HZ / cyc / 1e9
-        ach = kcells / (kms * 1e-3) / 1e9
-        out["roofline"].update({"bound": "valu", "achieved": ach, "peak": peak, "unit": "Gcell/s", "frac": ach / peak, "cells_per_launch": kcells / klaunch if klaunch else None,
-                                "cycles_per_cell_of_one_wave": cyc})
+        peak_cells = N_SIMD * CLOCK_HZ / cyc / 1e9
+        ach_cells = kcells / (kms * 1e-3) / 1e9
+        out["roofline"].update({"gcells_per_s": ach_cells, "cells_per_launch": kcells / klaunch if klaunch else None,
+                                "valu_model_peak_gcells_per_s": peak_cells, "valu_model_frac": ach_cells / peak_cells, "cycles_per_cell_of_one_wave": cyc})
+        vi = pmc_valu_insts([x for x in kname.replace(" ", "").split("+") if x.startswith("k_")])
+        if vi:
+            ach = vi / (kms * 1e-3)                      # wave-instructions per second while the family's launches run (summed launch time)
+            out["roofline"].update({"bound": "valu", "achieved": ach / 1e9, "peak": VALU_PEAK_WAVE_INST_S / 1e9, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_WAVE_INST_S,
+                                    "valu_insts_per_cell": vi / kcells if kcells else None})
         # what a DP kernel moves through HBM is its direction matrix (a byte or two per cell, written for the backtrack and read by it), not the bases its
         # alg_bytes count: traffic per CELL says whether that is all it moves
         tr, cpl = out["roofline"].get("traffic"), out["roofline"].get("cells_per_launch")
         if tr and cpl:
             out["roofline"]["traffic_bytes_per_cell"] = tr / cpl
+    out["roofline"]["rocprof_top_kernel"] = rocprof_top_kernel()
     out["roofline"].update(profile_counts(ms_step))
     out.update(parity)
     detail = {

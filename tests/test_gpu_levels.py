@@ -145,6 +145,25 @@ def test_c3_full_size_every_wave_vs_reference(gpu_lib, ref_lib):
             assert a == b, (label, g, len(a), len(b))
 
 
+def test_c5_first_three_heights_under_asm20_live_vs_reference(gpu_lib, ref_lib):
+    """The BASELINE build's block sets under the OTHER scoring row (sensitivity 20 = asm20: k 19, w 10, a 1 b 4 q 6 e 2 q2 26 e2 1, options.c:125-130;
+    the digests of the suite are asm10): every sixth group of both rounds of tree heights 1-3 (whole-genome pairs; a genome against a two-genome graph;
+    block sets of a few dozen blocks) through the batch entry, live against the compiled reference on this box's cores.  asm20's w = 10 doubles the
+    minimizers and anchors of a call and its low gap costs keep extensions alive longer: other DP classes, other band rings than under asm10."""
+    waves = Population(20260928, 1000, 5_000_000).build_waves()[:6]
+    n_groups = n_rec = 0
+    for label, groups, names in waves:
+        sel = list(range(0, len(groups), 6))
+        gs, ns = [groups[i] for i in sel], [names[i] for i in sel]
+        got = product_align_groups(gs, ns, sensitivity=20)
+        want = ref_align_groups(gs, ns, sensitivity=20)
+        for g, (a, b) in zip(sel, zip(got, want)):
+            assert a == b, (label, g, len(a), len(b))
+            n_rec += len(a)
+        n_groups += len(sel)
+    assert n_groups >= 100 and n_rec > 1000
+
+
 def test_c5_every_wave(gpu_lib):
     """config C5 = the BASELINE configuration (1000 x 5 Mbp, seed 20260928): all 42 waves, all 1998 find_matches calls of the build
     through pga_batch_create + pga_batch_align, per group against the digests the compiled reference produced in the build container
