@@ -1182,7 +1182,9 @@ static void chain_core(const DBuf<u128> &a, const DBuf<uint64_t> &q_aoff, const 
 		const bool prof_on = verbose && getenv("PGA_CHAIN_PROF");
 		DBuf<unsigned long long> cprof(16); if (prof_on) cprof.zero(st);
 		if (use_fast && prof_on) hipLaunchKernelGGL((k_chain_fast<2048, true>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, cprof.p);
-		else if (use_fast) hipLaunchKernelGGL((k_chain_fast<2048, false>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
+		else if (use_fast) {
+			hipLaunchKernelGGL((k_chain_fast<2048, false>), dim3(n_seg), dim3(64), 0, st, a.p, seg_start.p, ord.p, n_seg, n_a, q_aoff.p, n_seq, P, f.p, pp.p, seg_flag.p, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
+		}
 		const double ms_fast = verbose ? et.stop() : 0.0;
 		// segments the fast kernel gave up on (rare: ring overflow, a tied minimum, a crowded inner window) are re-run by the tree kernel
 		bool any_flagged = !use_fast;

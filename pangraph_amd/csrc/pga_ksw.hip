@@ -364,6 +364,9 @@ static inline int wide_ring(const DpJob &j)
 }
 static inline int wide_seqcap(const DpJob &j) { return ((j.qlen > j.tlen ? j.qlen : j.tlen) + 15) / 16 * 16; }
 size_t ll_lds_bytes(int t_cap);
+size_t ll_multi_scratch_bytes();
+int ll_groups(uint32_t n_jobs, int t_max);
+void launch_ll_multi(int G, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, unsigned long long *scratch, DpRes *res, hipStream_t st);
 void launch_ll_i16(unsigned n_blocks, int t_cap, const DpJob *jobs, uint32_t n_jobs, PkBases bases, const DpParams &P, uint32_t *counter,
                    unsigned long long *rowkey, size_t rowkey_stride, DpRes *res, hipStream_t st);
 
@@ -596,7 +599,7 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 		for (size_t i = lo; i < hi; ++i) {
 			const bool is_ll = jobs[i].flag & PGA_JOB_LL;
 			cls_of[i] = (uint8_t)dp_class(jobs[i], allow_band, P);
-			need[i] = is_ll ? (((size_t)jobs[i].tlen * 8 + 255) & ~(size_t)255) : cls_of[i] == 8 ? band_slab_bytes(jobs[i].qlen + jobs[i].tlen) : cls_of[i] == 9 ? strips_slab_bytes(jobs[i]) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
+			need[i] = is_ll ? ll_multi_scratch_bytes() : cls_of[i] == 8 ? band_slab_bytes(jobs[i].qlen + jobs[i].tlen) : cls_of[i] == 9 ? strips_slab_bytes(jobs[i]) : dp_slab_bytes(jobs[i].qlen, jobs[i].tlen, jobs[i].w);
 		}
 	});
 	{
@@ -917,9 +920,15 @@ static void dp_run_impl(PkBases d_bases, const std::vector<DpJob> &jobs, const D
 			               X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		} else if (c == 8) launch_gapfill_band((unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 6) {
-			int t_cap = 16;
-			for (uint32_t id : ids) t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16));
-			launch_ll_i16((unsigned)X.n_waves, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, (unsigned long long*)slab_p, slab_max[c] / 8, X.res_p, cs);
+			int t_cap = 16, t_max = 1;
+			for (uint32_t id : ids) { t_cap = std::max(t_cap, std::max((jobs[id].tlen + 15) / 16 * 16, (jobs[id].qlen + 15) / 16 * 16)); t_max = std::max(t_max, jobs[id].tlen); }
+			// a problem over several workgroups (pga_ll.hip: k_ll_multi) when the targets are long and the launch leaves the CUs for it; the lane's slab holds
+			// a scratch record per problem (n_waves x slab_max[6] bytes >= problems x record: the groups of all problems are resident at once, so problems <= 224)
+			const int G = ll_groups((uint32_t)ids.size(), t_max);
+			if (G > 1 && ids.size() * ll_multi_scratch_bytes() <= X.n_waves * slab_max[c])
+				launch_ll_multi(G, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, (unsigned long long*)slab_p, X.res_p, cs);
+			else
+				launch_ll_i16((unsigned)X.n_waves, t_cap, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, (unsigned long long*)slab_p, slab_max[c] / 8, X.res_p, cs);
 		} else if (c <= 1) launch_extd2_fast(c == 0 ? 4 : 8, (unsigned)X.n_waves, X.jobs_p, (uint32_t)ids.size(), d_bases, P, X.cnt_p, slab_p, slab_max[c], X.res_p, d_pool.p, d_cursor.p, cig_total, cs);
 		else if (c == 13) {
 			int q_cap = 16, t_cap = 16;
