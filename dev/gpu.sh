@@ -9,7 +9,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 R=$PWD
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 mkdir -p gpurun_out/profiles_out
 cmd=$1; shift
 
