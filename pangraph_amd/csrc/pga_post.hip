@@ -294,7 +294,54 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 					const int n_a = (int)wave_sum_u32((uint32_t)__popc(amb)), n_d = (int)wave_sum_u32((uint32_t)__popc(d2));
 					ambi += n_a, diff += n_d;
 					if (n_a == 0 && n_d == 0 && sc_mch > 0) { s += (double)sc_mch * (double)n_tot; smax = smax > s ? smax : s; continue; }   // all matches: s only grows
+					// The trip in block form (round 6).  With s_in the score before the trip, P_i the sum of the first i scores and pmin_i = min(P_1 .. P_i):
+					// s_i = max(s_in + P_i, P_i - pmin_i), hence the trip's maximum is max(s_in + A, B) with A = max_i P_i, B = max_i (P_i - pmin_i), and it leaves
+					// s_out = max(s_in + T, T - PM) (T = P_n, PM = pmin_n) -- four integers per trip that do not depend on s_in.  A match scores sc_mch > 0, so between
+					// two EVENTS (a mismatch or an ambiguous base) P_i rises: minima of P can only sit right behind an event or at the first position, maxima of P and
+					// of P - pmin right in front of an event, at one, or at the end -- a lane visits those positions only (one or two of its sixteen bases at 1 %
+					// divergence) instead of all sixteen twice.  sc_mch <= 0 (no preset has it) takes the position-by-position form.
 					int T = 0, Lm = 0x3fffffff;
+					const uint32_t dif16 = (d2 & 0x55555555u);                            // bit 2i -> compress to bit i
+					uint32_t dd = dif16; dd = (dd | dd >> 1) & 0x33333333u; dd = (dd | dd >> 2) & 0x0f0f0f0fu; dd = (dd | dd >> 4) & 0x00ff00ffu; dd = (dd | dd >> 8) & 0x0000ffffu;
+					const uint32_t ev16 = (amb | dd) & vm16;
+					double mx; 
+					if (sc_mch > 0) {
+						const int d_mis = sc_mis - sc_mch, d_amb = sc_ambi - sc_mch;
+						T = v * sc_mch + __popc(dd & ~amb) * d_mis + __popc(amb) * d_amb;
+						{	// pass 1: the lane's own prefix minimum (of sums that start at its first base)
+							int cum = 0; uint32_t E = ev16;
+							if (v > 0 && !(E & 1u)) Lm = sc_mch;
+							while (E) {
+								const int pz = __ffs((int)E) - 1; E &= E - 1;
+								cum += (amb >> pz & 1u) ? d_amb : d_mis;
+								const int part = (pz + 1) * sc_mch + cum;
+								Lm = Lm < part ? Lm : part;
+							}
+						}
+						const int Bx = (int)wave_prefix_sum_incl((uint32_t)T) - T;
+						const int Gi = wave_prefix_min_incl(v > 0 ? Bx + Lm : 0x3fffffff);
+						const int Ge = wave_shr1(Gi, 0x3fffffff);
+						int A_l = -0x3fffffff, B_l = -0x3fffffff;
+						if (v > 0) {	// pass 2: maxima of P and of P - pmin at the candidate positions
+							int cum = 0, pmin = Ge; uint32_t E = ev16;
+							auto at = [&](int i_) { const int run = Bx + i_ * sc_mch + cum; pmin = pmin < run ? pmin : run; A_l = A_l > run ? A_l : run; const int d_ = run - pmin; B_l = B_l > d_ ? B_l : d_; };
+							if (!(E & 1u)) at(1);
+							while (E) {
+								const int pz = __ffs((int)E) - 1; E &= E - 1;
+								if (pz >= 1) at(pz);                                           // right in front of the event
+								cum += (amb >> pz & 1u) ? d_amb : d_mis;
+								at(pz + 1);                                                    // ... and at it
+							}
+							at(v);
+						}
+						const int A = wave_max_i32(A_l), B = wave_max_i32(B_l);
+						const int ll = (n_tot - 1) >> 4;                                 // the lane of the trip's last base
+						const int Ttot = rl(Bx + T, ll), PM = rl(Gi, ll);
+						const double c1 = s + (double)A, c2 = (double)B;
+						mx = c1 > c2 ? c1 : c2;
+						const double o1 = s + (double)Ttot, o2 = (double)(Ttot - PM);
+						s = o1 > o2 ? o1 : o2;
+					} else {
 					for (int i = 0; i < v; ++i) { const int x = (amb >> i & 1u) ? sc_ambi : (d2 >> (2 * i) & 1u) ? sc_mis : sc_mch; T += x; Lm = Lm < T ? Lm : T; }
 					const int Bx = (int)wave_prefix_sum_incl((uint32_t)T) - T;          // sum of the scores in front of this lane
 					const int Gi = wave_prefix_min_incl(v > 0 ? Bx + Lm : 0x3fffffff);    // prefix minimum up to and including this lane
@@ -311,12 +358,13 @@ void k_cigar_finish(const PostFin *__restrict__ rq, uint32_t n, uint32_t *__rest
 							lmax = lmax > si ? lmax : si; slast = si;
 						}
 					}
-					const double mx = -wave_min_f64_key(-(v > 0 ? lmax : 0.0));
-					smax = smax > mx ? smax : mx;
+					mx = -wave_min_f64_key(-(v > 0 ? lmax : 0.0));
 					const int ll = (n_tot - 1) >> 4;                                     // the lane of the trip's last base
 					const long long bits = __double_as_longlong(slast);
 					const int lo = rl((int)(bits & 0xffffffffLL), ll), hi2 = rl((int)(bits >> 32), ll);
 					s = __longlong_as_double(((long long)hi2 << 32) | (unsigned)lo);
+					}
+					smax = smax > mx ? smax : mx;
 				}
 				blen += len - ambi, mlen += len - (ambi + diff), n_ambi += ambi;
 				toff += len, qoff += len;
