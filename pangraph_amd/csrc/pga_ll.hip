@@ -144,8 +144,8 @@ void k_ll_i16(const DpJob *__restrict__ jobs, uint32_t n_jobs, PkBases bases, Dp
 // last thread as it leaves a column; loads 64 columns at a time by wave 0 of the consumer, one block ahead of their use, so that the sweep never waits for a
 // load once it runs: a consumer starts when its producer is NT + 64 columns in and then keeps that distance).  Every group keeps the maximum of its rows in
 // k_ll_i16's key (score, LAST row, last slot in striped order); the group that arrives last combines them.  Groups of one problem have consecutive block
-// indices, producers first: a consumer is never resident before its producer was dispatched, and the launcher keeps all groups of all problems within what
-// the device holds at once.  Measured alone on the device (dev/ll_probe.py, wall time of a launch, host path included), 10 kb x 10 kb: 21.8 ms on one
+// indices, producers first, and the launcher keeps the groups of a launch few enough that waiting groups can never fill an XCD (ll_groups below): a
+// producer always finds a slot.  Measured alone on the device (dev/ll_probe.py, wall time of a launch, host path included), 10 kb x 10 kb: 21.8 ms on one
 // workgroup, 12.5 ms on 4 x 1024 threads, 9.3 ms on 16 x 512, **8.7 ms on 16 x 256** (three rows per thread: a group of four waves -- one per SIMD -- pays
 // a fraction of a sixteen-wave barrier per column; one wave per group, no barrier at all, is slower again: 9.5 ms on 64 x 64, the hand-over lag of 64
 // boundaries); 6 kb x 6 kb: 9.2 -> 5.2 ms; 3.5 kb x 3.5 kb: 4.3 -> 3.1 ms.
@@ -307,8 +307,13 @@ int ll_groups(uint32_t n_jobs, int t_max)
 	const int g_min = (t_max + LL_RMAX * nt - 1) / (LL_RMAX * nt);                      // a thread holds at most LL_RMAX rows
 	if (G < g_min) G = g_min;
 	if (G > LL_G_MAX) G = LL_G_MAX;
-	while (G > g_min && G > 1 && (uint64_t)n_jobs * (uint64_t)G * (uint64_t)nt > 224 * 1024) --G;
-	if (G < g_min || (uint64_t)n_jobs * (uint64_t)G * (uint64_t)nt > 224 * 1024) return 1;   // no room (or a target beyond the groups' reach): the single-workgroup kernel
+	// All groups of all problems of a launch are resident at once, and a group that waits for its producer holds its slot while it does.  Workgroups of a launch
+	// go round the XCDs, so a consumer can be placed before its producer if the producer's XCD is momentarily full; that resolves as soon as anything there
+	// finishes -- unless an XCD were full of WAITING groups only.  128 groups per launch are 16 per XCD (64 of its 1 024 wave slots at 256 threads a group): six
+	// launches of six batches in flight cannot fill an XCD between them.
+	const uint64_t max_groups = 128;
+	while (G > g_min && G > 1 && (uint64_t)n_jobs * (uint64_t)G > max_groups) --G;
+	if (G < g_min || (uint64_t)n_jobs * (uint64_t)G > max_groups) return 1;   // no room (or a target beyond the groups' reach): the single-workgroup kernel
 	return G < 1 ? 1 : G;
 }
 

@@ -69,20 +69,25 @@ void k_plan_regions(const PlanIn *__restrict__ in, uint32_t n_regions, u128 *__r
 		const int32_t q_lo = A.qpos(first) + 1 - sp0, q_hi = A.qpos(last) + 1;
 		if (rev) r_qs = qlen - q_hi, r_qe = qlen - q_lo; else r_qs = q_lo, r_qe = q_hi;
 		uint32_t cov = 0, blk = 0;
-		// (a whole-genome chain holds half a million anchors and ONE wave streams them: four windows of loads are in flight per trip -- the loop is bound
-		// by the latency of a load, not by its bytes)
-		for (int i0 = first + 1; i0 <= last; i0 += 256) {
-			u128 cur[4], prv[4];
+		// (a whole-genome chain holds half a million anchors and ONE wave streams them: the loop is bound by the latency of a load, not by its bytes.  Round 6:
+		// every anchor is loaded ONCE -- its predecessor is the neighbouring lane's anchor, one DPP move per field, the window's first lane takes the last anchor
+		// of the window before -- and EIGHT windows of loads are in flight per trip: half the loads, twice the anchors per round trip)
+		int32_t cx = (int32_t)A.a[first].x, cy = (int32_t)A.a[first].y;              // the anchor in front of the trip's first (uniform)
+		for (int i0 = first + 1; i0 <= last; i0 += 512) {
+			u128 cur[8];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; if (i <= last) { cur[u] = A.a[i]; prv[u] = A.a[i - 1]; } else { cur[u].x = cur[u].y = prv[u].x = prv[u].y = 0; } }
+			for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u + lane; if (i <= last) cur[u] = A.a[i]; else { cur[u].x = cur[u].y = 0; } }
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
+			for (int u = 0; u < 8; ++u) {
 				const int i = i0 + 64 * u + lane;
+				const int32_t x = (int32_t)cur[u].x, y = (int32_t)cur[u].y;
+				const int32_t px = wave_shr1(x, cx), py = wave_shr1(y, cy);
 				if (i <= last) {
-					const int32_t dt = (int32_t)cur[u].x - (int32_t)prv[u].x, dq = (int32_t)cur[u].y - (int32_t)prv[u].y, sp = (int32_t)(cur[u].y >> 32 & 0xff);
+					const int32_t dt = x - px, dq = y - py, sp = (int32_t)(cur[u].y >> 32 & 0xff);
 					blk += (uint32_t)plan_max(dt, dq);
 					cov += (uint32_t)((dt > sp && dq > sp) ? sp : plan_min(dt, dq));
 				}
+				cx = __builtin_amdgcn_readlane(x, 63); cy = __builtin_amdgcn_readlane(y, 63);      // (only read by a later window, which exists only if this one was full)
 			}
 		}
 		r_mlen = (int32_t)((uint32_t)sp0 + (uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_sum_incl(cov), 63));
@@ -115,17 +120,25 @@ void k_plan_regions(const PlanIn *__restrict__ in, uint32_t n_regions, u128 *__r
 	}
 	// ---- long gaps of [as1, as1 + cnt1): chain-relative indices with |indel| > 10, in order ----
 	int n_g = 0;
-	for (int i0 = 1; i0 < cnt1; i0 += 256) {
-		int32_t g4[4];
+	{
+		// (the same streaming form: an anchor is loaded once, its predecessor comes from the neighbouring lane, eight windows in flight)
+		int32_t cx = (int32_t)A.a[as1].x, cy = (int32_t)A.a[as1].y;
+		for (int i0 = 1; i0 < cnt1; i0 += 512) {
+			u128 cur[8];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; g4[u] = i < cnt1 ? A.indel(as1 + i) : 0; }       // (four windows of loads in flight)
+			for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u + lane; if (i < cnt1) cur[u] = A.a[as1 + i]; else { cur[u].x = cur[u].y = 0; } }
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int i = i0 + 64 * u + lane;
-			const bool lg = i < cnt1 && (g4[u] < -10 || g4[u] > 10);
-			const unsigned long long m = __ballot(lg);
-			if (lg) { const int o = n_g + __popcll(m & ((1ULL << lane) - 1)); if (o < PLAN_G_MAX) s_G[o] = i; }
-			n_g += __popcll(m);
+			for (int u = 0; u < 8; ++u) {
+				const int i = i0 + 64 * u + lane;
+				const int32_t x = (int32_t)cur[u].x, y = (int32_t)cur[u].y;
+				const int32_t px = wave_shr1(x, cx), py = wave_shr1(y, cy);
+				const int32_t g = (y - py) - (x - px);                                         // A.indel(as1 + i)
+				const bool lg = i < cnt1 && (g < -10 || g > 10);
+				const unsigned long long m = __ballot(lg);
+				if (lg) { const int o = n_g + __popcll(m & ((1ULL << lane) - 1)); if (o < PLAN_G_MAX) s_G[o] = i; }
+				n_g += __popcll(m);
+				cx = __builtin_amdgcn_readlane(x, 63); cy = __builtin_amdgcn_readlane(y, 63);
+			}
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
