@@ -723,12 +723,9 @@ def main():
                      "any_kernel_busy_ms_per_step": busy.get("any", 0.0) / args.steps,
                      "whole_path": {"alg_bytes_per_step": alg_step, "achieved": alg_step / (ms_step * 1e-3) / 1e9, "frac": alg_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      "valu_issue_frac": valu_frac,
-                     "note": "kernel = largest summed HIP-event time (own stream); batches overlap, see busy_ms; traffic: profiles/ PMC passes, same unit as alg_bytes_per_launch; "
-                             "an integer DP kernel is bound by VALU issue, not by HBM or MFMA: bound valu = VALU wave-instructions/s (SQ_INSTS_VALU of the committed PMC pass / this "
-                             "run's summed launch time) against 1024 SIMDs x 2.4 GHz / 2; valu_model_frac = round 5's cells/s against a ceiling from the kernel's own cycles per cell "
-                             "(self-referential, kept for continuity); valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of its largest instantiation; rocprof_top_kernel = the "
-                             "largest kernel of the committed rocprofv3 --stats summary with both fractions; "
-                             "dispatches_per_step, resident_waves_per_simd: profiles/ (rocprofv3 passes of this workload, not this run)"},
+                     "note": "kernel = family with the largest summed HIP-event time; bound valu: VALU wave-instructions/s (SQ_INSTS_VALU of the committed PMC pass over this run's launch "
+                             "time) against 1024 SIMD-32 x 2.4 GHz / 2; valu_model_*: round 5's self-referential cell model; rocprof_top_kernel, traffic, dispatches, waves: from profiles/, "
+                             "not this run (DESIGN.md section 7)"},
         "n_matches_gathered": last["n_matches"],
         "build_sha256": build_sha,
         "resident_gbp_s": resident["gbp_s"] if resident else (units * args.steps / dt / 1e9 if inp["lib"] is not None else None),
