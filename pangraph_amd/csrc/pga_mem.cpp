@@ -171,8 +171,11 @@ void *dev_alloc(size_t bytes)
 			const size_t lim = cache_limit();                     // what idle blocks may hold beside the live ones
 			if (g_idle_total + r > lim) {
 				const size_t target = lim > r + ((size_t)2 << 30) ? lim - r - ((size_t)2 << 30) : 0;
-				while (g_idle_total > target && !g_idle_by_age.empty()) {
-					const IdleRef v = g_idle_by_age.begin()->second;
+				// (oldest first, blocks of THIS device only -- hipFree of another device's block would need that device current -- and at most 64 per miss:
+				// every hipFree synchronises the device)
+				for (auto at = g_idle_by_age.begin(); at != g_idle_by_age.end() && g_idle_total > target && drop.size() < 64;) {
+					const IdleRef v = at->second; ++at;
+					if (v.pool.first != dev) continue;
 					Pool &V = g_pools[v.pool];
 					auto rg = V.idle.equal_range(v.size);
 					for (auto jt = rg.first; jt != rg.second; ++jt) if (jt->second == v.p) { V.idle.erase(jt); break; }
@@ -218,8 +221,11 @@ void dev_free(void *p)
 			// device: not on every free from here on)
 			if (g_idle_total > cache_limit()) {
 				const size_t lim = cache_limit(), target = lim > ((size_t)4 << 30) ? lim - ((size_t)4 << 30) : 0;
-				while (g_idle_total > target && !g_idle_by_age.empty()) {
-					const IdleRef v = g_idle_by_age.begin()->second;
+				// (oldest first, blocks of THIS device only -- hipFree of another device's block would need that device current -- and at most 64 per call:
+				// every hipFree synchronises the device)
+				for (auto at = g_idle_by_age.begin(); at != g_idle_by_age.end() && g_idle_total > target && drop.size() < 64;) {
+					const IdleRef v = at->second; ++at;
+					if (v.pool.first != lv.dev) continue;
 					Pool &V = g_pools[v.pool];
 					auto rg = V.idle.equal_range(v.size);
 					for (auto jt = rg.first; jt != rg.second; ++jt) if (jt->second == v.p) { V.idle.erase(jt); break; }

@@ -45,10 +45,10 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def _run(extra_env):
+def _run(extra_env, tail=""):
     # (the runs are processes of their own beside a pytest process whose block cache may hold most of the device by now: each keeps to a fifth of it)
     env = dict(os.environ, PGA_MEM_SHARE="0.2", **extra_env)
-    r = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", SCRIPT + tail, ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     return json.loads(line[len("RESULT "):])
@@ -79,3 +79,25 @@ def test_small_sorts_of_the_chaining_stage_by_rocprim_give_the_records_of_the_wo
 
 def test_both_rocprim_routes_together():
     assert _run({"PGA_MAXOCC_HIST": "0", "PGA_WG_SORT": "0"}) == _base()
+
+
+def test_a_cache_of_one_gigabyte_evicts_and_trims_without_changing_a_record():
+    """pga_mem.cpp: with PGA_CACHE_GB=1 nearly every block a stage gives back is beyond the cache's limit -- the eviction loops of dev_alloc / dev_free run
+    (oldest idle blocks of the current device first, at most 64 hipFree per miss) all through the run, and pga_trim() at the end releases what is left: the
+    records are those of the default run, hipFree was really called, and after the trim the library holds (almost) nothing of the device."""
+    tail = r"""
+import ctypes
+dll2 = ctypes.CDLL(os.path.join(root, "pangraph_amd", "libpgalign.so"))
+st = (ctypes.c_int64 * 6)(); dll2.pga_mem_stats(st)
+dll2.pga_trim.restype = ctypes.c_int64
+freed = dll2.pga_trim()
+st2 = (ctypes.c_int64 * 6)(); dll2.pga_mem_stats(st2)
+print("MEM " + json.dumps({"hipFree_calls": int(st[2]), "trimmed": int(freed), "idle_after": int(st2[5])}))
+"""
+    env = dict(os.environ, PGA_MEM_SHARE="0.2", PGA_CACHE_GB="1")
+    r = subprocess.run([sys.executable, "-c", SCRIPT + tail, ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    mem = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("MEM ")][-1][len("MEM "):])
+    assert got == _base()
+    assert mem["hipFree_calls"] > 0 and mem["idle_after"] == 0, mem
