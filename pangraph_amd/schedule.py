@@ -310,11 +310,17 @@ def run_ready_set(tasks: List[Task], run_batch: Callable[[List[Task]], object], 
 
 
 # ---- the compiled host (pangraph_amd/host/build_driver.cpp): a build as a task file, its records back ------------------------------------
-def write_task_file(tasks: List[Task], path: str, sensitivity: int = 10, n_threads: int = 8) -> None:
-    """the calls of a build -- dependencies, block names, block sequences -- in the little-endian layout build_driver.cpp reads"""
+def write_task_file(tasks: List[Task], path: str, sensitivity: int = 10, n_threads: int = 8, pop=None) -> None:
+    """the calls of a build -- dependencies, block names, block sequences, and (pop given) the guide tree a host of several ranks cuts into subtrees -- in
+    the little-endian layout build_driver.cpp reads"""
     import struct
     with open(path, "wb") as f:
-        f.write(b"PGAB1\0\0\0" + struct.pack("<4i", len(tasks), sensitivity, n_threads, 0))
+        n_nodes = len(pop.nodes) if pop is not None else 0
+        f.write(b"PGAB1\0\0\0" + struct.pack("<4i", len(tasks), sensitivity, n_threads, n_nodes))
+        if n_nodes:
+            f.write(np.asarray([nd.children[0] if nd.children else -1 for nd in pop.nodes], dtype="<i4").tobytes())
+            f.write(np.asarray([nd.children[1] if nd.children else -1 for nd in pop.nodes], dtype="<i4").tobytes())
+            f.write(np.asarray([t.node for t in tasks], dtype="<i4").tobytes())
         for t in tasks:
             f.write(struct.pack("<i", len(t.deps)) + struct.pack(f"<{len(t.deps)}i", *t.deps) + struct.pack("<i", len(t.seqs)))
             for a, name in zip(t.seqs, t.names):

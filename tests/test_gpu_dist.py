@@ -304,3 +304,43 @@ def test_bench_c5_eight_ranks_on_one_device_every_call_vs_reference_digests_and_
     m = ph["measured_s"]
     assert m["phase1_s"] > 0 and m["phase2_s"] > 0 and ph["model_s"]["phase1_s"] > 0 and ph["model_s"]["calls_above_the_cut"] > 0
     assert 1e-3 * b["ms_per_step"] >= m["phase1_s"] + m["phase2_s"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,genomes,length", [(2, 12, 150_000), (5, 12, 150_000), (8, 40, 400_000)], ids=["2_ranks", "5_ranks_small_tree", "8_ranks_40_genomes"])
+def test_compiled_host_several_ranks_equal_the_single_rank_build(gpu_lib, tmp_path, world, genomes, length):
+    """pangraph_amd/host/build_driver.cpp as several ranks WITHOUT Python or torch in the ranks (PGA_RANK / PGA_WORLD / PGA_XDIR; here all on one device, a
+    share of its memory each): subtrees per rank under each rank's own ready-set schedule, one exchange, the calls above the cut by all ranks with the queries
+    of every group split (pga_batch_align_shard), a second exchange, pga_merge_match_lists on rank 0.  Every field of every record and every CIGAR of every
+    call equal the single-rank driver's (whose records are held against the Python host and, through it, against the reference elsewhere).  Five ranks on a
+    twelve-genome tree: ranks that own little or nothing, most calls above the cut; eight ranks on forty genomes of 0.4 Mbp: every rank owns subtrees."""
+    import subprocess
+    from conftest import ROOT
+    from pangraph_amd import schedule as sched
+    from pangraph_amd.levels import Population
+    exe = os.path.join(ROOT, "pangraph_amd", "host", "build_driver")
+    pop = Population(5, genomes, length)
+    tasks = sched.build_tasks(pop)
+    tf, o1, ow, xd = str(tmp_path / "tasks.bin"), str(tmp_path / "one.bin"), str(tmp_path / "many.bin"), tmp_path / "x"
+    xd.mkdir()
+    sched.write_task_file(tasks, tf, sensitivity=10, n_threads=4, pop=pop)
+    share = "%.3f" % (0.6 / (world + 1))
+    r = subprocess.run([exe, tf, o1, "6"], env=dict(os.environ, PGA_MEM_SHARE=share), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    procs = [subprocess.Popen([exe, tf, ow if k == 0 else str(tmp_path / f"unused{k}.bin"), "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, PGA_MEM_SHARE=share, PGA_RANK=str(k), PGA_WORLD=str(world), PGA_XDIR=str(xd), PGA_DEVICE="0")) for k in range(world)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[0][-500:] + o[1][-1500:] for o in outs]
+    one, _ = sched.read_driver_results(o1)
+    many, _ = sched.read_driver_results(ow)
+    assert len(one) == len(many) == len(tasks)
+    fields = [f for f in one[0][0].dtype.names if f not in ("cigar_off", "pad")]
+    n_rec = 0
+    for tid, ((m1, c1), (m2, c2)) in enumerate(zip(one, many)):
+        assert len(m1) == len(m2), (tid, len(m1), len(m2))
+        for a, b in zip(m1, m2):
+            assert all(a[f] == b[f] for f in fields), (tid, a, b)
+            assert (c1[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] == c2[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["n_cigar"])]).all(), tid
+        n_rec += len(m1)
+    owner, _ = sched.partition_subtrees(pop, tasks, world)
+    assert n_rec > len(tasks) and any(o < 0 for o in owner) and f"{world} ranks: {len(tasks)} calls ({sum(1 for o in owner if o < 0)} above the cut)" in outs[0][0]

@@ -345,3 +345,36 @@ def test_compiled_host_loop_without_a_device(product_so, tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe, tf, of], capture_output=True, text=True, timeout=120)
         assert r.returncode == 3 and "no HIP device" in r.stderr
+
+
+def test_compiled_host_with_several_ranks_without_a_device(product_so, tmp_path):
+    """build_driver as THREE ranks (PGA_RANK / PGA_WORLD / PGA_XDIR; three processes, PGA_DRIVER_DRY=1): every rank cuts the guide tree the task file
+    carries with pga_sched_partition, runs the calls of its subtrees under its own schedule, publishes its list, walks the calls above the cut level by
+    level and publishes again; rank 0 merges and writes the result file.  Every call is accounted for exactly once -- the per-rank counts are those of
+    schedule.partition_subtrees -- and a task file without the tree, or a rank outside the world, is refused."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "pangraph_amd", "host", "build_driver")
+    pop = _pop(24)
+    tasks = sched.build_tasks(pop)
+    tf, of, xd = str(tmp_path / "tasks.bin"), str(tmp_path / "out.bin"), tmp_path / "x"
+    xd.mkdir()
+    sched.write_task_file(tasks, tf, pop=pop)
+    world = 3
+    owner, _ = sched.partition_subtrees(pop, tasks, world)
+    procs = [subprocess.Popen([exe, tf, of if r == 0 else str(tmp_path / f"unused{r}.bin"), "2", "150000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, PGA_DRIVER_DRY="1", PGA_RANK=str(r), PGA_WORLD=str(world), PGA_XDIR=str(xd), PGA_XTIMEOUT_S="60")) for r in range(world)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1] for o in outs]
+    n_above = sum(1 for o in owner if o < 0)
+    assert f"{world} ranks: {len(tasks)} calls ({n_above} above the cut)" in outs[0][0], outs[0][0]
+    for r in range(1, world):
+        assert f"rank {r} of {world}: {sum(1 for o in owner if o == r)} calls of its own" in outs[r][0], outs[r][0]
+    res, _ = sched.read_driver_results(of)
+    assert len(res) == len(tasks) and not os.path.exists(tmp_path / "unused1.bin")
+    assert sorted(os.listdir(xd)) == sorted(f"phase{p}_{r}.bin" for p in (1, 2) for r in range(world))
+    sched.write_task_file(tasks, str(tmp_path / "notree.bin"))
+    env = dict(os.environ, PGA_DRIVER_DRY="1", PGA_RANK="0", PGA_WORLD="2", PGA_XDIR=str(xd))
+    assert subprocess.run([exe, str(tmp_path / "notree.bin"), of], env=env, capture_output=True, text=True).returncode == 2
+    assert subprocess.run([exe, tf, of], env=dict(env, PGA_RANK="2"), capture_output=True, text=True).returncode == 2
