@@ -841,14 +841,22 @@ void k_bt_list(int n_seq, const uint64_t *__restrict__ q_aoff, const int32_t *__
 	if (n == 0) return;
 	const int32_t *f = f_all + b; int32_t *t = t_all + b; u128 *z = z_all + b;
 	// candidate ends in index order (order-preserving compaction), marks cleared
+	// (one wave streams a whole-genome query's half a million scores: EIGHT windows of loads in flight per trip -- with one the loop was a load latency per 64
+	// anchors, 4.7 ms of a leaf batch's chain stage; the windows are compacted in order, so the list is the same)
 	int64_t n_z = 0;
-	for (int64_t i0 = 0; i0 < n; i0 += 64) {
-		const int64_t i = i0 + lane;
-		const bool keep = i < n && f[i] >= P.min_sc;
-		if (i < n) t[i] = 0;
-		const unsigned long long m = __ballot(keep);
-		if (keep) { const int64_t o = n_z + __popcll(m & ((1ULL << lane) - 1)); z[o].x = (uint64_t)f[i]; z[o].y = (uint64_t)i; }
-		n_z += __popcll(m);
+	for (int64_t i0 = 0; i0 < n; i0 += 512) {
+		int32_t fv[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { const int64_t i = i0 + 64 * u + lane; fv[u] = i < n ? f[i] : 0; }
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int64_t i = i0 + 64 * u + lane;
+			const bool keep = i < n && fv[u] >= P.min_sc;
+			if (i < n) t[i] = 0;
+			const unsigned long long m = __ballot(keep);
+			if (keep) { const int64_t o = n_z + __popcll(m & ((1ULL << lane) - 1)); z[o].x = (uint64_t)fv[u]; z[o].y = (uint64_t)i; }
+			n_z += __popcll(m);
+		}
 	}
 	if (lane == 0) n_z_out[q] = n_z;
 }
@@ -885,25 +893,26 @@ void k_bt_walk(int n_seq, const uint64_t *__restrict__ q_aoff, const u128 *__res
 	// set needs nothing.  The candidates of the batch after next and the marks of the next batch are requested while this one is looked at
 	// (two dependent loads, ~2 us, per batch otherwise); marks are only ever set, so a mark read early can only err towards "look again".
 	auto load_z = [&](int64_t kb_, int32_t &f_, int32_t &i_) { const int64_t km = kb_ - 1 - lane; f_ = 0; i_ = -1; if (kb_ > 0 && km >= 0) { const u128 e = z[km]; f_ = (int32_t)e.x; i_ = (int32_t)e.y; } };
-	// FOUR batches per trip: their candidates and then their marks are four independent loads per lane, so a trip costs about two memory round
-	// trips for 256 candidates instead of one and a half for 64 (a whole-genome query holds 300 k candidates, nearly all of them marked)
-	int32_t zfA[4], ziA[4], tmA[4], zfB[4], ziB[4];
+	// EIGHT batches per trip (four until round 6): their candidates and then their marks are eight independent loads per lane, so a trip costs about two
+	// memory round trips for 512 candidates instead of one and a half for 64 (a whole-genome query holds 300 k candidates, nearly all of them marked)
+	constexpr int NB = 8;
+	int32_t zfA[NB], ziA[NB], tmA[NB], zfB[NB], ziB[NB];
 #pragma unroll
-	for (int s4 = 0; s4 < 4; ++s4) load_z(n_z - 64 * s4, zfA[s4], ziA[s4]);
+	for (int s4 = 0; s4 < NB; ++s4) load_z(n_z - 64 * s4, zfA[s4], ziA[s4]);
 #pragma unroll
-	for (int s4 = 0; s4 < 4; ++s4) load_z(n_z - 256 - 64 * s4, zfB[s4], ziB[s4]);
+	for (int s4 = 0; s4 < NB; ++s4) load_z(n_z - 64 * NB - 64 * s4, zfB[s4], ziB[s4]);
 #pragma unroll
-	for (int s4 = 0; s4 < 4; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }
-	for (int64_t kb4 = n_z; kb4 > 0; kb4 -= 256) {
-		int32_t zfC[4], ziC[4], tmC[4]; ++pc_trips;
+	for (int s4 = 0; s4 < NB; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }
+	for (int64_t kb4 = n_z; kb4 > 0; kb4 -= 64 * NB) {
+		int32_t zfC[NB], ziC[NB], tmC[NB]; ++pc_trips;
 #pragma unroll
-		for (int s4 = 0; s4 < 4; ++s4) { zfC[s4] = zfA[s4]; ziC[s4] = ziA[s4]; tmC[s4] = tmA[s4]; zfA[s4] = zfB[s4]; ziA[s4] = ziB[s4]; }
+		for (int s4 = 0; s4 < NB; ++s4) { zfC[s4] = zfA[s4]; ziC[s4] = ziA[s4]; tmC[s4] = tmA[s4]; zfA[s4] = zfB[s4]; ziA[s4] = ziB[s4]; }
 #pragma unroll
-		for (int s4 = 0; s4 < 4; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }      // (early: re-read below whenever it says "unmarked")
+		for (int s4 = 0; s4 < NB; ++s4) { tmA[s4] = 1; if (ziA[s4] >= 0) tmA[s4] = t[ziA[s4]]; }      // (early: re-read below whenever it says "unmarked")
 #pragma unroll
-		for (int s4 = 0; s4 < 4; ++s4) load_z(kb4 - 512 - 64 * s4, zfB[s4], ziB[s4]);
+		for (int s4 = 0; s4 < NB; ++s4) load_z(kb4 - 2 * 64 * NB - 64 * s4, zfB[s4], ziB[s4]);
 #pragma unroll
-	for (int s4 = 0; s4 < 4; ++s4) {
+	for (int s4 = 0; s4 < NB; ++s4) {
 		const int64_t kb = kb4 - 64 * s4;
 		if (kb <= 0) break;
 		// a batch of 64 candidates, highest rank in lane 0
